@@ -1,0 +1,99 @@
+/*
+ * skyrim_pangu.h -- C ABI of the MI355X (gfx950) Pangu-Weather 6-h step engine.
+ *
+ * Drop-in boundary.  The reference has no C ABI: its seam is the duck-typed earth2mip
+ * ``TimeLoop`` object returned by ``PanguModel.build_model()``
+ * (/root/reference/skyrim/core/models/pangu.py:45-46) and driven by ``run_basic_inference``
+ * (/root/reference/skyrim/core/models/utils.py:34: ``for k, (time, output, _) in enumerate(model(time, x))``).
+ * One iteration of that generator is one call of skpangu_step() here; the Python object that
+ * re-creates the TimeLoop protocol on top of this library is skyrim_amd/pangu/engine.py
+ * (see INTEGRATION.md for the binding a reference maintainer would add).
+ *
+ * Conventions
+ *   - every pointer argument named *_dev is DEVICE memory owned by the caller; the library never
+ *     allocates, frees or synchronises.  ``stream`` is a hipStream_t passed as void*; all work is
+ *     stream-ordered and re-entrant across contexts.
+ *   - state tensors are float32 [69][n_lat][n_lon], channel order of
+ *     /root/reference/skyrim/core/models/pangu.py:6-13 (z,q,t,u,v x 1000..50 hPa, then msl,u10m,v10m,t2m),
+ *     lat 90..-90, lon 0..360, physical units (normalisation constants are model parameters).
+ *   - return value: 0 on success, a positive hipError_t from the runtime, or a negative SKPANGU_E_*.
+ */
+#ifndef SKYRIM_PANGU_H
+#define SKYRIM_PANGU_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SKPANGU_ABI_VERSION 1
+
+/* precision modes: how each matrix product is formed on the MFMA pipe */
+#define SKPANGU_PREC_BF16X3 0 /* bf16 hi/lo split, 3 MFMA terms, fp32-class results (default; meets the 1e-3 bar) */
+#define SKPANGU_PREC_F16    1 /* single fp16 term (fast; ~1e-3 relative error per step) */
+
+#define SKPANGU_E_ARG        (-1) /* bad argument / unsupported geometry */
+#define SKPANGU_E_SIZE       (-2) /* a caller buffer is too small */
+#define SKPANGU_E_STATE      (-3) /* skpangu_prepare() has not run */
+#define SKPANGU_E_NOTFOUND   (-4)
+
+typedef struct skpangu_ctx skpangu_ctx;
+
+typedef struct skpangu_config {
+    int n_lat;     /* 721; any n_lat >= 8 */
+    int n_lon;     /* 1440; must be a multiple of 96 */
+    int precision; /* SKPANGU_PREC_* */
+} skpangu_config;
+
+typedef struct skpangu_sizes {
+    long long master_floats;   /* elements of the fp32 master parameter blob (skpangu_param_info layout) */
+    size_t prepared_bytes;     /* kernel-ready parameter arena (16-bit weight planes, expanded bias, tables) */
+    size_t workspace_bytes;    /* activations of one step (residual streams, Q/K/V, MLP hidden) */
+    long long state_floats;    /* 69 * n_lat * n_lon */
+    int n_params;              /* entries of the master parameter table */
+} skpangu_sizes;
+
+int skpangu_abi_version(void);
+const char* skpangu_error_string(int code);
+
+/* Buffer sizes for a configuration; no GPU needed. */
+int skpangu_query_sizes(const skpangu_config* cfg, skpangu_sizes* out);
+
+/* Master parameter table (the fp32 blob handed to skpangu_prepare): entry i is tensor ``name`` with
+ * ``ndim`` dims ``shape`` at element offset ``offset``.  Names mirror a PyTorch state dict of the public
+ * Pangu pseudocode (e.g. "layer2.block3.attn.qkv.weight").  No GPU needed. */
+int skpangu_param_info(const skpangu_config* cfg, int index, char* name, size_t name_cap,
+                       long long* offset, int* ndim, long long shape[6]);
+
+/* Create a context over caller-owned device buffers (sizes from skpangu_query_sizes). */
+int skpangu_create(const skpangu_config* cfg, void* prepared_dev, size_t prepared_bytes,
+                   void* workspace_dev, size_t workspace_bytes, skpangu_ctx** out);
+void skpangu_destroy(skpangu_ctx* ctx);
+
+/* One-time conversion of the fp32 master blob into the prepared arena (weight hi/lo planes,
+ * earth-specific bias expanded per window type with the shifted-window mask folded in, window
+ * gather tables).  Replaces the ONNX-session construction of earth2mip.networks.pangu.load. */
+int skpangu_prepare(skpangu_ctx* ctx, const float* master_dev, void* stream);
+
+/* One 6-h forecast step: state_out = Pangu6(state_in).  In-place (state_out == state_in) is allowed.
+ * Replaces one iteration of the reference's TimeLoop generator (models/utils.py:34). */
+int skpangu_step(skpangu_ctx* ctx, const float* state_in_dev, float* state_out_dev, void* stream);
+
+/* Stage-level entry points (same kernels as skpangu_step; used by the parity tests).
+ * Token tensors are float32 row-major [tokens][channels]:
+ *   x1/x4/skip: [8*H1*W1][192]   x2: [8*H2*W2][384] */
+int skpangu_patch_embed(skpangu_ctx* ctx, const float* state_in_dev, float* x1_dev, void* stream);
+int skpangu_block(skpangu_ctx* ctx, int layer /*1..4*/, int block, float* x_inout_dev, void* stream);
+int skpangu_downsample(skpangu_ctx* ctx, const float* x1_dev, float* x2_dev, void* stream);
+int skpangu_upsample(skpangu_ctx* ctx, const float* x2_dev, float* x4_dev, void* stream);
+int skpangu_patch_recover(skpangu_ctx* ctx, const float* skip_dev, const float* x4_dev, float* state_out_dev, void* stream);
+
+/* Debug view of an internal buffer ("q","k","vt","ao","hid","u","x1","x2","x4","widx<res><roll>",
+ * "bias_exp<blk>").  The pointer stays owned by the context's arenas. */
+int skpangu_debug_buffer(skpangu_ctx* ctx, const char* name, void** ptr_dev, size_t* bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SKYRIM_PANGU_H */

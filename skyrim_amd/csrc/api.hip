@@ -1,0 +1,442 @@
+// C ABI (include/skyrim_pangu.h) over the stage launchers: geometry, master-parameter table,
+// arena planning, prepare, and the fixed launch sequence of one Pangu 6-h step.
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/skyrim_pangu.h"
+#include "launchers.h"
+
+using namespace skp;
+
+namespace {
+
+constexpr int kDepths[4] = {2, 6, 6, 2};
+constexpr int kBiasRows = 3312;
+
+int pad_to(int n, int mult, int* front) {
+    const int padded = (n + mult - 1) / mult * mult;
+    if (front) *front = (padded - n) / 2;
+    return padded;
+}
+
+bool make_geom(const skpangu_config& c, Geom& g) {
+    if (c.n_lat < 8 || c.n_lon <= 0 || c.n_lon % 96 != 0) return false;
+    g.n_lat = c.n_lat; g.n_lon = c.n_lon; g.n_levels = 13; g.n_channels = 69; g.surf0 = 65;
+    const int latp = pad_to(c.n_lat, 4, &g.lat_top);
+    g.Z = 8; g.H1 = latp / 4; g.W1 = c.n_lon / 4;
+    g.H2 = pad_to(g.H1, 2, nullptr) / 2; g.W2 = g.W1 / 2;
+    const int H[2] = {g.H1, g.H2}, W[2] = {g.W1, g.W2};
+    for (int r = 0; r < 2; ++r) {
+        g.Hp[r] = pad_to(H[r], 6, &g.top[r]);
+        g.nH[r] = g.Hp[r] / 6; g.nW[r] = W[r] / 12;
+        g.types[r] = (g.Z / 2) * g.nH[r];
+        g.nwin[r] = g.types[r] * g.nW[r];
+        g.ntok[r] = g.Z * H[r] * W[r];
+        g.mwin[r] = g.nwin[r] * WIN_TOKENS;
+    }
+    return true;
+}
+
+struct Param { std::string name; std::vector<long long> shape; long long offset; long long numel; };
+
+std::vector<Param> build_params(const Geom& g, long long* total) {
+    std::vector<Param> v;
+    long long off = 0;
+    auto add = [&](const std::string& n, std::vector<long long> s) {
+        long long ne = 1;
+        for (long long d : s) ne *= d;
+        v.push_back(Param{n, s, off, ne});
+        off += (ne + 63) / 64 * 64;
+    };
+    add("norm.mean", {69}); add("norm.std", {69});
+    add("const_masks", {3, g.n_lat, g.n_lon});
+    add("embed.conv.weight", {192, 5, 2, 4, 4}); add("embed.conv.bias", {192});
+    add("embed.conv_surface.weight", {192, 7, 4, 4}); add("embed.conv_surface.bias", {192});
+    for (int layer = 0; layer < 4; ++layer) {
+        const int c = layer_dim(layer), heads = layer_heads(layer), types = g.types[layer_res(layer)];
+        for (int i = 0; i < kDepths[layer]; ++i) {
+            const std::string p = "layer" + std::to_string(layer + 1) + ".block" + std::to_string(i) + ".";
+            add(p + "attn.bias_table", {kBiasRows, types, heads});
+            add(p + "attn.qkv.weight", {3 * c, c}); add(p + "attn.qkv.bias", {3 * c});
+            add(p + "attn.proj.weight", {c, c}); add(p + "attn.proj.bias", {c});
+            add(p + "norm1.weight", {c}); add(p + "norm1.bias", {c});
+            add(p + "mlp.fc1.weight", {4 * c, c}); add(p + "mlp.fc1.bias", {4 * c});
+            add(p + "mlp.fc2.weight", {c, 4 * c}); add(p + "mlp.fc2.bias", {c});
+            add(p + "norm2.weight", {c}); add(p + "norm2.bias", {c});
+        }
+        if (layer == 0) { add("down.norm.weight", {768}); add("down.norm.bias", {768}); add("down.linear.weight", {384, 768}); }
+        if (layer == 2) { add("up.linear1.weight", {768, 384}); add("up.norm.weight", {192}); add("up.norm.bias", {192}); add("up.linear2.weight", {192, 192}); }
+    }
+    add("recover.conv.weight", {384, 5, 2, 4, 4}); add("recover.conv.bias", {5});
+    add("recover.conv_surface.weight", {384, 4, 4, 4}); add("recover.conv_surface.bias", {4});
+    if (total) *total = off;
+    return v;
+}
+
+struct Arena {
+    char* base;
+    size_t off;
+    template <class U> U* take(size_t n) {
+        off = (off + 255) / 256 * 256;
+        U* p = base ? reinterpret_cast<U*>(base + off) : nullptr;
+        off += n * sizeof(U);
+        return p;
+    }
+};
+
+struct IEngine {
+    virtual ~IEngine() {}
+    virtual hipError_t prepare(const float* master, hipStream_t s) = 0;
+    virtual hipError_t step(const float* in, float* out, hipStream_t s) = 0;
+    virtual hipError_t embed(const float* in, float* x1, hipStream_t s) = 0;
+    virtual hipError_t block(int layer, int blk, float* x, hipStream_t s) = 0;
+    virtual hipError_t down(const float* x1, float* x2, hipStream_t s) = 0;
+    virtual hipError_t up(const float* x2, float* x4, hipStream_t s) = 0;
+    virtual hipError_t recover(const float* skip, const float* x4, float* out, hipStream_t s) = 0;
+    virtual bool debug(const std::string& name, void** p, size_t* bytes) = 0;
+    virtual size_t prepared_bytes() const = 0;
+    virtual size_t workspace_bytes() const = 0;
+};
+
+template <class P>
+struct Engine : IEngine {
+    typedef typename P::T T;
+    typedef typename ActT<P>::type S;
+    static constexpr int NW = P::NW;
+    static constexpr int NPL = (P::NA > P::NW ? P::NA : P::NW);
+
+    Geom g;
+    ModelW<T> w;
+    Work<P> wk;
+    std::vector<Param> params;
+    size_t prep_bytes = 0, ws_bytes = 0;
+    size_t bias_exp_elems[16];
+    size_t q_elems = 0, ao_elems = 0, hid_elems = 0;
+
+    LinW<T> take_lin(Arena& a, int N, int ldd) {
+        LinW<T> l;
+        const long long plane = (long long)N * ldd;
+        l.w = a.take<T>((size_t)plane * NW);
+        l.plane = plane; l.ldw = ldd;
+        return l;
+    }
+
+    void plan_prepared(char* base) {
+        Arena a{base, 0};
+        w.mean = a.take<float>(69); w.std = a.take<float>(69); w.istd = a.take<float>(69);
+        w.masks = a.take<float>((size_t)3 * g.n_lat * g.n_lon);
+        w.embed_u = take_lin(a, 192, 160); w.embed_s = take_lin(a, 192, 128);
+        w.embed_u_b = a.take<float>(192); w.embed_s_b = a.take<float>(192);
+        int b = 0;
+        for (int layer = 0; layer < 4; ++layer) {
+            const int c = layer_dim(layer), heads = layer_heads(layer), res = layer_res(layer);
+            for (int i = 0; i < kDepths[layer]; ++i, ++b) {
+                BlockW<T>& bw = w.blk[b];
+                bw.qkv = take_lin(a, 3 * c, c); bw.proj = take_lin(a, c, c);
+                bw.fc1 = take_lin(a, 4 * c, c); bw.fc2 = take_lin(a, c, 4 * c);
+                bw.qkv_b = a.take<float>(3 * c); bw.proj_b = a.take<float>(c);
+                bw.fc1_b = a.take<float>(4 * c); bw.fc2_b = a.take<float>(c);
+                bw.n1_g = a.take<float>(c); bw.n1_b = a.take<float>(c);
+                bw.n2_g = a.take<float>(c); bw.n2_b = a.take<float>(c);
+                bias_exp_elems[b] = (size_t)g.types[res] * heads * 81 * 256;
+                bw.bias_exp = a.take<f16>(bias_exp_elems[b]);
+            }
+        }
+        w.down_g = a.take<float>(768); w.down_b = a.take<float>(768);
+        w.down = take_lin(a, 384, 768);
+        w.up1 = take_lin(a, 768, 384); w.up2 = take_lin(a, 192, 192);
+        w.up_g = a.take<float>(192); w.up_b = a.take<float>(192);
+        w.rec_u = take_lin(a, 160, 384); w.rec_s = take_lin(a, 64, 384);
+        w.rec_u_b = a.take<float>(5); w.rec_s_b = a.take<float>(4);
+        for (int r = 0; r < 2; ++r)
+            for (int roll = 0; roll < 2; ++roll) w.widx[r][roll] = a.take<int>(g.mwin[r]);
+        prep_bytes = (a.off + 255) / 256 * 256;
+    }
+
+    void plan_workspace(char* base) {
+        Arena a{base, 0};
+        wk.X1 = a.take<float>((size_t)g.ntok[0] * 192);
+        wk.X2 = a.take<float>((size_t)g.ntok[1] * 384);
+        wk.X4 = a.take<float>((size_t)g.ntok[0] * 192);
+        const size_t m0 = (size_t)g.mwin[0] * 192, m1 = (size_t)g.mwin[1] * 384;
+        q_elems = m0 > m1 ? m0 : m1;
+        wk.qkv_plane = (long long)q_elems;
+        wk.q = a.take<T>(q_elems * NPL); wk.k = a.take<T>(q_elems * NPL); wk.vt = a.take<T>(q_elems * NPL);
+        ao_elems = q_elems;
+        wk.ao = a.take<S>(ao_elems);
+        const size_t h0 = (size_t)g.ntok[0] * 768, h1 = (size_t)g.ntok[1] * 1536;
+        hid_elems = h0 > h1 ? h0 : h1;
+        wk.hid = a.take<S>(hid_elems);
+        wk.u = a.take<S>((size_t)g.ntok[0] * 192);
+        wk.stats = a.take<float2>((size_t)g.ntok[1]);
+        ws_bytes = (a.off + 255) / 256 * 256;
+    }
+
+    explicit Engine(const Geom& geom) : g(geom) {
+        params = build_params(g, nullptr);
+        plan_prepared(nullptr);
+        plan_workspace(nullptr);
+    }
+    size_t prepared_bytes() const override { return prep_bytes; }
+    size_t workspace_bytes() const override { return ws_bytes; }
+
+    const float* P_(const float* master, const std::string& name) const {
+        for (const Param& p : params)
+            if (p.name == name) return master + p.offset;
+        return nullptr;
+    }
+    hipError_t copyf(const float* dst, const float* src, size_t n, hipStream_t s) {
+        return hipMemcpyAsync(const_cast<float*>(dst), src, n * sizeof(float), hipMemcpyDeviceToDevice, s);
+    }
+    hipError_t lin(const LinW<T>& l, const float* src, int N, int K, long long sn, long long sk, hipStream_t s) {
+        return prep_weight<T, NW>(src, const_cast<T*>(l.w), l.plane, N, K, l.ldw, sn, sk, s);
+    }
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return e_; } while (0)
+
+    hipError_t prepare(const float* m, hipStream_t s) override {
+        CK(copyf(w.mean, P_(m, "norm.mean"), 69, s));
+        CK(copyf(w.std, P_(m, "norm.std"), 69, s));
+        CK(prep_reciprocal(P_(m, "norm.std"), const_cast<float*>(w.istd), 69, s));
+        CK(copyf(w.masks, P_(m, "const_masks"), (size_t)3 * g.n_lat * g.n_lon, s));
+        CK(lin(w.embed_u, P_(m, "embed.conv.weight"), 192, 160, 160, 1, s));
+        CK(lin(w.embed_s, P_(m, "embed.conv_surface.weight"), 192, 112, 112, 1, s));
+        CK(copyf(w.embed_u_b, P_(m, "embed.conv.bias"), 192, s));
+        CK(copyf(w.embed_s_b, P_(m, "embed.conv_surface.bias"), 192, s));
+        int b = 0;
+        for (int layer = 0; layer < 4; ++layer) {
+            const int c = layer_dim(layer), heads = layer_heads(layer), res = layer_res(layer);
+            for (int i = 0; i < kDepths[layer]; ++i, ++b) {
+                const std::string p = "layer" + std::to_string(layer + 1) + ".block" + std::to_string(i) + ".";
+                const BlockW<T>& bw = w.blk[b];
+                CK(lin(bw.qkv, P_(m, p + "attn.qkv.weight"), 3 * c, c, c, 1, s));
+                CK(lin(bw.proj, P_(m, p + "attn.proj.weight"), c, c, c, 1, s));
+                CK(lin(bw.fc1, P_(m, p + "mlp.fc1.weight"), 4 * c, c, c, 1, s));
+                CK(lin(bw.fc2, P_(m, p + "mlp.fc2.weight"), c, 4 * c, 4 * c, 1, s));
+                CK(copyf(bw.qkv_b, P_(m, p + "attn.qkv.bias"), 3 * c, s));
+                CK(copyf(bw.proj_b, P_(m, p + "attn.proj.bias"), c, s));
+                CK(copyf(bw.fc1_b, P_(m, p + "mlp.fc1.bias"), 4 * c, s));
+                CK(copyf(bw.fc2_b, P_(m, p + "mlp.fc2.bias"), c, s));
+                CK(copyf(bw.n1_g, P_(m, p + "norm1.weight"), c, s));
+                CK(copyf(bw.n1_b, P_(m, p + "norm1.bias"), c, s));
+                CK(copyf(bw.n2_g, P_(m, p + "norm2.weight"), c, s));
+                CK(copyf(bw.n2_b, P_(m, p + "norm2.bias"), c, s));
+                CK(prep_bias_expand(P_(m, p + "attn.bias_table"), const_cast<f16*>(bw.bias_exp), g.types[res], heads, g.nH[res], i & 1, s));
+            }
+        }
+        CK(copyf(w.down_g, P_(m, "down.norm.weight"), 768, s));
+        CK(copyf(w.down_b, P_(m, "down.norm.bias"), 768, s));
+        CK(lin(w.down, P_(m, "down.linear.weight"), 384, 768, 768, 1, s));
+        CK(lin(w.up1, P_(m, "up.linear1.weight"), 768, 384, 384, 1, s));
+        CK(lin(w.up2, P_(m, "up.linear2.weight"), 192, 192, 192, 1, s));
+        CK(copyf(w.up_g, P_(m, "up.norm.weight"), 192, s));
+        CK(copyf(w.up_b, P_(m, "up.norm.bias"), 192, s));
+        // ConvTranspose weights are [K = 384][N]; the GEMM wants [N][K]
+        CK(lin(w.rec_u, P_(m, "recover.conv.weight"), 160, 384, 1, 160, s));
+        CK(lin(w.rec_s, P_(m, "recover.conv_surface.weight"), 64, 384, 1, 64, s));
+        CK(copyf(w.rec_u_b, P_(m, "recover.conv.bias"), 5, s));
+        CK(copyf(w.rec_s_b, P_(m, "recover.conv_surface.bias"), 4, s));
+        const int H[2] = {g.H1, g.H2}, W[2] = {g.W1, g.W2};
+        for (int r = 0; r < 2; ++r)
+            for (int roll = 0; roll < 2; ++roll)
+                CK(prep_window_index(const_cast<int*>(w.widx[r][roll]), g.Z, H[r], W[r], g.Hp[r], g.top[r], roll, s));
+        return hipSuccess;
+    }
+
+    static int block_index(int layer0, int i) {
+        int b = 0;
+        for (int l = 0; l < layer0; ++l) b += kDepths[l];
+        return b + i;
+    }
+
+    hipError_t block(int layer0, int i, float* x, hipStream_t s) override {
+        const int res = layer_res(layer0), C = layer_dim(layer0), heads = layer_heads(layer0);
+        const BlockW<T>& bw = w.blk[block_index(layer0, i)];
+        const int* widx = w.widx[res][i & 1];
+        CK((op_qkv<P>(g, bw, widx, res, x, wk, s)));
+        AttnArgs<P> a{wk.q, wk.k, wk.vt, wk.qkv_plane, bw.bias_exp, wk.ao, C, g.nwin[res], g.nW[res], heads};
+        CK(launch_attention<P>(a, s));
+        CK((op_proj<P>(g, bw, widx, res, x, wk, s)));
+        CK((op_fc1<P>(g, bw, res, x, wk, s)));
+        CK((op_fc2<P>(g, bw, res, x, wk, s)));
+        return hipSuccess;
+    }
+    hipError_t embed(const float* in, float* x1, hipStream_t s) override { return op_embed<P>(g, w, in, x1, s); }
+    hipError_t down(const float* x1, float* x2, hipStream_t s) override { return op_down<P>(g, w, x1, x2, wk, s); }
+    hipError_t up(const float* x2, float* x4, hipStream_t s) override { return op_up<P>(g, w, x2, x4, wk, s); }
+    hipError_t recover(const float* skip, const float* x4, float* out, hipStream_t s) override { return op_recover<P>(g, w, skip, x4, out, s); }
+
+    hipError_t step(const float* in, float* out, hipStream_t s) override {
+        CK(embed(in, wk.X1, s));
+        for (int i = 0; i < kDepths[0]; ++i) CK(block(0, i, wk.X1, s));
+        CK(down(wk.X1, wk.X2, s));
+        for (int i = 0; i < kDepths[1]; ++i) CK(block(1, i, wk.X2, s));
+        for (int i = 0; i < kDepths[2]; ++i) CK(block(2, i, wk.X2, s));
+        CK(up(wk.X2, wk.X4, s));
+        for (int i = 0; i < kDepths[3]; ++i) CK(block(3, i, wk.X4, s));
+        CK(recover(wk.X1, wk.X4, out, s));
+        return hipSuccess;
+    }
+#undef CK
+
+    bool debug(const std::string& n, void** p, size_t* bytes) override {
+        auto set = [&](const void* ptr, size_t b) { *p = const_cast<void*>(ptr); *bytes = b; return true; };
+        if (n == "q") return set(wk.q, q_elems * NPL * sizeof(T));
+        if (n == "k") return set(wk.k, q_elems * NPL * sizeof(T));
+        if (n == "vt") return set(wk.vt, q_elems * NPL * sizeof(T));
+        if (n == "ao") return set(wk.ao, ao_elems * sizeof(S));
+        if (n == "hid") return set(wk.hid, hid_elems * sizeof(S));
+        if (n == "u") return set(wk.u, (size_t)g.ntok[0] * 192 * sizeof(S));
+        if (n == "x1") return set(wk.X1, (size_t)g.ntok[0] * 192 * 4);
+        if (n == "x2") return set(wk.X2, (size_t)g.ntok[1] * 384 * 4);
+        if (n == "x4") return set(wk.X4, (size_t)g.ntok[0] * 192 * 4);
+        if (n.rfind("widx", 0) == 0 && n.size() == 6) {
+            const int r = n[4] - '0', roll = n[5] - '0';
+            if (r < 0 || r > 1 || roll < 0 || roll > 1) return false;
+            return set(w.widx[r][roll], (size_t)g.mwin[r] * 4);
+        }
+        if (n.rfind("bias_exp", 0) == 0) {
+            const int b = atoi(n.c_str() + 8);
+            if (b < 0 || b > 15) return false;
+            return set(w.blk[b].bias_exp, bias_exp_elems[b] * sizeof(f16));
+        }
+        return false;
+    }
+};
+
+IEngine* make_engine(const skpangu_config& cfg, const Geom& g) {
+    switch (cfg.precision) {
+        case SKPANGU_PREC_BF16X3: return new Engine<PrecBF16x3>(g);
+        case SKPANGU_PREC_F16: return new Engine<PrecF16>(g);
+        default: return nullptr;
+    }
+}
+
+}  // namespace
+
+struct skpangu_ctx {
+    skpangu_config cfg;
+    Geom g;
+    IEngine* eng;
+    bool prepared;
+};
+
+extern "C" {
+
+int skpangu_abi_version(void) { return SKPANGU_ABI_VERSION; }
+
+const char* skpangu_error_string(int code) {
+    switch (code) {
+        case 0: return "success";
+        case SKPANGU_E_ARG: return "bad argument or unsupported geometry";
+        case SKPANGU_E_SIZE: return "caller buffer too small";
+        case SKPANGU_E_STATE: return "context not prepared";
+        case SKPANGU_E_NOTFOUND: return "not found";
+        default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown error";
+    }
+}
+
+int skpangu_query_sizes(const skpangu_config* cfg, skpangu_sizes* out) {
+    if (!cfg || !out) return SKPANGU_E_ARG;
+    Geom g;
+    if (!make_geom(*cfg, g)) return SKPANGU_E_ARG;
+    IEngine* e = make_engine(*cfg, g);
+    if (!e) return SKPANGU_E_ARG;
+    long long total = 0;
+    std::vector<Param> p = build_params(g, &total);
+    out->master_floats = total;
+    out->prepared_bytes = e->prepared_bytes();
+    out->workspace_bytes = e->workspace_bytes();
+    out->state_floats = 69LL * g.n_lat * g.n_lon;
+    out->n_params = (int)p.size();
+    delete e;
+    return 0;
+}
+
+int skpangu_param_info(const skpangu_config* cfg, int index, char* name, size_t name_cap, long long* offset, int* ndim, long long shape[6]) {
+    if (!cfg) return SKPANGU_E_ARG;
+    Geom g;
+    if (!make_geom(*cfg, g)) return SKPANGU_E_ARG;
+    std::vector<Param> p = build_params(g, nullptr);
+    if (index < 0 || index >= (int)p.size()) return SKPANGU_E_NOTFOUND;
+    const Param& q = p[index];
+    if (name && name_cap) { std::strncpy(name, q.name.c_str(), name_cap - 1); name[name_cap - 1] = 0; }
+    if (offset) *offset = q.offset;
+    if (ndim) *ndim = (int)q.shape.size();
+    if (shape) for (size_t i = 0; i < q.shape.size() && i < 6; ++i) shape[i] = q.shape[i];
+    return 0;
+}
+
+int skpangu_create(const skpangu_config* cfg, void* prepared_dev, size_t prepared_bytes, void* workspace_dev, size_t workspace_bytes, skpangu_ctx** out) {
+    if (!cfg || !out || !prepared_dev || !workspace_dev) return SKPANGU_E_ARG;
+    Geom g;
+    if (!make_geom(*cfg, g)) return SKPANGU_E_ARG;
+    IEngine* e = make_engine(*cfg, g);
+    if (!e) return SKPANGU_E_ARG;
+    if (prepared_bytes < e->prepared_bytes() || workspace_bytes < e->workspace_bytes()) { delete e; return SKPANGU_E_SIZE; }
+    if (((uintptr_t)prepared_dev & 255) || ((uintptr_t)workspace_dev & 255)) { delete e; return SKPANGU_E_ARG; }
+    if (cfg->precision == SKPANGU_PREC_BF16X3) {
+        auto* t = static_cast<Engine<PrecBF16x3>*>(e);
+        t->plan_prepared((char*)prepared_dev); t->plan_workspace((char*)workspace_dev);
+    } else {
+        auto* t = static_cast<Engine<PrecF16>*>(e);
+        t->plan_prepared((char*)prepared_dev); t->plan_workspace((char*)workspace_dev);
+    }
+    skpangu_ctx* c = new skpangu_ctx{*cfg, g, e, false};
+    *out = c;
+    return 0;
+}
+
+void skpangu_destroy(skpangu_ctx* ctx) {
+    if (!ctx) return;
+    delete ctx->eng;
+    delete ctx;
+}
+
+int skpangu_prepare(skpangu_ctx* ctx, const float* master_dev, void* stream) {
+    if (!ctx || !master_dev) return SKPANGU_E_ARG;
+    const int e = (int)ctx->eng->prepare(master_dev, (hipStream_t)stream);
+    if (e == 0) ctx->prepared = true;
+    return e;
+}
+
+#define NEED_PREPARED() do { if (!ctx) return SKPANGU_E_ARG; if (!ctx->prepared) return SKPANGU_E_STATE; } while (0)
+
+int skpangu_step(skpangu_ctx* ctx, const float* in, float* out, void* stream) {
+    NEED_PREPARED();
+    if (!in || !out) return SKPANGU_E_ARG;
+    return (int)ctx->eng->step(in, out, (hipStream_t)stream);
+}
+int skpangu_patch_embed(skpangu_ctx* ctx, const float* in, float* x1, void* stream) {
+    NEED_PREPARED();
+    if (!in || !x1) return SKPANGU_E_ARG;
+    return (int)ctx->eng->embed(in, x1, (hipStream_t)stream);
+}
+int skpangu_block(skpangu_ctx* ctx, int layer, int block, float* x, void* stream) {
+    NEED_PREPARED();
+    if (!x || layer < 1 || layer > 4 || block < 0 || block >= kDepths[layer - 1]) return SKPANGU_E_ARG;
+    return (int)ctx->eng->block(layer - 1, block, x, (hipStream_t)stream);
+}
+int skpangu_downsample(skpangu_ctx* ctx, const float* x1, float* x2, void* stream) {
+    NEED_PREPARED();
+    if (!x1 || !x2) return SKPANGU_E_ARG;
+    return (int)ctx->eng->down(x1, x2, (hipStream_t)stream);
+}
+int skpangu_upsample(skpangu_ctx* ctx, const float* x2, float* x4, void* stream) {
+    NEED_PREPARED();
+    if (!x2 || !x4) return SKPANGU_E_ARG;
+    return (int)ctx->eng->up(x2, x4, (hipStream_t)stream);
+}
+int skpangu_patch_recover(skpangu_ctx* ctx, const float* skip, const float* x4, float* out, void* stream) {
+    NEED_PREPARED();
+    if (!skip || !x4 || !out) return SKPANGU_E_ARG;
+    return (int)ctx->eng->recover(skip, x4, out, (hipStream_t)stream);
+}
+int skpangu_debug_buffer(skpangu_ctx* ctx, const char* name, void** ptr, size_t* bytes) {
+    if (!ctx || !name || !ptr || !bytes) return SKPANGU_E_ARG;
+    return ctx->eng->debug(name, ptr, bytes) ? 0 : SKPANGU_E_NOTFOUND;
+}
+
+}  // extern "C"

@@ -1,0 +1,152 @@
+// One-time "prepare" kernels (fp32 master parameters -> kernel-ready operands) and the small
+// row-statistics kernel of DownSample.  All HBM-bound, coalesced, no reuse worth staging.
+#include "common.h"
+#include "launchers.h"
+
+namespace skp {
+
+// dst[n][k] (ld = ldd, zero-filled for K <= k < ldd) = split(src[n*sn + k*sk]); generic strides cover
+// plain [N][K] linears (sn=K, sk=1) and the ConvTranspose weights stored [K][N] (sn=1, sk=N).
+template <class T, int NW>
+__global__ void prep_weight_kernel(const float* __restrict__ src, T* __restrict__ dst, long long plane, int N, int K, int ldd,
+                                   long long sn, long long sk) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)N * ldd) return;
+    const int n = (int)(i / ldd), k = (int)(i - (long long)n * ldd);
+    const float v = k < K ? src[n * sn + k * sk] : 0.f;
+    const T h = (T)v;
+    dst[i] = h;
+    if constexpr (NW == 2) dst[plane + i] = (T)(v - (float)h);
+}
+
+template <class T, int NW>
+hipError_t prep_weight(const float* src, T* dst, long long plane, int N, int K, int ldd, long long sn, long long sk, hipStream_t s) {
+    const long long total = (long long)N * ldd;
+    hipLaunchKernelGGL((prep_weight_kernel<T, NW>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, dst, plane, N, K, ldd, sn, sk);
+    return hipGetLastError();
+}
+template hipError_t prep_weight<bf16, 2>(const float*, bf16*, long long, int, int, int, long long, long long, hipStream_t);
+template hipError_t prep_weight<f16, 1>(const float*, f16*, long long, int, int, int, long long, long long, hipStream_t);
+
+// Earth-specific bias gathered from the compact (3312, types, heads) table into the attention
+// kernel's accumulator order [type][head][qf][kf][lane][r]:
+//   q = 16 qf + (lane & 15), key = 16 kf + 4 (lane >> 4) + r,
+//   index = (z_q + 2 z_k) * 23*36 + (h_q + 6 h_k) * 23 + (w_q - w_k + 11)   (pseudocode _construct_index)
+// Odd (rolled) blocks fold the shifted-window mask in: -100 where q and key sit in different Swin
+// regions of the last Z window / last latitude window (longitude is periodic -> never masked).
+__global__ void prep_bias_expand_kernel(const float* __restrict__ table, f16* __restrict__ out, int types, int heads, int nH, int roll) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = (long long)types * heads * 81 * 256;
+    if (i >= total) return;
+    const int r = (int)(i & 3), lane = (int)((i >> 2) & 63);
+    long long rest = i >> 8;
+    const int kf = (int)(rest % 9); rest /= 9;
+    const int qf = (int)(rest % 9); rest /= 9;
+    const int head = (int)(rest % heads);
+    const int type = (int)(rest / heads);
+    const int q = qf * 16 + (lane & 15), key = kf * 16 + 4 * (lane >> 4) + r;
+    const int zq = q / 72, hq = (q / 12) % 6, wq = q % 12;
+    const int zk = key / 72, hk = (key / 12) % 6, wk = key % 12;
+    const int idx = (zq + 2 * zk) * (23 * 36) + (hq + 6 * hk) * 23 + (wq - wk + 11);
+    float v = table[((long long)idx * types + type) * heads + head];
+    if (roll) {
+        const int zi = type / nH, hi = type % nH;
+        const int nZ = types / nH;
+        const bool mz = (zi == nZ - 1) && (zq != zk);
+        const bool mh = (hi == nH - 1) && ((hq < 3) != (hk < 3));
+        if (mz || mh) v += -100.0f;
+    }
+    out[i] = (f16)v;
+}
+
+hipError_t prep_bias_expand(const float* table, f16* out, int types, int heads, int nH, int roll, hipStream_t s) {
+    const long long total = (long long)types * heads * 81 * 256;
+    hipLaunchKernelGGL(prep_bias_expand_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, table, out, types, heads, nH, roll);
+    return hipGetLastError();
+}
+
+// Window gather table: row m = win*144 + t of the (padded, rolled, window-partitioned) token grid
+// -> source token row, or -1 for latitude padding.  win = (zi*nH + hi)*nW + wi, t = (tz*6 + th)*12 + tw.
+__global__ void prep_window_index_kernel(int* __restrict__ idx, int Z, int H, int W, int Hp, int top, int roll) {
+    const int nH = Hp / 6, nW = W / 12;
+    const long long total = (long long)(Z / 2) * nH * nW * WIN_TOKENS;
+    const long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= total) return;
+    const int t = (int)(m % WIN_TOKENS);
+    const int win = (int)(m / WIN_TOKENS);
+    const int wi = win % nW, hi = (win / nW) % nH, zi = win / (nW * nH);
+    int pz = 2 * zi + t / 72, ph = 6 * hi + (t / 12) % 6, pw = 12 * wi + t % 12;
+    if (roll) { pz = (pz + 1) % Z; ph = (ph + 3) % Hp; pw = (pw + 6) % W; }
+    const int h = ph - top;
+    idx[m] = (h >= 0 && h < H) ? (pz * H + h) * W + pw : -1;
+}
+
+hipError_t prep_window_index(int* idx, int Z, int H, int W, int Hp, int top, int roll, hipStream_t s) {
+    const long long total = (long long)(Z / 2) * (Hp / 6) * (W / 12) * WIN_TOKENS;
+    hipLaunchKernelGGL(prep_window_index_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, idx, Z, H, W, Hp, top, roll);
+    return hipGetLastError();
+}
+
+__global__ void prep_reciprocal_kernel(const float* __restrict__ src, float* __restrict__ dst, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = 1.0f / src[i];
+}
+hipError_t prep_reciprocal(const float* src, float* dst, int n, hipStream_t s) {
+    hipLaunchKernelGGL(prep_reciprocal_kernel, dim3((n + 255) / 256), dim3(256), 0, s, src, dst, n);
+    return hipGetLastError();
+}
+
+// DownSample LayerNorm(4C) statistics of the 2x2-merged rows: one wavefront per merged row
+// (z, h', w'); the 4 source tokens are 4 x C contiguous floats (the one below the grid is zero padding).
+__global__ void __launch_bounds__(256) merge_stats_kernel(const float* __restrict__ x, float2* __restrict__ stats, int Z, int H1, int W1,
+                                                           int H2, int W2, int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    const long long m = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long M = (long long)Z * H2 * W2;
+    if (m >= M) return;
+    const int hw = H2 * W2;
+    const int z = (int)(m / hw), rem = (int)(m - (long long)z * hw);
+    const int h = rem / W2, w = rem - h * W2;
+    const int c4 = C / 4;                      // float4 per token
+    float vals[4][3][4];                       // [quadrant][iteration][4]  (C/4 <= 192 float4 -> 3 iterations of 64 lanes)
+    float s = 0.f;
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) {
+        const int hf = 2 * h + (qd >> 1), wf = 2 * w + (qd & 1);
+        const bool ok = hf < H1;
+        const float4* p = reinterpret_cast<const float4*>(x + (((long long)z * H1 + hf) * W1 + wf) * C);
+#pragma unroll
+        for (int it = 0; it < 3; ++it) {
+            const int j = it * 64 + lane;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok && j < c4) v = p[j];
+            vals[qd][it][0] = v.x; vals[qd][it][1] = v.y; vals[qd][it][2] = v.z; vals[qd][it][3] = v.w;
+            s += (v.x + v.y) + (v.z + v.w);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s / (4.0f * C);
+    float ss = 0.f;
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd)
+#pragma unroll
+        for (int it = 0; it < 3; ++it) {
+            const int j = it * 64 + lane;
+            if (j < c4) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float d = vals[qd][it][e] - mean; ss += d * d; }
+            }
+        }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+    if (lane == 0) stats[m] = make_float2(mean, rsqrtf(ss / (4.0f * C) + eps));
+}
+
+hipError_t merge_stats(const float* x, float2* stats, int Z, int H1, int W1, int H2, int W2, int C, float eps, hipStream_t s) {
+    const long long M = (long long)Z * H2 * W2;
+    hipLaunchKernelGGL(merge_stats_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, x, stats, Z, H1, W1, H2, W2, C, eps);
+    return hipGetLastError();
+}
+
+}  // namespace skp

@@ -1,0 +1,107 @@
+// Shared device-side vocabulary for the gfx950 Pangu engine: 16-bit operand types,
+// MFMA wrappers, hi/lo operand splitting and the LDS swizzle.  gfx950 only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace skp {
+
+typedef _Float16 f16;
+typedef __bf16 bf16;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef f16 f16x8 __attribute__((ext_vector_type(8)));
+typedef bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// ---- operand type traits ------------------------------------------------- //
+template <class T> struct OpT;
+template <> struct OpT<f16> {
+    typedef f16x8 v8;
+    // D(16x16) += A(16x32) * B(32x16); lane l holds A[l&15][8*(l>>4)+j], B[8*(l>>4)+j][l&15];
+    // D: col = l&15, row = 4*(l>>4)+r.
+    static __device__ __forceinline__ f32x4 mfma(v8 a, v8 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+    }
+};
+template <> struct OpT<bf16> {
+    typedef bf16x8 v8;
+    static __device__ __forceinline__ f32x4 mfma(v8 a, v8 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    }
+};
+
+template <class T>
+__device__ __forceinline__ typename OpT<T>::v8 as_v8(const uint4& u) {
+    return __builtin_bit_cast(typename OpT<T>::v8, u);
+}
+
+// ---- precision modes ------------------------------------------------------ //
+// A GEMM computes sum over "terms": (A_hi,W_hi) [+ (A_lo,W_hi) if NA==2] [+ (A_hi,W_lo) if NW==2].
+// bf16x3 carries 16 significand bits per operand: fp32-class results on the bf16 MFMA pipe.
+struct PrecBF16x3 { typedef bf16 T; static constexpr int NA = 2, NW = 2; };
+struct PrecF16    { typedef f16 T;  static constexpr int NA = 1, NW = 1; };
+
+// storage type of inter-kernel activations: fp32 when the consumer splits hi/lo, else T
+template <class P> struct ActT { typedef typename P::T type; };
+template <> struct ActT<PrecBF16x3> { typedef float type; };
+
+// ---- hi/lo split ---------------------------------------------------------- //
+// 8 fp32 -> NP planes of 8 x T packed as uint4.  lo = T(v - float(hi)).
+template <class T, int NP>
+__device__ __forceinline__ void split8(const float (&v)[8], uint4 (&out)[NP]) {
+    T h[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) h[i] = (T)v[i];
+    out[0] = __builtin_bit_cast(uint4, *reinterpret_cast<typename OpT<T>::v8*>(h));
+    if constexpr (NP == 2) {
+        T l[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) l[i] = (T)(v[i] - (float)h[i]);
+        out[1] = __builtin_bit_cast(uint4, *reinterpret_cast<typename OpT<T>::v8*>(l));
+    }
+}
+
+template <class T, int NP>
+__device__ __forceinline__ void split4(const float (&v)[4], uint2 (&out)[NP]) {
+    typedef T t4 __attribute__((ext_vector_type(4)));
+    t4 h;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) h[i] = (T)v[i];
+    out[0] = __builtin_bit_cast(uint2, h);
+    if constexpr (NP == 2) {
+        t4 l;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) l[i] = (T)(v[i] - (float)h[i]);
+        out[1] = __builtin_bit_cast(uint2, l);
+    }
+}
+
+// store 4 consecutive activations (fp32 or T)
+template <class S>
+__device__ __forceinline__ void store4(S* p, const float (&v)[4]) {
+    if constexpr (sizeof(S) == 4) {
+        *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+        uint2 o[1];
+        split4<S, 1>(v, o);
+        *reinterpret_cast<uint2*>(p) = o[0];
+    }
+}
+
+// ---- LDS tile addressing --------------------------------------------------- //
+// A [rows][BK] tile of 16-bit elements is stored as 16-byte slots; slot s of row r lives at
+// physical slot s ^ f(r) so that the 16-lane groups of ds_read_b128 (rows l&15, k-group l>>4)
+// and the 8-lane groups of ds_write_b128 hit 16 / 8 distinct bank quads.
+template <int BK>
+__device__ __forceinline__ int lds_off(int row, int slot) {
+    if constexpr (BK == 64) return row * 128 + ((slot ^ (row & 7)) << 4);
+    else                    return row * 64 + ((slot ^ ((row >> 1) & 3)) << 4);
+}
+
+__device__ __forceinline__ float gelu_erf(float x) {
+    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+
+constexpr int WIN_TOKENS = 144;
+constexpr int HEAD_DIM = 32;
+
+}  // namespace skp

@@ -1,0 +1,300 @@
+// Fused GEMM epilogues for gemm.h.  An epilogue receives the wave's accumulator fragments and owns
+// everything between "sum over k" and HBM: bias, GELU, LayerNorm + residual, window reverse /
+// un-roll / crop, pixel shuffle, QKV head split (+ V transpose), ConvTranspose scatter + de-normalise.
+//
+// Swapped order (default):  acc[a][b][r] = C[m = m0w + 16a + (lane&15)][n = n0w + 16b + 4(lane>>4) + r]
+// Un-swapped order:         acc[a][b][r] = C[m = m0w + 16a + 4(lane>>4) + r][n = n0w + 16b + (lane&15)]
+#pragma once
+#include "common.h"
+
+namespace skp {
+
+// ---- bias + plain fp32 store (PatchEmbedding, DownSample, UpSample.linear2) ---- //
+struct EpStoreF32 {
+    static constexpr bool kDualOrder = false;
+    float* out;
+    const float* bias;      // nullable
+    int ld, row_off;
+    template <class TC, bool SWAP>
+    __device__ __forceinline__ void run(f32x4 (&acc)[TC::FM][TC::FN], int m0w, int n0w, int lane, int, int, char*, int M, int N) const {
+        static_assert(SWAP, "swapped order only");
+        const int lm = lane & 15, ln = (lane >> 4) * 4;
+#pragma unroll
+        for (int a = 0; a < TC::FM; ++a) {
+            const int m = m0w + a * 16 + lm;
+            if (m >= M) continue;
+            float* orow = out + (long long)(m + row_off) * ld;
+#pragma unroll
+            for (int b = 0; b < TC::FN; ++b) {
+                const int n = n0w + b * 16 + ln;
+                if (n >= N) continue;
+                float4 v = make_float4(acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]);
+                if (bias != nullptr) {
+                    const float4 bb = *reinterpret_cast<const float4*>(bias + n);
+                    v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
+                }
+                *reinterpret_cast<float4*>(orow + n) = v;
+            }
+        }
+    }
+};
+
+// ---- bias + GELU -> activation store (MLP fc1) ------------------------------- //
+template <class S>
+struct EpGelu {
+    static constexpr bool kDualOrder = false;
+    S* out;
+    const float* bias;
+    int ld;
+    template <class TC, bool SWAP>
+    __device__ __forceinline__ void run(f32x4 (&acc)[TC::FM][TC::FN], int m0w, int n0w, int lane, int, int, char*, int M, int N) const {
+        static_assert(SWAP, "swapped order only");
+        const int lm = lane & 15, ln = (lane >> 4) * 4;
+#pragma unroll
+        for (int a = 0; a < TC::FM; ++a) {
+            const int m = m0w + a * 16 + lm;
+            if (m >= M) continue;
+            S* orow = out + (long long)m * ld;
+#pragma unroll
+            for (int b = 0; b < TC::FN; ++b) {
+                const int n = n0w + b * 16 + ln;
+                if (n >= N) continue;
+                const float4 bb = *reinterpret_cast<const float4*>(bias + n);
+                float v[4] = {gelu_erf(acc[a][b][0] + bb.x), gelu_erf(acc[a][b][1] + bb.y),
+                              gelu_erf(acc[a][b][2] + bb.z), gelu_erf(acc[a][b][3] + bb.w)};
+                store4<S>(orow + n, v);
+            }
+        }
+    }
+};
+
+// ---- QKV head split: Q (scaled), K as [win][head][144][32]; V transposed [win][head][32][144] ---- //
+// Q/K tiles run in swapped order (4 consecutive d per lane), V tiles in un-swapped order (4 consecutive
+// tokens per lane) so that the attention kernel reads every MFMA fragment as contiguous bytes.
+template <class T, int NPL>
+struct EpQKV {
+    static constexpr bool kDualOrder = true;
+    T* q; T* k; T* vt;          // hi planes; lo plane at + plane
+    long long plane;
+    const float* bias;          // [3C]
+    int C, heads;
+    float scale;
+    __device__ __forceinline__ bool unswapped(int n0) const { return n0 >= 2 * C; }
+    template <class TC, bool SWAP>
+    __device__ __forceinline__ void run(f32x4 (&acc)[TC::FM][TC::FN], int m0w, int n0w, int lane, int, int, char*, int M, int N) const {
+        const int l15 = lane & 15, l4 = (lane >> 4) * 4;
+        if constexpr (SWAP) {
+#pragma unroll
+            for (int a = 0; a < TC::FM; ++a) {
+                const int m = m0w + a * 16 + l15;
+                if (m >= M) continue;
+                const int win = m / WIN_TOKENS, t = m - win * WIN_TOKENS;
+#pragma unroll
+                for (int b = 0; b < TC::FN; ++b) {
+                    const int n = n0w + b * 16 + l4;
+                    if (n >= N) continue;
+                    const int which = n >= C ? 1 : 0;
+                    const int c = n - which * C;
+                    const int head = c >> 5, d = c & 31;
+                    const float4 bb = *reinterpret_cast<const float4*>(bias + n);
+                    const float s = which == 0 ? scale : 1.0f;
+                    const float v[4] = {(acc[a][b][0] + bb.x) * s, (acc[a][b][1] + bb.y) * s,
+                                        (acc[a][b][2] + bb.z) * s, (acc[a][b][3] + bb.w) * s};
+                    uint2 o[NPL];
+                    split4<T, NPL>(v, o);
+                    T* dst = (which == 0 ? q : k) + (((long long)win * heads + head) * WIN_TOKENS + t) * HEAD_DIM + d;
+#pragma unroll
+                    for (int p = 0; p < NPL; ++p) *reinterpret_cast<uint2*>(dst + p * plane) = o[p];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int a = 0; a < TC::FM; ++a) {
+                const int m = m0w + a * 16 + l4;
+                if (m >= M) continue;
+                const int win = m / WIN_TOKENS, t = m - win * WIN_TOKENS;
+#pragma unroll
+                for (int b = 0; b < TC::FN; ++b) {
+                    const int n = n0w + b * 16 + l15;
+                    if (n >= N) continue;
+                    const int c = n - 2 * C;
+                    const int head = c >> 5, d = c & 31;
+                    const float bb = bias[n];
+                    const float v[4] = {acc[a][b][0] + bb, acc[a][b][1] + bb, acc[a][b][2] + bb, acc[a][b][3] + bb};
+                    uint2 o[NPL];
+                    split4<T, NPL>(v, o);
+                    T* dst = vt + (((long long)win * heads + head) * HEAD_DIM + d) * WIN_TOKENS + t;
+#pragma unroll
+                    for (int p = 0; p < NPL; ++p) *reinterpret_cast<uint2*>(dst + p * plane) = o[p];
+                }
+            }
+        }
+    }
+};
+
+// ---- row LayerNorm over the tile's BN columns + (residual add | activation store) ---- //
+// Requires the block to own complete LayerNorm groups: BN == group width (N == BN for proj/fc2,
+// N == 4*BN for UpSample where each n-tile is one pixel-shuffle quadrant).
+struct RowMapIndexed {          // proj: window reverse + un-roll + crop via the window table; fc2: identity
+    const int* idx;             // nullable
+    __device__ __forceinline__ long long dest(int m, int) const { return idx ? idx[m] : m; }
+};
+struct RowMapPixelShuffle {     // UpSample: (z,h,w) of the coarse grid, quadrant = n-tile -> fine token, cropped
+    int H1, W1, H2, W2;
+    __device__ __forceinline__ long long dest(int m, int ntile) const {
+        const int hw = H2 * W2;
+        const int z = m / hw, rem = m - z * hw;
+        const int h = rem / W2, w = rem - h * W2;
+        const int hf = 2 * h + (ntile >> 1), wf = 2 * w + (ntile & 1);
+        if (hf >= H1 || wf >= W1) return -1;
+        return ((long long)z * H1 + hf) * W1 + wf;
+    }
+};
+struct SinkResidual {           // x[dest][c..c+3] += y
+    float* x;
+    __device__ __forceinline__ void put(long long row, int ld, int c, const float (&y)[4]) const {
+        float4* p = reinterpret_cast<float4*>(x + row * ld + c);
+        float4 o = *p;
+        o.x += y[0]; o.y += y[1]; o.z += y[2]; o.w += y[3];
+        *p = o;
+    }
+};
+template <class S>
+struct SinkStore {              // out[dest][c..c+3] = y
+    S* out;
+    __device__ __forceinline__ void put(long long row, int ld, int c, const float (&y)[4]) const {
+        store4<S>(out + row * ld + c, y);
+    }
+};
+
+template <class RowMap, class Sink>
+struct EpLayerNorm {
+    static constexpr bool kDualOrder = false;
+    RowMap map;
+    Sink sink;
+    const float* bias;       // nullable, [N]
+    const float* gamma;      // [BN]
+    const float* beta;       // [BN]
+    float eps;
+    template <class TC, bool SWAP>
+    __device__ __forceinline__ void run(f32x4 (&acc)[TC::FM][TC::FN], int m0w, int n0w, int lane, int wm, int wn, char* smem, int M, int N) const {
+        static_assert(SWAP, "swapped order only");
+        constexpr int FM = TC::FM, FN = TC::FN, WN = TC::WN, BM = TC::BM, BN = TC::BN;
+        const int l15 = lane & 15, l4 = (lane >> 4) * 4;
+        const int ntile = blockIdx.x;
+        const int nloc0 = n0w - ntile * BN;          // column of this wave inside the LN group
+        float* red = reinterpret_cast<float*>(smem);  // [2][BM][WN]
+        if (bias != nullptr) {
+#pragma unroll
+            for (int b = 0; b < FN; ++b) {
+                const float4 bb = *reinterpret_cast<const float4*>(bias + n0w + b * 16 + l4);
+#pragma unroll
+                for (int a = 0; a < FM; ++a) { acc[a][b][0] += bb.x; acc[a][b][1] += bb.y; acc[a][b][2] += bb.z; acc[a][b][3] += bb.w; }
+            }
+        }
+        float mean[FM], rstd[FM];
+        // pass 1: mean
+#pragma unroll
+        for (int a = 0; a < FM; ++a) {
+            float s = 0.f;
+#pragma unroll
+            for (int b = 0; b < FN; ++b) s += (acc[a][b][0] + acc[a][b][1]) + (acc[a][b][2] + acc[a][b][3]);
+            s += __shfl_xor(s, 16);
+            s += __shfl_xor(s, 32);
+            if (lane < 16) red[(wm * TC::WTM + a * 16 + lane) * WN + wn] = s;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int a = 0; a < FM; ++a) {
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < WN; ++w) s += red[(wm * TC::WTM + a * 16 + l15) * WN + w];
+            mean[a] = s * (1.0f / BN);
+        }
+        // pass 2: centred second moment
+        float* red2 = red + BM * WN;
+#pragma unroll
+        for (int a = 0; a < FM; ++a) {
+            float s = 0.f;
+#pragma unroll
+            for (int b = 0; b < FN; ++b) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const float d = acc[a][b][r] - mean[a]; s += d * d; }
+            }
+            s += __shfl_xor(s, 16);
+            s += __shfl_xor(s, 32);
+            if (lane < 16) red2[(wm * TC::WTM + a * 16 + lane) * WN + wn] = s;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int a = 0; a < FM; ++a) {
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < WN; ++w) s += red2[(wm * TC::WTM + a * 16 + l15) * WN + w];
+            rstd[a] = rsqrtf(s * (1.0f / BN) + eps);
+        }
+#pragma unroll
+        for (int a = 0; a < FM; ++a) {
+            const int m = m0w + a * 16 + l15;
+            if (m >= M) continue;
+            const long long row = map.dest(m, ntile);
+            if (row < 0) continue;
+#pragma unroll
+            for (int b = 0; b < FN; ++b) {
+                const int c = nloc0 + b * 16 + l4;
+                const float4 g = *reinterpret_cast<const float4*>(gamma + c);
+                const float4 be = *reinterpret_cast<const float4*>(beta + c);
+                const float y[4] = {(acc[a][b][0] - mean[a]) * rstd[a] * g.x + be.x, (acc[a][b][1] - mean[a]) * rstd[a] * g.y + be.y,
+                                    (acc[a][b][2] - mean[a]) * rstd[a] * g.z + be.z, (acc[a][b][3] - mean[a]) * rstd[a] * g.w + be.w};
+                sink.put(row, BN, c, y);
+            }
+        }
+    }
+};
+
+// ---- PatchRecovery: ConvTranspose scatter + crop + de-normalise --------------- //
+// Upper air: token (zt,h,w), n = ((v*2+dz)*4+dh)*4+dw -> state[v*13 + 2zt+dz][4h+dh-top][4w+dw]
+// Surface:   token (h,w),    n = (v*4+dh)*4+dw       -> state[surf0+v][4h+dh-top][4w+dw]
+struct EpRecover {
+    static constexpr bool kDualOrder = false;
+    float* state;            // [69][n_lat][n_lon]
+    const float* bias;       // [n_vars]
+    const float* mean;       // [69]
+    const float* std;        // [69]
+    int n_lat, n_lon, lat_top, H1, W1, n_levels, surface, surf0;
+    template <class TC, bool SWAP>
+    __device__ __forceinline__ void run(f32x4 (&acc)[TC::FM][TC::FN], int m0w, int n0w, int lane, int, int, char*, int M, int N) const {
+        static_assert(SWAP, "swapped order only");
+        const int l15 = lane & 15, l4 = (lane >> 4) * 4;
+        const int hw = H1 * W1;
+#pragma unroll
+        for (int a = 0; a < TC::FM; ++a) {
+            const int m = m0w + a * 16 + l15;
+            if (m >= M) continue;
+            const int zt = m / hw, rem = m - zt * hw;
+            const int h = rem / W1, w = rem - h * W1;
+#pragma unroll
+            for (int b = 0; b < TC::FN; ++b) {
+                const int n = n0w + b * 16 + l4;      // dw = 0..3 are this lane's 4 values
+                if (n >= N) continue;
+                const int dh = (n >> 2) & 3;
+                int ch, v;
+                if (surface) { v = n >> 4; ch = surf0 + v; }
+                else {
+                    v = n >> 5;
+                    const int level = 2 * zt + ((n >> 4) & 1);
+                    if (level >= n_levels) continue;
+                    ch = v * n_levels + level;
+                }
+                const int lat = 4 * h + dh - lat_top;
+                if (lat < 0 || lat >= n_lat) continue;
+                const float bb = bias[v], sd = std[ch], mu = mean[ch];
+                const float4 o = make_float4((acc[a][b][0] + bb) * sd + mu, (acc[a][b][1] + bb) * sd + mu,
+                                             (acc[a][b][2] + bb) * sd + mu, (acc[a][b][3] + bb) * sd + mu);
+                *reinterpret_cast<float4*>(state + ((long long)ch * n_lat + lat) * n_lon + 4 * w) = o;
+            }
+        }
+    }
+};
+
+}  // namespace skp

@@ -1,0 +1,86 @@
+// Host-side declarations shared by the engine's translation units: geometry, prepared-weight
+// views, scratch views and the per-stage launchers (one 6-h Pangu step = a fixed sequence of these).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "common.h"
+
+namespace skp {
+
+struct Geom {
+    int n_lat, n_lon, n_levels, n_channels, surf0;   // 721, 1440, 13, 69, 65
+    int lat_top;                                      // input latitude front pad (to a multiple of 4)
+    int Z, H1, W1, H2, W2;
+    int Hp[2], top[2], nH[2], nW[2], types[2], nwin[2];   // per resolution (0: layers 1/4, 1: layers 2/3)
+    int ntok[2], mwin[2];                                 // tokens, padded window tokens (nwin*144)
+};
+
+template <class T>
+struct LinW { const T* w; long long plane; int ldw; };   // [N][ldw] hi plane (+ lo plane at +plane)
+
+template <class T>
+struct BlockW {
+    LinW<T> qkv, proj, fc1, fc2;
+    const float *qkv_b, *proj_b, *fc1_b, *fc2_b, *n1_g, *n1_b, *n2_g, *n2_b;
+    const f16* bias_exp;     // [types][heads][9][9][64][4] (+ shifted-window mask on odd blocks)
+};
+
+template <class T>
+struct ModelW {
+    const float *mean, *std, *istd, *masks;
+    LinW<T> embed_u, embed_s;
+    const float *embed_u_b, *embed_s_b;
+    BlockW<T> blk[16];
+    const float *down_g, *down_b;
+    LinW<T> down;
+    LinW<T> up1, up2;
+    const float *up_g, *up_b;
+    LinW<T> rec_u, rec_s;
+    const float *rec_u_b, *rec_s_b;
+    const int* widx[2][2];   // [resolution][roll] window gather table: mwin entries, -1 = padding
+};
+
+template <class P>
+struct Work {
+    typedef typename P::T T;
+    typedef typename ActT<P>::type S;
+    float *X1, *X2, *X4;
+    T *q, *k, *vt;           // planes: + qkv_plane
+    long long qkv_plane;
+    S *ao, *hid, *u;
+    float2* stats;
+};
+
+template <class P>
+struct AttnArgs {
+    const typename P::T *q, *k, *vt;
+    long long plane;
+    const f16* bias_exp;
+    typename ActT<P>::type* out;
+    int ld_out, n_win, nW, heads;
+};
+
+// layer index 0..3 -> resolution 0/1, channels, heads
+inline int layer_res(int layer) { return (layer == 0 || layer == 3) ? 0 : 1; }
+inline int layer_dim(int layer) { return layer_res(layer) == 0 ? 192 : 384; }
+inline int layer_heads(int layer) { return layer_res(layer) == 0 ? 6 : 12; }
+
+template <class P> hipError_t launch_attention(const AttnArgs<P>&, hipStream_t);
+
+template <class P> hipError_t op_embed(const Geom&, const ModelW<typename P::T>&, const float* state, float* X1, hipStream_t);
+template <class P> hipError_t op_recover(const Geom&, const ModelW<typename P::T>&, const float* skip, const float* x4, float* state, hipStream_t);
+template <class P> hipError_t op_qkv(const Geom&, const BlockW<typename P::T>&, const int* widx, int res, const float* X, const Work<P>&, hipStream_t);
+template <class P> hipError_t op_proj(const Geom&, const BlockW<typename P::T>&, const int* widx, int res, float* X, const Work<P>&, hipStream_t);
+template <class P> hipError_t op_fc1(const Geom&, const BlockW<typename P::T>&, int res, const float* X, const Work<P>&, hipStream_t);
+template <class P> hipError_t op_fc2(const Geom&, const BlockW<typename P::T>&, int res, float* X, const Work<P>&, hipStream_t);
+template <class P> hipError_t op_down(const Geom&, const ModelW<typename P::T>&, const float* X1, float* X2, const Work<P>&, hipStream_t);
+template <class P> hipError_t op_up(const Geom&, const ModelW<typename P::T>&, const float* X2, float* X4, const Work<P>&, hipStream_t);
+
+// prepare-time helpers (aux.hip)
+template <class T, int NW>
+hipError_t prep_weight(const float* src, T* dst, long long plane, int N, int K, int ldd, long long sn, long long sk, hipStream_t);
+hipError_t prep_bias_expand(const float* table, f16* out, int types, int heads, int nH, int roll, hipStream_t);
+hipError_t prep_window_index(int* idx, int Z, int H, int W, int Hp, int top, int roll, hipStream_t);
+hipError_t prep_reciprocal(const float* src, float* dst, int n, hipStream_t);
+hipError_t merge_stats(const float* x, float2* stats, int Z, int H1, int W1, int H2, int W2, int C, float eps, hipStream_t);
+
+}  // namespace skp

@@ -1,0 +1,214 @@
+"""ctypes binding of the C-ABI Pangu engine (include/skyrim_pangu.h) + torch plumbing.
+
+PyTorch is used for device memory and streams only: every tensor handed to the library is a raw
+device pointer, every launch goes to ``torch.cuda.current_stream()``.  There is no CPU fallback:
+constructing an engine without the built HIP library (or without a GPU) raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from pathlib import Path
+
+import torch
+
+from .spec import PanguGeometry
+
+PREC_BF16X3 = 0
+PREC_F16 = 1
+PRECISIONS = {"bf16x3": PREC_BF16X3, "f16": PREC_F16}
+
+_LIB_PATH = Path(__file__).resolve().parent.parent / "lib" / "libskyrim_pangu.so"
+
+
+class SkConfig(ctypes.Structure):
+    _fields_ = [("n_lat", ctypes.c_int), ("n_lon", ctypes.c_int), ("precision", ctypes.c_int)]
+
+
+class SkSizes(ctypes.Structure):
+    _fields_ = [("master_floats", ctypes.c_longlong), ("prepared_bytes", ctypes.c_size_t),
+                ("workspace_bytes", ctypes.c_size_t), ("state_floats", ctypes.c_longlong),
+                ("n_params", ctypes.c_int)]
+
+
+EXPORTS = [
+    "skpangu_abi_version", "skpangu_error_string", "skpangu_query_sizes", "skpangu_param_info",
+    "skpangu_create", "skpangu_destroy", "skpangu_prepare", "skpangu_step", "skpangu_patch_embed",
+    "skpangu_block", "skpangu_downsample", "skpangu_upsample", "skpangu_patch_recover",
+    "skpangu_debug_buffer",
+]
+
+_lib = None
+
+
+def load_library() -> ctypes.CDLL:
+    """Load libskyrim_pangu.so (built in-tree by ``__graft_entry__.build()`` / ``make -C skyrim_amd/csrc``)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = os.environ.get("SKYRIM_PANGU_LIB", str(_LIB_PATH))
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"HIP engine library not found at {path}; build it with `python -c 'import __graft_entry__ as g; g.build()'`"
+            " -- there is no CPU fallback for the Pangu hot path")
+    lib = ctypes.CDLL(path)
+    vp, ci, cll = ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong
+    lib.skpangu_abi_version.restype = ci
+    lib.skpangu_error_string.restype = ctypes.c_char_p
+    lib.skpangu_error_string.argtypes = [ci]
+    lib.skpangu_query_sizes.argtypes = [ctypes.POINTER(SkConfig), ctypes.POINTER(SkSizes)]
+    lib.skpangu_param_info.argtypes = [ctypes.POINTER(SkConfig), ci, ctypes.c_char_p, ctypes.c_size_t,
+                                       ctypes.POINTER(cll), ctypes.POINTER(ci), ctypes.POINTER(cll * 6)]
+    lib.skpangu_create.argtypes = [ctypes.POINTER(SkConfig), vp, ctypes.c_size_t, vp, ctypes.c_size_t, ctypes.POINTER(vp)]
+    lib.skpangu_destroy.argtypes = [vp]
+    lib.skpangu_destroy.restype = None
+    lib.skpangu_prepare.argtypes = [vp, vp, vp]
+    lib.skpangu_step.argtypes = [vp, vp, vp, vp]
+    lib.skpangu_patch_embed.argtypes = [vp, vp, vp, vp]
+    lib.skpangu_block.argtypes = [vp, ci, ci, vp, vp]
+    lib.skpangu_downsample.argtypes = [vp, vp, vp, vp]
+    lib.skpangu_upsample.argtypes = [vp, vp, vp, vp]
+    lib.skpangu_patch_recover.argtypes = [vp, vp, vp, vp, vp]
+    lib.skpangu_debug_buffer.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_size_t)]
+    for name in EXPORTS:
+        getattr(lib, name)
+    _lib = lib
+    return lib
+
+
+def _check(code: int, what: str):
+    if code != 0:
+        msg = load_library().skpangu_error_string(code).decode()
+        raise RuntimeError(f"{what} failed: {msg} (code {code})")
+
+
+def query_sizes(geom: PanguGeometry, precision: str = "bf16x3") -> SkSizes:
+    cfg = SkConfig(geom.n_lat, geom.n_lon, PRECISIONS[precision])
+    out = SkSizes()
+    _check(load_library().skpangu_query_sizes(ctypes.byref(cfg), ctypes.byref(out)), "skpangu_query_sizes")
+    return out
+
+
+def param_table(geom: PanguGeometry, precision: str = "bf16x3") -> list[tuple[str, int, tuple[int, ...]]]:
+    """(name, element offset, shape) of every master parameter, as the library lays them out."""
+    lib = load_library()
+    cfg = SkConfig(geom.n_lat, geom.n_lon, PRECISIONS[precision])
+    n = query_sizes(geom, precision).n_params
+    out = []
+    for i in range(n):
+        name = ctypes.create_string_buffer(128)
+        off, nd, shape = ctypes.c_longlong(), ctypes.c_int(), (ctypes.c_longlong * 6)()
+        _check(lib.skpangu_param_info(ctypes.byref(cfg), i, name, 128, ctypes.byref(off), ctypes.byref(nd), ctypes.byref(shape)),
+               "skpangu_param_info")
+        out.append((name.value.decode(), off.value, tuple(shape[j] for j in range(nd.value))))
+    return out
+
+
+class PanguEngine:
+    """Device-resident Pangu 6-h step.  ``step`` maps a (69, n_lat, n_lon) fp32 CUDA tensor to the next state."""
+
+    def __init__(self, geom: PanguGeometry | None = None, precision: str = "bf16x3", device: str | torch.device = "cuda:0"):
+        self.lib = load_library()
+        if not torch.cuda.is_available():
+            raise RuntimeError("PanguEngine needs a ROCm GPU (gfx950); there is no CPU fallback")
+        self.geom = geom or PanguGeometry()
+        self.precision = precision
+        self.device = torch.device(device)
+        self.cfg = SkConfig(self.geom.n_lat, self.geom.n_lon, PRECISIONS[precision])
+        self.sizes = query_sizes(self.geom, precision)
+        with torch.cuda.device(self.device):
+            self._prepared = torch.empty(self.sizes.prepared_bytes, dtype=torch.uint8, device=self.device)
+            self._workspace = torch.empty(self.sizes.workspace_bytes, dtype=torch.uint8, device=self.device)
+        self._ctx = ctypes.c_void_p()
+        _check(self.lib.skpangu_create(ctypes.byref(self.cfg), self._prepared.data_ptr(), self.sizes.prepared_bytes,
+                                       self._workspace.data_ptr(), self.sizes.workspace_bytes, ctypes.byref(self._ctx)),
+               "skpangu_create")
+        self.state_shape = (self.geom.n_channels, self.geom.n_lat, self.geom.n_lon)
+
+    def __del__(self):
+        ctx = getattr(self, "_ctx", None)
+        if ctx:
+            self.lib.skpangu_destroy(ctx)
+            self._ctx = None
+
+    # ------------------------------------------------------------------ #
+    def _stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _chk_dev(self, t: torch.Tensor, shape=None):
+        if t.device != self.device or t.dtype != torch.float32 or not t.is_contiguous():
+            raise ValueError("expected a contiguous float32 tensor on the engine device")
+        if shape is not None and tuple(t.shape) != tuple(shape):
+            raise ValueError(f"expected shape {tuple(shape)}, got {tuple(t.shape)}")
+        return ctypes.c_void_p(t.data_ptr())
+
+    def load_params(self, params: dict[str, torch.Tensor]):
+        """Pack fp32 master parameters into the library's blob layout, upload and prepare."""
+        table = param_table(self.geom, self.precision)
+        with torch.cuda.device(self.device):
+            master = torch.zeros(self.sizes.master_floats, dtype=torch.float32, device=self.device)
+            for name, off, shape in table:
+                t = params[name]
+                if tuple(t.shape) != shape:
+                    raise ValueError(f"{name}: expected {shape}, got {tuple(t.shape)}")
+                master[off:off + t.numel()] = t.reshape(-1).to(self.device, torch.float32)
+            _check(self.lib.skpangu_prepare(self._ctx, master.data_ptr(), self._stream()), "skpangu_prepare")
+            torch.cuda.current_stream(self.device).synchronize()
+        del master
+
+    def step(self, x: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+        if out is None:
+            out = torch.empty_like(x)
+        with torch.cuda.device(self.device):
+            _check(self.lib.skpangu_step(self._ctx, self._chk_dev(x, self.state_shape), self._chk_dev(out, self.state_shape),
+                                         self._stream()), "skpangu_step")
+        return out
+
+    # ---- stage-level (tests) ------------------------------------------- #
+    def tokens(self, layer: int):
+        return self.geom.tokens(layer), self.geom.dim(layer)
+
+    def patch_embed(self, x: torch.Tensor) -> torch.Tensor:
+        out = torch.empty(self.tokens(1), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _check(self.lib.skpangu_patch_embed(self._ctx, self._chk_dev(x, self.state_shape), self._chk_dev(out), self._stream()),
+                   "skpangu_patch_embed")
+        return out
+
+    def block(self, layer: int, i: int, x: torch.Tensor) -> torch.Tensor:
+        y = x.clone()
+        with torch.cuda.device(self.device):
+            _check(self.lib.skpangu_block(self._ctx, layer, i, self._chk_dev(y, self.tokens(layer)), self._stream()), "skpangu_block")
+        return y
+
+    def downsample(self, x1: torch.Tensor) -> torch.Tensor:
+        out = torch.empty(self.tokens(2), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _check(self.lib.skpangu_downsample(self._ctx, self._chk_dev(x1, self.tokens(1)), self._chk_dev(out), self._stream()),
+                   "skpangu_downsample")
+        return out
+
+    def upsample(self, x2: torch.Tensor) -> torch.Tensor:
+        out = torch.empty(self.tokens(1), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _check(self.lib.skpangu_upsample(self._ctx, self._chk_dev(x2, self.tokens(2)), self._chk_dev(out), self._stream()),
+                   "skpangu_upsample")
+        return out
+
+    def patch_recover(self, skip: torch.Tensor, x4: torch.Tensor) -> torch.Tensor:
+        out = torch.zeros(self.state_shape, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _check(self.lib.skpangu_patch_recover(self._ctx, self._chk_dev(skip, self.tokens(1)), self._chk_dev(x4, self.tokens(1)),
+                                                  self._chk_dev(out), self._stream()), "skpangu_patch_recover")
+        return out
+
+    def debug_buffer(self, name: str, dtype: torch.dtype) -> torch.Tensor:
+        """Copy of an internal buffer as a flat tensor of ``dtype`` (tests only)."""
+        ptr, nbytes = ctypes.c_void_p(), ctypes.c_size_t()
+        _check(self.lib.skpangu_debug_buffer(self._ctx, name.encode(), ctypes.byref(ptr), ctypes.byref(nbytes)), "skpangu_debug_buffer")
+        torch.cuda.synchronize(self.device)
+        for base in (self._workspace, self._prepared):
+            off = ptr.value - base.data_ptr()
+            if 0 <= off < base.numel():
+                return base[off:off + nbytes.value].clone().view(dtype)
+        raise RuntimeError("debug pointer outside the engine arenas")
