@@ -1,0 +1,187 @@
+#!/usr/bin/env python
+"""Headline benchmark: Pangu 6-h forecast steps/s on the 721x1440x69 state (BASELINE.json).
+
+    python bench.py --gpus N --steps K --warmup W            (N=1)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one skpangu_step() = one 6-h forward of the Pangu network on a synthetic state that is
+already resident in HBM (autoregressive, in place).  N > 1: one process per GPU, one ensemble member
+per rank (weak scaling, members are independent); the timed region ends with the RCCL reduction that
+forms the ensemble mean/spread of the final step.  Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import torch
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+# algorithmic work of one 721x1440 step
+F_ALG_STEP = 8.42e12
+PEAK_MFMA_BF16 = 2.5e15      # dense bf16/fp16 MFMA peak, MI355X_MICROARCH.md
+PEAK_HBM = 8.0e12
+
+
+def cpu_baseline(params, geom, x):
+    """CPU restatement (oracle/, kind 'port') timed on this box's host cores on a bounded sample of the
+    same workload: embed + layer1.block0-1 + downsample + layer2.block0-1 of one full-size step,
+    scaled to steps/s by algorithmic FLOPs."""
+    from oracle import pangu_oracle as O
+    g = O.Geometry(geom.n_lat, geom.n_lon)
+    p = {k: v for k, v in params.items()}
+    mean, std = p["norm.mean"][:, None, None], p["norm.std"][:, None, None]
+    cores = torch.get_num_threads()
+    t0 = time.time()
+    with torch.no_grad():
+        upper, surface = O.split_state((x - mean) / std)
+        t = O.patch_embed(p, g, upper, surface)
+        for i in range(2):
+            t = O.earth_block(O._block_params(p, 1, i), t, g.res(1), O.HEADS[0], i % 2 == 1)
+        t = O.downsample(p, g, t)
+        for i in range(2):
+            t = O.earth_block(O._block_params(p, 2, i), t, g.res(2), O.HEADS[1], i % 2 == 1)
+    dt = time.time() - t0
+    f_sample = (30.8 + 2 * 524.7 + 77.3 + 2 * 502.8) * 1e9
+    t_step = dt * F_ALG_STEP / f_sample
+    return {"value": 1.0 / t_step, "unit": "steps/s", "cores": cores, "kind": "port",
+            "sample": f"embed + layer1.block0-1 + downsample + layer2.block0-1 of one 721x1440 step "
+                      f"({100 * f_sample / F_ALG_STEP:.1f}% of its FLOPs) in {dt:.1f} s, scaled by FLOPs; "
+                      "PyTorch-CPU fp32 restatement, not the reference's ONNX graph",
+            "s_per_step_est": t_step}
+
+
+def toy_parity(precision):
+    """Engine vs oracle on the 13x49x192 toy grid (seconds)."""
+    from oracle import pangu_oracle as O
+    from skyrim_amd.pangu.engine import PanguEngine
+    from skyrim_amd.pangu.spec import PanguGeometry, init_synthetic, synthetic_state
+    g = PanguGeometry(49, 192)
+    p = init_synthetic(g, 0)
+    x = synthetic_state(g, 0)
+    eng = PanguEngine(g, precision)
+    eng.load_params(p)
+    y = eng.step(x.to(eng.device)).cpu()
+    return {"grid": "49x192", "max_rel_err": O.per_channel_rel_err(y, O.forward(p, x)).max().item(), "bar": 1e-3}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "f16"])
+    ap.add_argument("--n-lat", type=int, default=721)
+    ap.add_argument("--n-lon", type=int, default=1440)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run")
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from skyrim_amd.pangu.engine import PanguEngine
+    from skyrim_amd.pangu.ensemble import ensemble_mean_spread
+    from skyrim_amd.pangu.spec import PanguGeometry, init_synthetic, synthetic_state
+
+    geom = PanguGeometry(args.n_lat, args.n_lon)
+    params = init_synthetic(geom, 0)
+    dev = torch.device("cuda", local_rank)
+    eng = PanguEngine(geom, args.precision, dev)
+    eng.load_params(params)
+    x_host = synthetic_state(geom, 0, member=rank if world > 1 else None)
+    x = x_host.to(dev)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        eng.step(x, x)
+    if world > 1:   # warm the communicator outside the timed region
+        ensemble_mean_spread([x], world)
+    eng.profile(True)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.step(x, x)
+    if world > 1:
+        mean, spread = ensemble_mean_spread([x], world)
+    sync()
+    elapsed = time.perf_counter() - t0
+    stats = eng.profile_read()
+    eng.profile(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    finite = bool(torch.isfinite(x).all().item())
+
+    if rank == 0:
+        timed = [s for s in stats if s["launches"] > 0]
+        dom = max(timed, key=lambda s: s["total_ms"])
+        dom_ms = dom["total_ms"] / dom["launches"]
+        achieved = dom["flops"] / (dom_ms * 1e-3)
+        gpu_ms = sum(s["total_ms"] for s in timed) / args.steps
+        out = {
+            "metric": "6-h forecast steps/sec on 721x1440 state, 1/2/4/8 MI355X; per-channel max rel-err vs ref",
+            "value": world * args.steps / elapsed,
+            "unit": "steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "bf16" if args.precision == "bf16x3" else "f16",
+            "data": "synthetic",
+            "config": {
+                "workload": f"Pangu 6-h autoregressive rollout, {args.n_lat}x{args.n_lon}x69 state "
+                            "(13 levels x 5 vars + 4 surface), random-init weights (64 M params), "
+                            "state resident in HBM, 1 ensemble member per GPU",
+                "precision": {"bf16x3": "bf16 MFMA, hi/lo operand split (3 terms), fp32 accumulate, fp32 residual stream",
+                              "f16": "fp16 MFMA single term, fp32 accumulate, fp32 residual stream"}[args.precision],
+                "parallelism": f"member-parallel x{world}" if world > 1 else "single GPU",
+                "finite": finite,
+            },
+            "roofline": {
+                "bound": "mfma", "kernel": dom["name"], "achieved": achieved / 1e12, "peak": PEAK_MFMA_BF16 / 1e12,
+                "unit": "TFLOP/s", "frac": achieved / PEAK_MFMA_BF16, "traffic": None,
+                "avg_launch_ms": dom_ms, "alg_flops_per_launch": dom["flops"],
+                "step": {"alg_tflop": F_ALG_STEP / 1e12, "gpu_ms": gpu_ms,
+                         "mfma_frac": F_ALG_STEP / (gpu_ms * 1e-3) / PEAK_MFMA_BF16,
+                         "t_roof_ms": 1e3 * F_ALG_STEP / PEAK_MFMA_BF16},
+                "stages": {s["name"]: {"ms_per_launch": round(s["total_ms"] / s["launches"], 4),
+                                       "launches_per_step": s["launches"] // args.steps,
+                                       "tflops": round(s["flops"] / (s["total_ms"] / s["launches"] * 1e-3) / 1e12, 1),
+                                       "alg_GBps": round(s["bytes"] / (s["total_ms"] / s["launches"] * 1e-3) / 1e9, 1)}
+                           for s in timed},
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(params, geom, x_host)
+        if world == 1 and not args.no_parity:
+            out["parity"] = toy_parity(args.precision)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -89,6 +89,19 @@ int skpangu_downsample(skpangu_ctx* ctx, const float* x1_dev, float* x2_dev, voi
 int skpangu_upsample(skpangu_ctx* ctx, const float* x2_dev, float* x4_dev, void* stream);
 int skpangu_patch_recover(skpangu_ctx* ctx, const float* skip_dev, const float* x4_dev, float* state_out_dev, void* stream);
 
+/* Per-stage timing with HIP events recorded on the launch stream between the launches of
+ * skpangu_step (bench.py's roofline leg).  flops / bytes are the ALGORITHMIC work of one launch
+ * of that stage (2*M*N*K of the model's GEMM; minimum HBM traffic at the mode's storage types). */
+typedef struct skpangu_stage_stat {
+    char name[24];
+    int launches;      /* launches timed since skpangu_profile(ctx, 1) / the last read */
+    double total_ms;   /* sum of their durations */
+    double flops;      /* per launch */
+    double bytes;      /* per launch */
+} skpangu_stage_stat;
+int skpangu_profile(skpangu_ctx* ctx, int enable);
+int skpangu_profile_read(skpangu_ctx* ctx, skpangu_stage_stat* out, int cap, int* n);
+
 /* Debug view of an internal buffer ("q","k","vt","ao","hid","u","x1","x2","x4","widx<res><roll>",
  * "bias_exp<blk>").  The pointer stays owned by the context's arenas. */
 int skpangu_debug_buffer(skpangu_ctx* ctx, const char* name, void** ptr_dev, size_t* bytes);

@@ -96,6 +96,8 @@ struct IEngine {
     virtual hipError_t up(const float* x2, float* x4, hipStream_t s) = 0;
     virtual hipError_t recover(const float* skip, const float* x4, float* out, hipStream_t s) = 0;
     virtual bool debug(const std::string& name, void** p, size_t* bytes) = 0;
+    virtual void profile(bool on) = 0;
+    virtual hipError_t profile_read(skpangu_stage_stat* out, int cap, int* n) = 0;
     virtual size_t prepared_bytes() const = 0;
     virtual size_t workspace_bytes() const = 0;
 };
@@ -114,6 +116,69 @@ struct Engine : IEngine {
     size_t prep_bytes = 0, ws_bytes = 0;
     size_t bias_exp_elems[16];
     size_t q_elems = 0, ao_elems = 0, hid_elems = 0;
+
+    // ---- per-stage timing with HIP events on the launch stream (bench.py roofline leg) ---- //
+    enum Cat { C_EMBED, C_QKV0, C_ATTN0, C_PROJ0, C_FC1_0, C_FC2_0, C_QKV1, C_ATTN1, C_PROJ1, C_FC1_1, C_FC2_1, C_DOWN, C_UP, C_RECOVER, C_COUNT };
+    bool prof_on = false;
+    std::vector<hipEvent_t> prof_ev;
+    std::vector<int> prof_cat;
+    size_t prof_used = 0;
+    void mark(int cat, hipStream_t s) {
+        if (!prof_on) return;
+        if (prof_used == prof_ev.size()) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) return;
+            prof_ev.push_back(e);
+            prof_cat.push_back(-1);
+        }
+        prof_cat[prof_used] = cat;
+        (void)hipEventRecord(prof_ev[prof_used], s);
+        ++prof_used;
+    }
+    void profile(bool on) override { prof_on = on; prof_used = 0; }
+    ~Engine() override { for (hipEvent_t e : prof_ev) (void)hipEventDestroy(e); }
+    hipError_t profile_read(skpangu_stage_stat* out, int cap, int* n) override {
+        static const char* names[C_COUNT] = {"embed", "qkv_r0", "attn_r0", "proj_r0", "fc1_r0", "fc2_r0", "qkv_r1", "attn_r1",
+                                             "proj_r1", "fc1_r1", "fc2_r1", "downsample", "upsample", "recover"};
+        double ms[C_COUNT] = {0}; int cnt[C_COUNT] = {0};
+        if (prof_used > 0) {
+            hipError_t e = hipEventSynchronize(prof_ev[prof_used - 1]);
+            if (e != hipSuccess) return e;
+        }
+        for (size_t i = 0; i + 1 < prof_used; ++i) {
+            if (prof_cat[i] < 0) continue;
+            float t = 0.f;
+            hipError_t e = hipEventElapsedTime(&t, prof_ev[i], prof_ev[i + 1]);
+            if (e != hipSuccess) return e;
+            ms[prof_cat[i]] += t; cnt[prof_cat[i]]++;
+        }
+        const double sa = sizeof(S), hw = (double)g.H1 * g.W1;
+        double fl[C_COUNT], by[C_COUNT];
+        for (int r = 0; r < 2; ++r) {
+            const double C = r == 0 ? 192 : 384, mw = g.mwin[r], nt = g.ntok[r], heads = C / 32, wb = 2.0 * NW;
+            const int o = r == 0 ? 0 : 5;
+            fl[C_QKV0 + o] = 2 * mw * C * 3 * C;      by[C_QKV0 + o] = nt * C * 4 + 3 * mw * C * 2 * NPL + 3 * C * C * wb;
+            fl[C_ATTN0 + o] = g.nwin[r] * heads * 4.0 * 144 * 144 * 32;
+            by[C_ATTN0 + o] = 3 * mw * C * 2 * NPL + mw * C * sa + (double)g.types[r] * heads * 81 * 256 * 2;
+            fl[C_PROJ0 + o] = 2 * mw * C * C;          by[C_PROJ0 + o] = mw * C * sa + 2 * nt * C * 4 + C * C * wb;
+            fl[C_FC1_0 + o] = 2 * nt * C * 4 * C;      by[C_FC1_0 + o] = nt * C * 4 + nt * 4 * C * sa + 4 * C * C * wb;
+            fl[C_FC2_0 + o] = 2 * nt * C * 4 * C;      by[C_FC2_0 + o] = nt * 4 * C * sa + 2 * nt * C * 4 + 4 * C * C * wb;
+        }
+        fl[C_EMBED] = 2 * hw * 112 * 192 + 2 * 7 * hw * 160 * 192; by[C_EMBED] = (69.0 + 3) * g.n_lat * g.n_lon * 4 + g.ntok[0] * 192.0 * 4;
+        fl[C_DOWN] = 2.0 * g.ntok[1] * 768 * 384;                   by[C_DOWN] = g.ntok[0] * 192.0 * 4 + g.ntok[1] * 384.0 * 4;
+        fl[C_UP] = 2.0 * g.ntok[1] * 384 * 768 + 2.0 * g.ntok[0] * 192 * 192;
+        by[C_UP] = g.ntok[1] * 384.0 * 4 + 2 * g.ntok[0] * 192.0 * sa + g.ntok[0] * 192.0 * 4;
+        fl[C_RECOVER] = 2 * hw * 384 * 64 + 2 * 7 * hw * 384 * 160; by[C_RECOVER] = 2 * g.ntok[0] * 192.0 * 4 + 69.0 * g.n_lat * g.n_lon * 4;
+        int k = 0;
+        for (int c = 0; c < C_COUNT && k < cap; ++c, ++k) {
+            std::memset(&out[k], 0, sizeof(out[k]));
+            std::strncpy(out[k].name, names[c], sizeof(out[k].name) - 1);
+            out[k].launches = cnt[c]; out[k].total_ms = ms[c]; out[k].flops = fl[c]; out[k].bytes = by[c];
+        }
+        *n = k;
+        prof_used = 0;
+        return hipSuccess;
+    }
 
     LinW<T> take_lin(Arena& a, int N, int ldd) {
         LinW<T> l;
@@ -255,12 +320,19 @@ struct Engine : IEngine {
         const int res = layer_res(layer0), C = layer_dim(layer0), heads = layer_heads(layer0);
         const BlockW<T>& bw = w.blk[block_index(layer0, i)];
         const int* widx = w.widx[res][i & 1];
+        const int o = res == 0 ? 0 : 5;
+        mark(C_QKV0 + o, s);
         CK((op_qkv<P>(g, bw, widx, res, x, wk, s)));
+        mark(C_ATTN0 + o, s);
         AttnArgs<P> a{wk.q, wk.k, wk.vt, wk.qkv_plane, bw.bias_exp, wk.ao, C, g.nwin[res], g.nW[res], heads};
         CK(launch_attention<P>(a, s));
+        mark(C_PROJ0 + o, s);
         CK((op_proj<P>(g, bw, widx, res, x, wk, s)));
+        mark(C_FC1_0 + o, s);
         CK((op_fc1<P>(g, bw, res, x, wk, s)));
+        mark(C_FC2_0 + o, s);
         CK((op_fc2<P>(g, bw, res, x, wk, s)));
+        mark(-1, s);
         return hipSuccess;
     }
     hipError_t embed(const float* in, float* x1, hipStream_t s) override { return op_embed<P>(g, w, in, x1, s); }
@@ -269,14 +341,19 @@ struct Engine : IEngine {
     hipError_t recover(const float* skip, const float* x4, float* out, hipStream_t s) override { return op_recover<P>(g, w, skip, x4, out, s); }
 
     hipError_t step(const float* in, float* out, hipStream_t s) override {
+        mark(C_EMBED, s);
         CK(embed(in, wk.X1, s));
         for (int i = 0; i < kDepths[0]; ++i) CK(block(0, i, wk.X1, s));
+        mark(C_DOWN, s);
         CK(down(wk.X1, wk.X2, s));
         for (int i = 0; i < kDepths[1]; ++i) CK(block(1, i, wk.X2, s));
         for (int i = 0; i < kDepths[2]; ++i) CK(block(2, i, wk.X2, s));
+        mark(C_UP, s);
         CK(up(wk.X2, wk.X4, s));
         for (int i = 0; i < kDepths[3]; ++i) CK(block(3, i, wk.X4, s));
+        mark(C_RECOVER, s);
         CK(recover(wk.X1, wk.X4, out, s));
+        mark(-1, s);
         return hipSuccess;
     }
 #undef CK
@@ -433,6 +510,15 @@ int skpangu_patch_recover(skpangu_ctx* ctx, const float* skip, const float* x4, 
     NEED_PREPARED();
     if (!skip || !x4 || !out) return SKPANGU_E_ARG;
     return (int)ctx->eng->recover(skip, x4, out, (hipStream_t)stream);
+}
+int skpangu_profile(skpangu_ctx* ctx, int enable) {
+    if (!ctx) return SKPANGU_E_ARG;
+    ctx->eng->profile(enable != 0);
+    return 0;
+}
+int skpangu_profile_read(skpangu_ctx* ctx, skpangu_stage_stat* out, int cap, int* n) {
+    if (!ctx || !out || !n || cap <= 0) return SKPANGU_E_ARG;
+    return (int)ctx->eng->profile_read(out, cap, n);
 }
 int skpangu_debug_buffer(skpangu_ctx* ctx, const char* name, void** ptr, size_t* bytes) {
     if (!ctx || !name || !ptr || !bytes) return SKPANGU_E_ARG;

@@ -31,11 +31,16 @@ class SkSizes(ctypes.Structure):
                 ("n_params", ctypes.c_int)]
 
 
+class SkStageStat(ctypes.Structure):
+    _fields_ = [("name", ctypes.c_char * 24), ("launches", ctypes.c_int), ("total_ms", ctypes.c_double),
+                ("flops", ctypes.c_double), ("bytes", ctypes.c_double)]
+
+
 EXPORTS = [
     "skpangu_abi_version", "skpangu_error_string", "skpangu_query_sizes", "skpangu_param_info",
     "skpangu_create", "skpangu_destroy", "skpangu_prepare", "skpangu_step", "skpangu_patch_embed",
     "skpangu_block", "skpangu_downsample", "skpangu_upsample", "skpangu_patch_recover",
-    "skpangu_debug_buffer",
+    "skpangu_debug_buffer", "skpangu_profile", "skpangu_profile_read",
 ]
 
 _lib = None
@@ -70,6 +75,8 @@ def load_library() -> ctypes.CDLL:
     lib.skpangu_upsample.argtypes = [vp, vp, vp, vp]
     lib.skpangu_patch_recover.argtypes = [vp, vp, vp, vp, vp]
     lib.skpangu_debug_buffer.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_size_t)]
+    lib.skpangu_profile.argtypes = [vp, ci]
+    lib.skpangu_profile_read.argtypes = [vp, ctypes.POINTER(SkStageStat), ci, ctypes.POINTER(ci)]
     for name in EXPORTS:
         getattr(lib, name)
     _lib = lib
@@ -164,6 +171,17 @@ class PanguEngine:
                                          self._stream()), "skpangu_step")
         return out
 
+    def profile(self, on: bool):
+        """Record HIP events between the launches of ``step`` (per-stage kernel time, bench.py)."""
+        _check(self.lib.skpangu_profile(self._ctx, 1 if on else 0), "skpangu_profile")
+
+    def profile_read(self) -> list[dict]:
+        arr = (SkStageStat * 32)()
+        n = ctypes.c_int()
+        _check(self.lib.skpangu_profile_read(self._ctx, arr, 32, ctypes.byref(n)), "skpangu_profile_read")
+        return [dict(name=arr[i].name.decode(), launches=arr[i].launches, total_ms=arr[i].total_ms,
+                     flops=arr[i].flops, bytes=arr[i].bytes) for i in range(n.value)]
+
     # ---- stage-level (tests) ------------------------------------------- #
     def tokens(self, layer: int):
         return self.geom.tokens(layer), self.geom.dim(layer)
@@ -176,7 +194,7 @@ class PanguEngine:
         return out
 
     def block(self, layer: int, i: int, x: torch.Tensor) -> torch.Tensor:
-        y = x.clone()
+        y = x.contiguous().clone()
         with torch.cuda.device(self.device):
             _check(self.lib.skpangu_block(self._ctx, layer, i, self._chk_dev(y, self.tokens(layer)), self._stream()), "skpangu_block")
         return y
@@ -184,21 +202,21 @@ class PanguEngine:
     def downsample(self, x1: torch.Tensor) -> torch.Tensor:
         out = torch.empty(self.tokens(2), dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
-            _check(self.lib.skpangu_downsample(self._ctx, self._chk_dev(x1, self.tokens(1)), self._chk_dev(out), self._stream()),
+            _check(self.lib.skpangu_downsample(self._ctx, self._chk_dev(x1.contiguous(), self.tokens(1)), self._chk_dev(out), self._stream()),
                    "skpangu_downsample")
         return out
 
     def upsample(self, x2: torch.Tensor) -> torch.Tensor:
         out = torch.empty(self.tokens(1), dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
-            _check(self.lib.skpangu_upsample(self._ctx, self._chk_dev(x2, self.tokens(2)), self._chk_dev(out), self._stream()),
+            _check(self.lib.skpangu_upsample(self._ctx, self._chk_dev(x2.contiguous(), self.tokens(2)), self._chk_dev(out), self._stream()),
                    "skpangu_upsample")
         return out
 
     def patch_recover(self, skip: torch.Tensor, x4: torch.Tensor) -> torch.Tensor:
         out = torch.zeros(self.state_shape, dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
-            _check(self.lib.skpangu_patch_recover(self._ctx, self._chk_dev(skip, self.tokens(1)), self._chk_dev(x4, self.tokens(1)),
+            _check(self.lib.skpangu_patch_recover(self._ctx, self._chk_dev(skip.contiguous(), self.tokens(1)), self._chk_dev(x4.contiguous(), self.tokens(1)),
                                                   self._chk_dev(out), self._stream()), "skpangu_patch_recover")
         return out
 

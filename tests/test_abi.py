@@ -1,0 +1,70 @@
+"""CPU tests of the C-ABI boundary: the library loads, exports every symbol include/skyrim_pangu.h
+declares, and its host-side planning (sizes, parameter table, argument errors) works without a GPU."""
+import ctypes
+import re
+from pathlib import Path
+
+import pytest
+
+from skyrim_amd.pangu import engine as E
+from skyrim_amd.pangu.spec import PanguGeometry, param_offsets
+
+HEADER = Path(__file__).resolve().parent.parent / "include" / "skyrim_pangu.h"
+
+
+def declared_symbols():
+    text = HEADER.read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(skpangu_[a-z_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = E.load_library()
+    syms = declared_symbols()
+    assert len(syms) >= 14
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in skyrim_pangu.h but not exported"
+    assert set(syms) == set(E.EXPORTS)
+    assert lib.skpangu_abi_version() == 1
+
+
+@pytest.mark.parametrize("prec", ["bf16x3", "f16"])
+@pytest.mark.parametrize("grid", [(49, 192), (721, 1440)])
+def test_param_table_matches_host_spec(grid, prec):
+    g = PanguGeometry(*grid)
+    table = E.param_table(g, prec)
+    offs, total = param_offsets(g)
+    sizes = E.query_sizes(g, prec)
+    assert sizes.master_floats == total and sizes.n_params == len(offs)
+    assert sizes.state_floats == 69 * grid[0] * grid[1]
+    for name, off, shape in table:
+        assert offs[name] == (off, shape)
+
+
+def test_sizes_full_grid_fit_one_gpu():
+    s = E.query_sizes(PanguGeometry(721, 1440), "bf16x3")
+    assert s.prepared_bytes + s.workspace_bytes < 16 * 2 ** 30      # a few GB of the 288 GB
+
+
+def test_bad_arguments_are_errors_not_crashes():
+    lib = E.load_library()
+    out = E.SkSizes()
+    for cfg in (E.SkConfig(721, 1000, 0), E.SkConfig(4, 1440, 0), E.SkConfig(721, 1440, 7)):
+        assert lib.skpangu_query_sizes(ctypes.byref(cfg), ctypes.byref(out)) == -1
+    assert lib.skpangu_query_sizes(None, ctypes.byref(out)) == -1
+    assert lib.skpangu_step(None, None, None, None) == -1
+    assert lib.skpangu_prepare(None, None, None) == -1
+    assert b"geometry" in lib.skpangu_error_string(-1)
+    with pytest.raises(ValueError):
+        PanguGeometry(721, 1000)
+
+
+def test_engine_refuses_to_run_without_gpu_or_library(monkeypatch, tmp_path):
+    import torch
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            E.PanguEngine(PanguGeometry(49, 192))
+    monkeypatch.setattr(E, "_lib", None)
+    monkeypatch.setenv("SKYRIM_PANGU_LIB", str(tmp_path / "missing.so"))
+    with pytest.raises(RuntimeError, match="not found"):
+        E.load_library()

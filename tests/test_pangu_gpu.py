@@ -1,0 +1,187 @@
+"""GPU parity tests: the HIP engine, called through the C ABI, against the CPU oracle.
+
+Tolerances (floating point; stated per the north star): per-channel max|y - ref| / max|ref| <= 1e-3
+for the default bf16x3 mode on a full step (observed ~2e-5); the single-term fp16 mode is a speed
+mode and is held to 5e-3 (observed ~1.2e-3).  Stage-level tests use max-abs / max-abs-ref.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import pangu_oracle as O
+from skyrim_amd.pangu.spec import PanguGeometry, init_synthetic, synthetic_state
+
+pytestmark = pytest.mark.gpu
+
+STAGE_TOL = {"bf16x3": 1e-4, "f16": 4e-3}
+STEP_TOL = {"bf16x3": 1e-4, "f16": 5e-3}       # bf16x3 is asserted 10x inside the 1e-3 bar
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).abs().max() / b.abs().max()).item()
+
+
+@pytest.fixture(scope="module")
+def ref(toy):
+    g, params, x = toy
+    taps = {}
+    y = O.forward(params, x, taps=taps)
+    return taps, y
+
+
+@pytest.fixture(scope="module", params=["bf16x3", "f16"])
+def eng(request, toy):
+    from skyrim_amd.pangu.engine import PanguEngine
+    g, params, x = toy
+    e = PanguEngine(g, request.param, "cuda:0")
+    e.load_params(params)
+    return e
+
+
+def test_native_library_is_the_path_that_runs(eng):
+    import ctypes
+    assert isinstance(eng.lib, ctypes.CDLL) and "libskyrim_pangu.so" in eng.lib._name
+    with open("/proc/self/maps") as f:
+        assert "libskyrim_pangu.so" in f.read()
+
+
+def test_patch_embed(eng, toy, ref):
+    g, params, x = toy
+    assert rel(eng.patch_embed(x.cuda()), ref[0]["embed"]) < STAGE_TOL[eng.precision]
+
+
+@pytest.mark.parametrize("layer,i", [(1, 0), (1, 1), (2, 0), (2, 1), (2, 5), (3, 4), (4, 1)])
+def test_earth_specific_block(eng, toy, ref, layer, i):
+    """Window gather (pad/roll/partition), QKV, earth-specific bias + shift mask, softmax, PV, proj,
+    LayerNorm, window reverse + crop, residual, MLP -- one block, plain and rolled, both resolutions."""
+    g, params, x = toy
+    torch.manual_seed(layer * 10 + i)
+    xin = {1: ref[0]["embed"], 2: ref[0]["down"], 3: ref[0]["down"], 4: ref[0]["up"]}[layer].contiguous()
+    want = O.earth_block(O._block_params(params, layer, i), xin, O.Geometry(g.n_lat, g.n_lon).res(layer), O.HEADS[layer - 1], i % 2 == 1)
+    got = eng.block(layer, i, xin.cuda())
+    assert rel(got, want) < STAGE_TOL[eng.precision]
+
+
+def test_downsample_upsample_recover(eng, toy, ref):
+    taps, y = ref
+    tol = STAGE_TOL[eng.precision]
+    assert rel(eng.downsample(taps["layer1.block1"].cuda()), taps["down"]) < tol
+    assert rel(eng.upsample(taps["layer3"].cuda()), taps["up"]) < tol
+    got = eng.patch_recover(taps["layer1.block1"].cuda(), taps["layer4"].cuda())
+    assert O.per_channel_rel_err(got.cpu(), y).max().item() < tol
+
+
+def test_full_step_per_channel(eng, toy, ref):
+    g, params, x = toy
+    y = eng.step(x.cuda())
+    assert torch.isfinite(y).all()
+    e = O.per_channel_rel_err(y.cpu(), ref[1])
+    assert e.max().item() < STEP_TOL[eng.precision], e
+
+
+def test_step_matches_golden_fixture(eng, toy):
+    g, params, x = toy
+    gold = np.load(__file__.rsplit("/", 1)[0] + "/golden/pangu_toy_49x192.npz")
+    y = eng.step(x.cuda()).cpu()
+    for c in range(69):
+        want = torch.from_numpy(gold["step1_sub"][c])
+        assert ((y[c, ::6, ::16] - want).abs().max() / torch.from_numpy(gold["step1_channel_absmax"])[c]).item() < STEP_TOL[eng.precision]
+
+
+def test_rollout_4_steps_in_place(eng, toy):
+    """config[1]: 24-h rollout = 4 autoregressive 6-h steps, state never leaves HBM (in-place step)."""
+    g, params, x = toy
+    xs = x.cuda().clone()
+    xr = x
+    for _ in range(4):
+        eng.step(xs, xs)
+        xr = O.forward(params, xr)
+    e = O.per_channel_rel_err(xs.cpu(), xr)
+    assert e.max().item() < 2 * STEP_TOL[eng.precision]
+
+
+def test_deterministic(eng, toy):
+    g, params, x = toy
+    a = eng.step(x.cuda())
+    b = eng.step(x.cuda())
+    assert torch.equal(a, b)
+
+
+def test_longitude_shift_equivariance_toy(eng, toy):
+    from skyrim_amd.pangu.engine import PanguEngine
+    g, params, x = toy
+    y = eng.step(x.cuda())
+    p2 = dict(params)
+    p2["const_masks"] = torch.roll(params["const_masks"], 96, dims=-1)
+    e2 = PanguEngine(g, eng.precision, "cuda:0")
+    e2.load_params(p2)
+    y2 = e2.step(torch.roll(x, 96, dims=-1).cuda())
+    assert O.per_channel_rel_err(torch.roll(y2, -96, dims=-1).cpu(), y.cpu()).max().item() < 3 * STEP_TOL[eng.precision]
+
+
+def test_step_before_prepare_is_an_error(toy):
+    from skyrim_amd.pangu.engine import PanguEngine
+    g, params, x = toy
+    e = PanguEngine(g, "bf16x3", "cuda:0")
+    with pytest.raises(RuntimeError, match="not prepared"):
+        e.step(x.cuda())
+    e.load_params(params)
+    with pytest.raises(ValueError):
+        e.step(x.cuda()[:, :, :96].contiguous())
+
+
+def test_profile_hooks_cover_the_step(eng, toy):
+    g, params, x = toy
+    eng.profile(True)
+    eng.step(x.cuda())
+    stats = eng.profile_read()
+    eng.profile(False)
+    by = {s["name"]: s for s in stats}
+    assert by["fc1_r1"]["launches"] == 12 and by["qkv_r0"]["launches"] == 4 and by["embed"]["launches"] == 1
+    assert all(s["total_ms"] > 0 for s in stats)
+
+
+# --------------------------------------------------------------------------------------------- #
+#  BASELINE.json full size: 721 x 1440
+# --------------------------------------------------------------------------------------------- #
+@pytest.fixture(scope="module")
+def full():
+    from skyrim_amd.pangu.engine import PanguEngine
+    g = PanguGeometry(721, 1440)
+    params = init_synthetic(g, 0)
+    x = synthetic_state(g, 0)
+    e = PanguEngine(g, "bf16x3", "cuda:0")
+    e.load_params(params)
+    return g, params, x, e
+
+
+@pytest.mark.timeout(900)
+def test_full_size_step_vs_oracle(full):
+    """The headline configuration against the CPU oracle, per channel (the north star's 1e-3 bar)."""
+    g, params, x, e = full
+    y = e.step(x.cuda())
+    want = O.forward(params, x)
+    err = O.per_channel_rel_err(y.cpu(), want)
+    assert torch.isfinite(y).all()
+    assert err.max().item() < 1e-3, err
+    assert err.max().item() < 1e-4, err          # what bf16x3 actually delivers
+
+
+@pytest.mark.timeout(900)
+def test_full_size_longitude_shift_equivariance_and_fp16_mode(full):
+    """Size-independent property at full size (no oracle needed) + agreement of the two precision modes."""
+    from skyrim_amd.pangu.engine import PanguEngine
+    g, params, x, e = full
+    y = e.step(x.cuda())
+    p2 = dict(params)
+    p2["const_masks"] = torch.roll(params["const_masks"], 480, dims=-1)
+    e2 = PanguEngine(g, "bf16x3", "cuda:0")
+    e2.load_params(p2)
+    y2 = e2.step(torch.roll(x, 480, dims=-1).cuda())
+    assert O.per_channel_rel_err(torch.roll(y2, -480, dims=-1).cpu(), y.cpu()).max().item() < 2e-4
+    del e2
+    e3 = PanguEngine(g, "f16", "cuda:0")
+    e3.load_params(params)
+    y3 = e3.step(x.cuda())
+    assert O.per_channel_rel_err(y3.cpu(), y.cpu()).max().item() < 5e-3
