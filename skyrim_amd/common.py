@@ -1,0 +1,98 @@
+"""Forecast ids, file naming and ``save_forecast`` -- the on-disk contract of
+/root/reference/skyrim/common.py (:23-31 id, :34-45 SaveConfig, :48-69 file name, :115-204 save).
+
+Local netCDF (per-step files) and local zarr (one store per forecast id, appended along ``time``) are
+implemented; the s3 / Hugging Face targets need network services and raise NotImplementedError.
+
+Divergences from the reference as written (each is a defect there):
+  * an omitted ``file_type`` keeps SaveConfig's default "netcdf" for local targets (the reference
+    forces "zarr" for every target because ``target`` is always truthy, common.py:123-129);
+  * local zarr appends along "time" (the reference names a "step" dim the array does not have);
+  * ``filter_vars`` selects channels (the reference indexes a DataArray like a Dataset, common.py:132).
+"""
+from __future__ import annotations
+
+import hashlib
+import os
+import time
+from dataclasses import dataclass, field
+from datetime import datetime
+from pathlib import Path
+from typing import Callable, Literal
+from urllib.parse import urlparse
+
+AVAILABLE_MODELS = ["pangu", "fourcastnet", "fourcastnet_v2", "graphcast", "dlwp"]
+LOCAL_CACHE = os.path.join(os.path.expanduser("~"), ".cache", "skyrim")
+OUTPUT_DIR = str(Path.cwd() / "outputs")
+
+_B58 = "123456789ABCDEFGHJKLMNPQRSTUVWXYZabcdefghijkmnopqrstuvwxyz"
+
+
+def _b58encode(b: bytes) -> str:
+    n = int.from_bytes(b, "big")
+    out = ""
+    while n:
+        n, r = divmod(n, 58)
+        out = _B58[r] + out
+    pad = len(b) - len(b.lstrip(b"\0"))
+    return "1" * pad + out
+
+
+def generate_forecast_id(length=10):
+    """Unique forecast id from the current time: base58(sha256(str(time.time())))[:length]."""
+    return _b58encode(hashlib.sha256(str(time.time()).encode()).digest())[:length]
+
+
+@dataclass
+class SaveConfig:
+    forecast_id: str = ""
+    output_dir: str = OUTPUT_DIR
+    file_type: str = "netcdf"
+    filter_vars: tuple = ()
+    mapping_func: Callable = lambda x: x
+    zarr_store_config: dict = field(default_factory=dict)
+
+    def __post_init__(self):
+        if not self.forecast_id:
+            self.forecast_id = generate_forecast_id()
+
+
+def generate_filename(model: str, start_time: datetime, pred_time: datetime,
+                      ic_source: Literal["cds", "file", "ifs", "gfs"] = "cds"):
+    """``{model}__{src}__{%Y%m%d_%H:%M}__{%Y%m%d_%H:%M}.nc`` (parsed back by the reference's plotting lib)."""
+    return (f"{model}" + "__" + f"{ic_source}__" + f"{start_time.strftime('%Y%m%d_%H:%M')}" + "__"
+            + f"{pred_time.strftime('%Y%m%d_%H:%M')}.nc")
+
+
+def save_forecast(pred, model_name: str, start_time: datetime, pred_time: datetime,
+                  source: Literal["cds", "file", "ifs", "gfs"] = "cds", config: dict = {}):
+    requested_file_type = config.get("file_type")
+    config = SaveConfig(**config)
+    p = urlparse(str(config.output_dir))
+    target = p.scheme or "local"
+    if target != "local" and not requested_file_type:
+        config.file_type = "zarr"          # remote targets default to zarr
+
+    pred = config.mapping_func(pred)
+    if len(config.filter_vars):
+        pred = pred.sel(channel=list(config.filter_vars))
+
+    if target == "local":
+        if config.file_type == "netcdf":
+            filename = generate_filename(model_name, start_time, pred_time, source)
+            output_path = Path(config.output_dir) / config.forecast_id / filename
+            output_path.parent.mkdir(parents=True, exist_ok=True)
+            pred.to_netcdf(output_path, engine="scipy")
+        elif config.file_type == "zarr":
+            output_path = str(Path(config.output_dir) / config.forecast_id)
+            if Path(output_path).exists():
+                pred.to_zarr(output_path, append_dim="time", mode="a", consolidated=True)
+            else:
+                pred.to_zarr(output_path, mode="w", consolidated=True)
+        else:
+            raise ValueError(f"Invalid file type. {config.file_type} not supported.")
+    elif target in ("s3", "hf"):
+        raise NotImplementedError(f"{target}:// targets need network services that this build does not ship")
+    else:
+        raise ValueError(f"Unknown output target {target!r}")
+    return str(output_path)

@@ -1,0 +1,93 @@
+"""netCDF-3 persistence of a labelled array through scipy.io.netcdf_file.
+
+The reference writes per-step files with ``pred.to_netcdf(output_path, engine="scipy")``
+(/root/reference/skyrim/common.py:144), i.e. netCDF-3 classic in xarray's CF encoding; this module
+produces the same on-disk convention without xarray: dimension variables for every coordinate,
+datetimes as "hours since <t0>" (float64, proleptic_gregorian), strings as fixed-width char arrays
+with a trailing ``string<N>`` dimension, and the payload variable named like xarray's unnamed
+DataArray (``__xarray_dataarray_variable__``).  Files written here open with
+``xarray.open_dataarray(path)``; files written by xarray's scipy engine read back here.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+UNNAMED = "__xarray_dataarray_variable__"
+
+
+def _encode_time(vals: np.ndarray):
+    t0 = vals.reshape(-1)[0].astype("datetime64[s]")
+    hours = (vals.astype("datetime64[s]") - t0).astype("timedelta64[s]").astype(np.float64) / 3600.0
+    return hours, f"hours since {str(t0).replace('T', ' ')}"
+
+
+def _decode_time(vals: np.ndarray, units: str) -> np.ndarray:
+    unit, _, epoch = units.partition(" since ")
+    scale = {"seconds": 1.0, "minutes": 60.0, "hours": 3600.0, "days": 86400.0}[unit.strip()]
+    t0 = np.datetime64(epoch.strip().replace(" ", "T"), "s")
+    return (t0 + (np.asarray(vals, dtype=np.float64) * scale).round().astype("timedelta64[s]")).astype("datetime64[ns]")
+
+
+def _native(a: np.ndarray) -> np.ndarray:
+    return a.astype(a.dtype.newbyteorder("=")) if a.dtype.byteorder not in ("=", "|") else a
+
+
+def write_dataarray_netcdf3(da, path):
+    from scipy.io import netcdf_file
+    with netcdf_file(str(path), "w", version=2) as f:
+        for d, n in zip(da.dims, da.shape):
+            f.createDimension(d, int(n))
+        for name, vals in da._coords.items():
+            dims = (name,) if (name in da.dims and vals.ndim == 1) else ()
+            if np.issubdtype(vals.dtype, np.datetime64):
+                enc, units = _encode_time(vals)
+                v = f.createVariable(name, "d", dims)
+                v[...] = enc if dims else enc.reshape(())
+                v.units = units
+                v.calendar = "proleptic_gregorian"
+            elif vals.dtype.kind in "US":
+                b = np.char.encode(vals.astype(str), "utf-8") if vals.dtype.kind == "U" else vals
+                width = max(1, b.dtype.itemsize)
+                sdim = f"string{width}"
+                if sdim not in f.dimensions:
+                    f.createDimension(sdim, width)
+                v = f.createVariable(name, "c", dims + (sdim,))
+                v[...] = b.astype(f"S{width}").reshape(b.shape + (1,)).view("S1").reshape(b.shape + (width,))
+            else:
+                arr = vals.astype(np.float64) if vals.dtype.kind == "f" else vals.astype(np.int32)
+                v = f.createVariable(name, arr.dtype.char, dims)
+                v[...] = arr
+        payload = da.values
+        if payload.dtype == np.float16 or payload.dtype.kind not in "fi":
+            payload = payload.astype(np.float32)
+        v = f.createVariable(da.name or UNNAMED, payload.dtype.char, da.dims)
+        v[...] = payload
+        coord_names = " ".join(k for k in da._coords if k not in da.dims)
+        if coord_names:
+            v.coordinates = coord_names
+
+
+def read_dataarray_netcdf3(path):
+    from scipy.io import netcdf_file
+    from .labeled import DataArray
+    with netcdf_file(str(path), "r", mmap=False) as f:
+        names = list(f.variables)
+        dimnames = set(f.dimensions)
+        data_vars = [n for n in names if n not in dimnames and len(f.variables[n].dimensions) > 1
+                     and not (f.variables[n].typecode() == "c" and len(f.variables[n].dimensions) == 2)]
+        if len(data_vars) != 1:
+            raise ValueError(f"expected exactly one data variable in {path}, found {data_vars}")
+        var = f.variables[data_vars[0]]
+        coords = {}
+        for n in names:
+            if n == data_vars[0]:
+                continue
+            v = f.variables[n]
+            vals = _native(np.array(v[...]))
+            if v.typecode() == "c":
+                vals = np.array([b"".join(row).decode("utf-8").rstrip("\x00 ") for row in vals.reshape(-1, vals.shape[-1])]).reshape(vals.shape[:-1])
+            elif hasattr(v, "units") and " since " in (v.units.decode() if isinstance(v.units, bytes) else v.units):
+                vals = _decode_time(vals, v.units.decode() if isinstance(v.units, bytes) else v.units)
+            coords[n] = vals
+        name = None if data_vars[0] == UNNAMED else data_vars[0]
+        return DataArray(_native(np.array(var[...])), var.dimensions, coords, name)

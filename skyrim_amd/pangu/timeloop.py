@@ -1,0 +1,70 @@
+"""``PanguTimeLoop``: the earth2mip ``TimeLoop`` protocol on top of the HIP engine.
+
+This is the drop-in seam of the reference: the object ``PanguModel.build_model()``
+returns (/root/reference/skyrim/core/models/pangu.py:45-46) and ``run_basic_inference`` iterates
+(/root/reference/skyrim/core/models/utils.py:34-40):
+
+    for k, (time, output, restart) in enumerate(model(time, x)):   # k = 0 echoes the initial state
+
+  * ``x``: float32 ``(B=1, n_history_levels=1, 69, n_lat, n_lon)`` on ``.device``
+  * yields ``(time, (B, 69, n_lat, n_lon) tensor, restart)``; infinite, the caller breaks
+  * every step is the 6-h network (the reference's rollout re-creates the loop each step, base.py:131-132)
+
+The state stays in HBM between steps; the yielded tensor is a fresh buffer the caller owns.
+"""
+from __future__ import annotations
+
+import datetime
+import os
+from dataclasses import dataclass
+
+import torch
+
+from .engine import PanguEngine
+from .spec import CHANNELS, PanguGeometry, init_synthetic
+
+
+@dataclass
+class Grid:
+    lat: list
+    lon: list
+
+    @property
+    def shape(self):
+        return (len(self.lat), len(self.lon))
+
+
+class PanguTimeLoop:
+    n_history_levels = 1
+    time_step = datetime.timedelta(hours=6)
+    in_channel_names = list(CHANNELS)
+    out_channel_names = list(CHANNELS)
+
+    def __init__(self, params: dict | None = None, geom: PanguGeometry | None = None, precision: str = "bf16x3",
+                 device: str | torch.device = "cuda:0", seed: int = 0):
+        self.geom = geom or PanguGeometry()
+        self.engine = PanguEngine(self.geom, precision, device)
+        if params is None:
+            path = os.environ.get("SKYRIM_PANGU_WEIGHTS")
+            params = torch.load(path, map_location="cpu") if path else init_synthetic(self.geom, seed)
+        self.engine.load_params(params)
+        self.grid = Grid(self.geom.lat, self.geom.lon)
+
+    @property
+    def device(self):
+        return self.engine.device
+
+    def to(self, device):
+        if torch.device(device) != self.engine.device:
+            raise NotImplementedError("the engine's arenas are bound to one GPU; build a new PanguTimeLoop for another device")
+        return self
+
+    def __call__(self, time: datetime.datetime, x: torch.Tensor, restart=None):
+        if x.dim() != 5 or x.shape[0] != 1 or x.shape[1] != self.n_history_levels or tuple(x.shape[2:]) != self.engine.state_shape:
+            raise ValueError(f"expected x of shape (1, 1, {', '.join(map(str, self.engine.state_shape))}), got {tuple(x.shape)}")
+        state = x[0, 0].to(self.device, torch.float32).contiguous()
+        yield time, state.unsqueeze(0).clone(), restart
+        while True:
+            state = self.engine.step(state)          # new buffer each step: the caller keeps the yielded one
+            time = time + self.time_step
+            yield time, state.unsqueeze(0), restart

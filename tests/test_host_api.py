@@ -1,0 +1,208 @@
+"""CPU tests of the host-side mirror of the reference API (skyrim.core / skyrim.common), driven by a
+fake TimeLoop exactly like the reference's own tests/core/test_base.py (BoringModel)."""
+import datetime
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from skyrim_amd import common
+from skyrim_amd.core import Skyrim
+from skyrim_amd.core import models as models_pkg
+from skyrim_amd.core.models.base import GlobalModel, GlobalPrediction, GlobalPredictionRollout, adjust_lead_time
+from skyrim_amd.core.models.ensemble import GlobalEnsemble
+from skyrim_amd.core.models.utils import perturb_initial_conditions, run_basic_inference
+from skyrim_amd.datasource import SyntheticDataSource, get_data_source
+from skyrim_amd.labeled import DataArray, open_dataarray
+from skyrim_amd.pangu.spec import CHANNELS, PanguGeometry
+
+GEOM = PanguGeometry(9, 96)
+
+
+class BoringTimeLoop:
+    """CPU stand-in with the TimeLoop protocol: each 6-h step adds 1 to every field."""
+    n_history_levels = 1
+    time_step = datetime.timedelta(hours=6)
+    device = torch.device("cpu")
+
+    def __init__(self, channels):
+        self.in_channel_names = list(channels)
+        self.out_channel_names = list(channels)
+        self.geom = GEOM
+        self.grid = GEOM
+
+    def __call__(self, time, x, restart=None):
+        assert x.shape == (1, 1, len(self.in_channel_names), GEOM.n_lat, GEOM.n_lon)
+        state = x[:, 0].clone()
+        yield time, state, restart
+        while True:
+            state = state + 1.0
+            time = time + self.time_step
+            yield time, state, restart
+
+
+class BoringGlobalModel(GlobalModel):
+    model_name = "boring"
+    channels = ["u1000", "v1000", "t2m"]
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(self.model_name, *args, **kwargs)
+
+    def build_model(self):
+        return BoringTimeLoop(self.channels)
+
+    @property
+    def time_step(self):
+        return self.model.time_step
+
+    @property
+    def in_channel_names(self):
+        return self.model.in_channel_names
+
+    @property
+    def out_channel_names(self):
+        return self.model.out_channel_names
+
+
+class OtherBoringModel(BoringGlobalModel):
+    model_name = "other"
+    channels = ["t2m", "u1000", "msl"]
+
+
+@pytest.fixture()
+def boring_registry(monkeypatch):
+    monkeypatch.setitem(models_pkg.MODELS, "boring", BoringGlobalModel)
+    monkeypatch.setitem(models_pkg.MODELS, "other", OtherBoringModel)
+
+
+T0 = datetime.datetime(2024, 5, 13, 18, 0)
+
+
+@pytest.mark.parametrize("lead,want", [(0, 6), (5, 6), (6, 6), (13, 12), (24, 24), (167, 162)])
+def test_adjust_lead_time(lead, want):
+    assert adjust_lead_time(lead, 6) == want          # base.py:13-15
+
+
+def test_ic_source_selection_and_validation():
+    m = BoringGlobalModel(ic_source="ifs")           # reference tests/core/test_base.py:24-27 (source by name)
+    assert isinstance(m.data_source, SyntheticDataSource) and m.data_source.channel_names == m.in_channel_names
+    with pytest.raises(ValueError):
+        BoringGlobalModel(ic_source="nope")
+    with pytest.raises(ValueError):
+        get_data_source(["t2m"], "nope")
+
+
+def test_predict_one_step_layout():
+    m = BoringGlobalModel(ic_source="gfs")
+    da = m.predict_one_step(T0)
+    assert set(da.dims) == {"time", "channel", "lat", "lon"}          # reference tests/core/test_graphcast.py:14
+    assert da.dims == ("time", "channel", "lat", "lon") and da.shape == (2, 3, 9, 96)
+    assert da.channel.values.tolist() == m.out_channel_names          # test_graphcast.py:22
+    assert list(da.time.values) == [np.datetime64(T0, "ns"), np.datetime64(T0 + datetime.timedelta(hours=6), "ns")]
+    assert da.lat.values[0] == 90.0 and da.lat.values[-1] == -90.0 and da.lon.values[0] == 0.0
+    assert np.allclose(da.values[1], da.values[0] + 1.0)              # entry 0 echoes the initial state
+    assert da.values.dtype == np.float32
+
+
+def test_rollout_saves_one_file_per_step(tmp_path):
+    m = BoringGlobalModel(ic_source="gfs")
+    cfg = {"output_dir": str(tmp_path), "file_type": "netcdf"}
+    pred, paths = m.rollout(T0, n_steps=3, save=True, save_config=cfg)
+    assert len(paths) == 3 and "forecast_id" in cfg                   # rollout mutates save_config (base.py:129-130)
+    names = [Path(p).name for p in paths]
+    assert names[0] == "boring__gfs__20240513_18:00__20240514_00:00.nc"
+    assert names[1] == "boring__file__20240514_00:00__20240514_06:00.nc"      # source flips to "file" (base.py:144)
+    assert all(Path(p).parent.name == cfg["forecast_id"] for p in paths)
+    assert pred.shape == (2, 3, 9, 96)
+    first = m.predict_one_step(T0)
+    assert np.allclose(pred.values[1], first.values[0] + 3.0)         # state fed back step to step
+    back = open_dataarray(paths[-1])
+    assert back.shape == (2, 3, 9, 96) and np.allclose(back.values, pred.values)
+    # restart from a saved step (utils.py:24-27): path as initial condition
+    again = run_basic_inference(m.model, 1, m.data_source, T0, x=paths[-1])
+    assert np.allclose(again.values[0], pred.values[1])
+    roll = GlobalPredictionRollout(paths)
+    assert len(roll.surface_wind_speed(10.0, 20.0)) == 3
+
+
+def test_forecast_keeps_every_step_and_selects_channels():
+    m = BoringGlobalModel(ic_source="cds")
+    da = m.forecast(T0, n_steps=4, channels=["t2m"])
+    assert da.shape == (5, 1, 9, 96) and da.channel.values.tolist() == ["t2m"]
+    assert np.allclose(da.values[4] - da.values[0], 4.0)
+
+
+def test_skyrim_facade(boring_registry, tmp_path):
+    assert "pangu" in Skyrim.list_available_models()
+    with pytest.raises(ValueError, match=r"Invalid model name\(s\): \['nope'\]"):
+        Skyrim("nope")                                                # skyrim.py:20-22
+    s = Skyrim("boring", ic_source="gfs")
+    pred, paths = s.predict("20240513", "1800", lead_time=13, save=True, save_config={"output_dir": str(tmp_path), "file_type": "netcdf"})
+    assert isinstance(pred, GlobalPrediction) and len(paths) == 2     # 13 h -> 12 h -> 2 steps
+    assert pred.prediction.shape == (2, 3, 9, 96)
+    pred2, paths2 = s.predict("20240513", "1800", lead_time=6)
+    assert paths2 == [] and pred2.prediction.time.values[-1] == np.datetime64("2024-05-14T00:00")
+    fc = s.forecast(datetime.datetime(2024, 5, 13, 18, 0, 33, 7), n_steps=2)
+    assert fc.shape == (3, 3, 9, 96) and fc.time.values[0] == np.datetime64("2024-05-13T18:00")
+
+
+def test_global_prediction_accessors():
+    m = BoringGlobalModel(ic_source="cds")
+    gp = GlobalPrediction(m.predict_one_step(T0), model_name="boring")
+    v = gp.prediction.values
+    assert gp.point(90.0, 0.0, "t2m", n_step=1) == pytest.approx(v[1, 2, 0, 0])
+    assert gp.point(21.0, -3.75, "t2m", n_step=0) == pytest.approx(v[0, 2, 3, 95])      # negative lon wraps, nearest lat
+    u, w = gp.point_wind_uv(0.0, 180.0, 1000)
+    assert gp.wind_speed(0.0, 180.0, 1000) == pytest.approx((u ** 2 + w ** 2) ** 0.5)
+    assert gp.surface_wind_speed(0.0, 180.0) == gp.wind_speed(0.0, 180.0, 1000)
+    assert gp.slice(channel="u1000").shape == (2, 9, 96)
+    assert gp.slice(lat=slice(90, 0), lon=slice(0, 90)).shape[2:] == (5, 25)
+    with pytest.raises(ValueError):
+        GlobalPrediction(123)
+
+
+def test_save_forecast_local_netcdf_and_zarr(tmp_path):
+    # mirrors reference tests/test_common.py:31-53 (path parts + shape round trip)
+    m = BoringGlobalModel(ic_source="cds")
+    pred = m.predict_one_step(T0)
+    fid = common.generate_forecast_id()
+    assert len(fid) == 10 and fid != common.generate_forecast_id()
+    p = common.save_forecast(pred, "test_model", T0, T0 + datetime.timedelta(hours=6), "cds",
+                             config={"forecast_id": fid, "file_type": "netcdf", "output_dir": str(tmp_path)})
+    assert Path(p).exists() and fid in p and "test_model" in p and p.endswith(".nc")
+    assert open_dataarray(p).shape == (2, 3, 9, 96)
+    z = common.save_forecast(pred, "test_model", T0, T0, "cds", config={"forecast_id": fid + "z", "file_type": "zarr", "output_dir": str(tmp_path)})
+    z2 = common.save_forecast(pred, "test_model", T0, T0, "file", config={"forecast_id": fid + "z", "file_type": "zarr", "output_dir": str(tmp_path)})
+    assert z == z2 and (Path(z) / ".zmetadata").exists()
+    assert open_dataarray(z).shape == (4, 3, 9, 96)                   # appended along time
+    only = common.save_forecast(pred, "m", T0, T0, "cds", config={"output_dir": str(tmp_path), "filter_vars": ["t2m"]})
+    assert only.endswith(".nc") and open_dataarray(only).shape == (2, 1, 9, 96)   # default file_type stays netcdf locally
+    with pytest.raises(ValueError):
+        common.save_forecast(pred, "m", T0, T0, "cds", config={"output_dir": str(tmp_path), "file_type": "grib"})
+    with pytest.raises(NotImplementedError):
+        common.save_forecast(pred, "m", T0, T0, "cds", config={"output_dir": "s3://bucket/x"})
+    assert common.generate_filename("pangu", T0, T0 + datetime.timedelta(hours=6), "gfs") == "pangu__gfs__20240513_18:00__20240514_00:00.nc"
+
+
+def test_multi_model_ensemble_mean_over_common_channels(boring_registry):
+    ens = Skyrim("boring", "other", ic_source="cds").model
+    assert isinstance(ens, GlobalEnsemble)
+    mean, paths = ens.rollout(T0, n_steps=1, save=False)
+    assert mean.channel.values.tolist() == ["u1000", "t2m"] and mean.shape == (2, 2, 9, 96) and paths == []
+    with pytest.raises(ValueError):
+        GlobalEnsemble(["boring", "missing"])
+
+
+def test_perturb_initial_conditions():
+    da = DataArray(np.zeros((1, 2, 9, 96), np.float32), ["time", "channel", "lat", "lon"],
+                   dict(time=[T0], channel=["t2m", "msl"], lat=GEOM.lat, lon=GEOM.lon))
+    perturb_initial_conditions(da, "msl", 44.0, -7.0, 5.0)
+    assert da.values[0, 1, 2, 94] == 5.0 and da.values.sum() == 5.0
+
+
+def test_synthetic_source_is_deterministic_and_era5_sized():
+    src = SyntheticDataSource(CHANNELS, GEOM)
+    a, b = src[T0], src[T0]
+    assert a.shape == (69, 9, 96) and np.array_equal(a, b) and not np.array_equal(a, src[T0 + datetime.timedelta(hours=6)])
+    assert 2.0e5 > a[CHANNELS.index("z500")].mean() > 4.0e4 and 330 > a[CHANNELS.index("t2m")].mean() > 230

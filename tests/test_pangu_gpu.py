@@ -185,3 +185,43 @@ def test_full_size_longitude_shift_equivariance_and_fp16_mode(full):
     e3.load_params(params)
     y3 = e3.step(x.cuda())
     assert O.per_channel_rel_err(y3.cpu(), y.cpu()).max().item() < 5e-3
+
+
+# --------------------------------------------------------------------------------------------- #
+#  through the reference's own API surface (skyrim.core mirror)
+# --------------------------------------------------------------------------------------------- #
+def test_pangu_model_rollout_through_reference_api(toy, tmp_path):
+    """GlobalModel.rollout -> predict_one_step -> run_basic_inference -> TimeLoop -> skpangu_step, with the
+    per-step netCDF files of save_forecast; values against the oracle's rollout from the same IC."""
+    import datetime
+    from skyrim_amd.core.models.pangu import PanguModel
+    from skyrim_amd.labeled import open_dataarray
+    g, params, x = toy
+    t0 = datetime.datetime(2024, 5, 13, 18, 0)
+    m = PanguModel(ic_source="gfs", geom=g, params=params)
+    assert m.in_channel_names == m.out_channel_names and len(m.out_channel_names) == 69
+    pred, paths = m.rollout(t0, n_steps=2, save=True, save_config={"output_dir": str(tmp_path), "file_type": "netcdf"})
+    assert pred.dims == ("time", "channel", "lat", "lon") and pred.shape == (2, 69, g.n_lat, g.n_lon)
+    assert [p.rsplit("/", 1)[1] for p in paths] == ["pangu__gfs__20240513_18:00__20240514_00:00.nc",
+                                                     "pangu__file__20240514_00:00__20240514_06:00.nc"]
+    ic = torch.from_numpy(m.data_source[t0])
+    want = O.rollout(params, ic, 2)
+    assert O.per_channel_rel_err(torch.from_numpy(pred.values[0]), want[0]).max().item() < 1e-3
+    assert O.per_channel_rel_err(torch.from_numpy(pred.values[1]), want[1]).max().item() < 1e-3
+    back = open_dataarray(paths[0])
+    assert O.per_channel_rel_err(torch.from_numpy(back.values[1].copy()), want[0]).max().item() < 1e-3
+    fc = m.forecast(t0, n_steps=2, channels=["t2m", "z500"])
+    assert fc.shape == (3, 2, g.n_lat, g.n_lon)
+    assert np.allclose(fc.values[2, 0], pred.values[1, 68], rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.timeout(600)
+def test_skyrim_facade_default_grid():
+    """config[0] plumbing on the real grid: Skyrim('pangu').predict(6 h) -> GlobalPrediction (2, 69, 721, 1440)."""
+    from skyrim_amd.core import Skyrim
+    s = Skyrim("pangu", ic_source="gfs")
+    pred, paths = s.predict("20240513", "1800", lead_time=6, save=False)
+    assert pred.prediction.shape == (2, 69, 721, 1440) and paths == []
+    assert np.isfinite(pred.prediction.values).all()
+    assert pred.prediction.time.values[1] == np.datetime64("2024-05-14T00:00")
+    assert abs(pred.point(48.0, 11.5, "t2m", n_step=1)) < 1e4
