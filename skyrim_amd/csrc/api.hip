@@ -116,6 +116,7 @@ struct Engine : IEngine {
     size_t prep_bytes = 0, ws_bytes = 0;
     size_t bias_exp_elems[16];
     size_t q_elems = 0, ao_elems = 0, hid_elems = 0;
+    T* zrow = nullptr;
 
     // ---- per-stage timing with HIP events on the launch stream (bench.py roofline leg) ---- //
     enum Cat { C_EMBED, C_QKV0, C_ATTN0, C_PROJ0, C_FC1_0, C_FC2_0, C_QKV1, C_ATTN1, C_PROJ1, C_FC1_1, C_FC2_1, C_DOWN, C_UP, C_RECOVER, C_COUNT };
@@ -152,7 +153,7 @@ struct Engine : IEngine {
             if (e != hipSuccess) return e;
             ms[prof_cat[i]] += t; cnt[prof_cat[i]]++;
         }
-        const double sa = sizeof(S), hw = (double)g.H1 * g.W1;
+        const double sa = 2.0 * NPL, hw = (double)g.H1 * g.W1;
         double fl[C_COUNT], by[C_COUNT];
         for (int r = 0; r < 2; ++r) {
             const double C = r == 0 ? 192 : 384, mw = g.mwin[r], nt = g.ntok[r], heads = C / 32, wb = 2.0 * NW;
@@ -217,24 +218,31 @@ struct Engine : IEngine {
         w.rec_u_b = a.take<float>(5); w.rec_s_b = a.take<float>(4);
         for (int r = 0; r < 2; ++r)
             for (int roll = 0; roll < 2; ++roll) w.widx[r][roll] = a.take<int>(g.mwin[r]);
+        zrow = a.take<T>(4096);
         prep_bytes = (a.off + 255) / 256 * 256;
     }
 
     void plan_workspace(char* base) {
         Arena a{base, 0};
-        wk.X1 = a.take<float>((size_t)g.ntok[0] * 192);
-        wk.X2 = a.take<float>((size_t)g.ntok[1] * 384);
-        wk.X4 = a.take<float>((size_t)g.ntok[0] * 192);
+        const size_t n0 = (size_t)g.ntok[0] * 192, n1 = (size_t)g.ntok[1] * 384;
+        wk.X1 = a.take<float>(n0);
+        wk.X2 = a.take<float>(n1);
+        wk.X4 = a.take<float>(n0);
+        wk.xs_plane[0] = (long long)n0; wk.xs_plane[1] = (long long)n1;
+        wk.X1s = a.take<T>(n0 * NPL); wk.X2s = a.take<T>(n1 * NPL); wk.X4s = a.take<T>(n0 * NPL);
         const size_t m0 = (size_t)g.mwin[0] * 192, m1 = (size_t)g.mwin[1] * 384;
         q_elems = m0 > m1 ? m0 : m1;
         wk.qkv_plane = (long long)q_elems;
         wk.q = a.take<T>(q_elems * NPL); wk.k = a.take<T>(q_elems * NPL); wk.vt = a.take<T>(q_elems * NPL);
         ao_elems = q_elems;
-        wk.ao = a.take<S>(ao_elems);
+        wk.ao_plane = (long long)ao_elems;
+        wk.ao = a.take<T>(ao_elems * NPL);
         const size_t h0 = (size_t)g.ntok[0] * 768, h1 = (size_t)g.ntok[1] * 1536;
         hid_elems = h0 > h1 ? h0 : h1;
-        wk.hid = a.take<S>(hid_elems);
-        wk.u = a.take<S>((size_t)g.ntok[0] * 192);
+        wk.hid_plane = (long long)hid_elems;
+        wk.hid = a.take<T>(hid_elems * NPL);
+        wk.u_plane = (long long)n0;
+        wk.u = a.take<T>(n0 * NPL);
         wk.stats = a.take<float2>((size_t)g.ntok[1]);
         ws_bytes = (a.off + 255) / 256 * 256;
     }
@@ -255,19 +263,22 @@ struct Engine : IEngine {
     hipError_t copyf(const float* dst, const float* src, size_t n, hipStream_t s) {
         return hipMemcpyAsync(const_cast<float*>(dst), src, n * sizeof(float), hipMemcpyDeviceToDevice, s);
     }
-    hipError_t lin(const LinW<T>& l, const float* src, int N, int K, long long sn, long long sk, hipStream_t s) {
-        return prep_weight<T, NW>(src, const_cast<T*>(l.w), l.plane, N, K, l.ldw, sn, sk, s);
+    // blocked = 1 for weights read by the DMA GEMMs, 0 for the register-staged GEMMs (embed, DownSample)
+    hipError_t lin(const LinW<T>& l, const float* src, int N, int K, long long sn, long long sk, hipStream_t s, int blocked = 1) {
+        return prep_weight<T, NW>(src, const_cast<T*>(l.w), l.plane, N, K, l.ldw, sn, sk, blocked, s);
     }
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return e_; } while (0)
 
     hipError_t prepare(const float* m, hipStream_t s) override {
+        wk.zrow = zrow;
+        CK(hipMemsetAsync(zrow, 0, 4096 * sizeof(T), s));
         CK(copyf(w.mean, P_(m, "norm.mean"), 69, s));
         CK(copyf(w.std, P_(m, "norm.std"), 69, s));
         CK(prep_reciprocal(P_(m, "norm.std"), const_cast<float*>(w.istd), 69, s));
         CK(copyf(w.masks, P_(m, "const_masks"), (size_t)3 * g.n_lat * g.n_lon, s));
-        CK(lin(w.embed_u, P_(m, "embed.conv.weight"), 192, 160, 160, 1, s));
-        CK(lin(w.embed_s, P_(m, "embed.conv_surface.weight"), 192, 112, 112, 1, s));
+        CK(lin(w.embed_u, P_(m, "embed.conv.weight"), 192, 160, 160, 1, s, 0));
+        CK(lin(w.embed_s, P_(m, "embed.conv_surface.weight"), 192, 112, 112, 1, s, 0));
         CK(copyf(w.embed_u_b, P_(m, "embed.conv.bias"), 192, s));
         CK(copyf(w.embed_s_b, P_(m, "embed.conv_surface.bias"), 192, s));
         int b = 0;
@@ -293,7 +304,7 @@ struct Engine : IEngine {
         }
         CK(copyf(w.down_g, P_(m, "down.norm.weight"), 768, s));
         CK(copyf(w.down_b, P_(m, "down.norm.bias"), 768, s));
-        CK(lin(w.down, P_(m, "down.linear.weight"), 384, 768, 768, 1, s));
+        CK(lin(w.down, P_(m, "down.linear.weight"), 384, 768, 768, 1, s, 0));
         CK(lin(w.up1, P_(m, "up.linear1.weight"), 768, 384, 384, 1, s));
         CK(lin(w.up2, P_(m, "up.linear2.weight"), 192, 192, 192, 1, s));
         CK(copyf(w.up_g, P_(m, "up.norm.weight"), 192, s));
@@ -316,43 +327,61 @@ struct Engine : IEngine {
         return b + i;
     }
 
-    hipError_t block(int layer0, int i, float* x, hipStream_t s) override {
+    // one EarthSpecificBlock on the (fp32 master, 16-bit shadow) pair
+    hipError_t block_pair(int layer0, int i, float* x, T* xs, hipStream_t s) {
         const int res = layer_res(layer0), C = layer_dim(layer0), heads = layer_heads(layer0);
         const BlockW<T>& bw = w.blk[block_index(layer0, i)];
         const int* widx = w.widx[res][i & 1];
         const int o = res == 0 ? 0 : 5;
         mark(C_QKV0 + o, s);
-        CK((op_qkv<P>(g, bw, widx, res, x, wk, s)));
+        CK((op_qkv<P>(g, bw, widx, res, xs, wk, s)));
         mark(C_ATTN0 + o, s);
-        AttnArgs<P> a{wk.q, wk.k, wk.vt, wk.qkv_plane, bw.bias_exp, wk.ao, C, g.nwin[res], g.nW[res], heads};
+        AttnArgs<P> a{wk.q, wk.k, wk.vt, wk.qkv_plane, bw.bias_exp, wk.ao, wk.ao_plane, C, g.nwin[res], g.nW[res], heads};
         CK(launch_attention<P>(a, s));
         mark(C_PROJ0 + o, s);
-        CK((op_proj<P>(g, bw, widx, res, x, wk, s)));
+        CK((op_proj<P>(g, bw, widx, res, x, xs, wk, s)));
         mark(C_FC1_0 + o, s);
-        CK((op_fc1<P>(g, bw, res, x, wk, s)));
+        CK((op_fc1<P>(g, bw, res, xs, wk, s)));
         mark(C_FC2_0 + o, s);
-        CK((op_fc2<P>(g, bw, res, x, wk, s)));
+        CK((op_fc2<P>(g, bw, res, x, xs, wk, s)));
         mark(-1, s);
         return hipSuccess;
     }
-    hipError_t embed(const float* in, float* x1, hipStream_t s) override { return op_embed<P>(g, w, in, x1, s); }
-    hipError_t down(const float* x1, float* x2, hipStream_t s) override { return op_down<P>(g, w, x1, x2, wk, s); }
-    hipError_t up(const float* x2, float* x4, hipStream_t s) override { return op_up<P>(g, w, x2, x4, wk, s); }
-    hipError_t recover(const float* skip, const float* x4, float* out, hipStream_t s) override { return op_recover<P>(g, w, skip, x4, out, s); }
+    hipError_t to_planes(const float* x, T* xs, int res, hipStream_t s) {
+        return split_planes<T, NPL>(x, xs, wk.xs_plane[res], wk.xs_plane[res], res == 0 ? 192 : 384, s);
+    }
+    // stage-level API: the caller hands fp32 tensors; shadows are (re)built here
+    hipError_t block(int layer0, int i, float* x, hipStream_t s) override {
+        const int res = layer_res(layer0);
+        T* xs = res == 0 ? wk.X1s : wk.X2s;
+        CK(to_planes(x, xs, res, s));
+        return block_pair(layer0, i, x, xs, s);
+    }
+    hipError_t embed(const float* in, float* x1, hipStream_t s) override { return op_embed<P>(g, w, in, x1, wk.X1s, wk, s); }
+    hipError_t down(const float* x1, float* x2, hipStream_t s) override { return op_down<P>(g, w, x1, x2, wk.X2s, wk, s); }
+    hipError_t up(const float* x2, float* x4, hipStream_t s) override {
+        CK(to_planes(x2, wk.X2s, 1, s));
+        return op_up<P>(g, w, wk.X2s, x4, wk.X4s, wk, s);
+    }
+    hipError_t recover(const float* skip, const float* x4, float* out, hipStream_t s) override {
+        CK(to_planes(skip, wk.X1s, 0, s));
+        CK(to_planes(x4, wk.X4s, 0, s));
+        return op_recover<P>(g, w, wk.X1s, wk.X4s, out, wk, s);
+    }
 
     hipError_t step(const float* in, float* out, hipStream_t s) override {
         mark(C_EMBED, s);
-        CK(embed(in, wk.X1, s));
-        for (int i = 0; i < kDepths[0]; ++i) CK(block(0, i, wk.X1, s));
+        CK((op_embed<P>(g, w, in, wk.X1, wk.X1s, wk, s)));
+        for (int i = 0; i < kDepths[0]; ++i) CK(block_pair(0, i, wk.X1, wk.X1s, s));
         mark(C_DOWN, s);
-        CK(down(wk.X1, wk.X2, s));
-        for (int i = 0; i < kDepths[1]; ++i) CK(block(1, i, wk.X2, s));
-        for (int i = 0; i < kDepths[2]; ++i) CK(block(2, i, wk.X2, s));
+        CK((op_down<P>(g, w, wk.X1, wk.X2, wk.X2s, wk, s)));
+        for (int i = 0; i < kDepths[1]; ++i) CK(block_pair(1, i, wk.X2, wk.X2s, s));
+        for (int i = 0; i < kDepths[2]; ++i) CK(block_pair(2, i, wk.X2, wk.X2s, s));
         mark(C_UP, s);
-        CK(up(wk.X2, wk.X4, s));
-        for (int i = 0; i < kDepths[3]; ++i) CK(block(3, i, wk.X4, s));
+        CK((op_up<P>(g, w, wk.X2s, wk.X4, wk.X4s, wk, s)));
+        for (int i = 0; i < kDepths[3]; ++i) CK(block_pair(3, i, wk.X4, wk.X4s, s));
         mark(C_RECOVER, s);
-        CK(recover(wk.X1, wk.X4, out, s));
+        CK((op_recover<P>(g, w, wk.X1s, wk.X4s, out, wk, s)));
         mark(-1, s);
         return hipSuccess;
     }
@@ -363,9 +392,9 @@ struct Engine : IEngine {
         if (n == "q") return set(wk.q, q_elems * NPL * sizeof(T));
         if (n == "k") return set(wk.k, q_elems * NPL * sizeof(T));
         if (n == "vt") return set(wk.vt, q_elems * NPL * sizeof(T));
-        if (n == "ao") return set(wk.ao, ao_elems * sizeof(S));
-        if (n == "hid") return set(wk.hid, hid_elems * sizeof(S));
-        if (n == "u") return set(wk.u, (size_t)g.ntok[0] * 192 * sizeof(S));
+        if (n == "ao") return set(wk.ao, ao_elems * NPL * sizeof(T));
+        if (n == "hid") return set(wk.hid, hid_elems * NPL * sizeof(T));
+        if (n == "u") return set(wk.u, (size_t)g.ntok[0] * 192 * NPL * sizeof(T));
         if (n == "x1") return set(wk.X1, (size_t)g.ntok[0] * 192 * 4);
         if (n == "x2") return set(wk.X2, (size_t)g.ntok[1] * 384 * 4);
         if (n == "x4") return set(wk.X4, (size_t)g.ntok[0] * 192 * 4);

@@ -18,10 +18,10 @@
 
 namespace skp {
 
-template <class T, int NPL, class S>
+template <class T, int NPL>
 __global__ void __launch_bounds__(256) earth_attention_kernel(const T* __restrict__ q, const T* __restrict__ k,
                                                               const T* __restrict__ vt, long long plane,
-                                                              const f16* __restrict__ bias_exp, S* __restrict__ out,
+                                                              const f16* __restrict__ bias_exp, T* __restrict__ out, long long out_plane,
                                                               int ld_out, int n_win, int nW, int heads) {
     const int lane = threadIdx.x & 63;
     const long long wg = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -123,11 +123,12 @@ __global__ void __launch_bounds__(256) earth_attention_kernel(const T* __restric
                 o[df] = OpT<T>::mfma(as_v8<T>(vf[0][df][kb]), as_v8<T>(pf[0]), o[df]);
             }
         }
-        S* orow = out + ((long long)win * WIN_TOKENS + qf * 16 + l15) * ld_out + head * HEAD_DIM + g * 4;
+        // blocked [row/16][col/32][16][32] layout: this head's 32 columns are exactly one column block
+        T* orow = out + blk_off((long long)win * WIN_TOKENS + qf * 16 + l15, head * HEAD_DIM, ld_out) + g * 4;
 #pragma unroll
         for (int df = 0; df < 2; ++df) {
             const float y[4] = {o[df][0] * inv, o[df][1] * inv, o[df][2] * inv, o[df][3] * inv};
-            store4<S>(orow + df * 16, y);
+            store4_planes<T, NPL>(orow + df * 16, out_plane, y);
         }
     }
 }
@@ -138,8 +139,8 @@ hipError_t launch_attention(const AttnArgs<P>& a, hipStream_t stream) {
     constexpr int NPL = (P::NA > P::NW ? P::NA : P::NW);
     const long long waves = (long long)a.n_win * a.heads;
     const unsigned blocks = (unsigned)((waves + 3) / 4);
-    hipLaunchKernelGGL((earth_attention_kernel<T, NPL, typename ActT<P>::type>), dim3(blocks), dim3(256), 0, stream,
-                       a.q, a.k, a.vt, a.plane, a.bias_exp, a.out, a.ld_out, a.n_win, a.nW, a.heads);
+    hipLaunchKernelGGL((earth_attention_kernel<T, NPL>), dim3(blocks), dim3(256), 0, stream,
+                       a.q, a.k, a.vt, a.plane, a.bias_exp, a.out, a.out_plane, a.ld_out, a.n_win, a.nW, a.heads);
     return hipGetLastError();
 }
 

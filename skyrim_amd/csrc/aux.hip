@@ -9,24 +9,25 @@ namespace skp {
 // plain [N][K] linears (sn=K, sk=1) and the ConvTranspose weights stored [K][N] (sn=1, sk=N).
 template <class T, int NW>
 __global__ void prep_weight_kernel(const float* __restrict__ src, T* __restrict__ dst, long long plane, int N, int K, int ldd,
-                                   long long sn, long long sk) {
+                                   long long sn, long long sk, int blocked) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long long)N * ldd) return;
     const int n = (int)(i / ldd), k = (int)(i - (long long)n * ldd);
     const float v = k < K ? src[n * sn + k * sk] : 0.f;
     const T h = (T)v;
-    dst[i] = h;
-    if constexpr (NW == 2) dst[plane + i] = (T)(v - (float)h);
+    const long long o = blocked ? blk_off(n, k, ldd) : i;     // blocked: the DMA GEMMs' [N/16][K/32][16][32] layout
+    dst[o] = h;
+    if constexpr (NW == 2) dst[plane + o] = (T)(v - (float)h);
 }
 
 template <class T, int NW>
-hipError_t prep_weight(const float* src, T* dst, long long plane, int N, int K, int ldd, long long sn, long long sk, hipStream_t s) {
+hipError_t prep_weight(const float* src, T* dst, long long plane, int N, int K, int ldd, long long sn, long long sk, int blocked, hipStream_t s) {
     const long long total = (long long)N * ldd;
-    hipLaunchKernelGGL((prep_weight_kernel<T, NW>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, dst, plane, N, K, ldd, sn, sk);
+    hipLaunchKernelGGL((prep_weight_kernel<T, NW>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, dst, plane, N, K, ldd, sn, sk, blocked);
     return hipGetLastError();
 }
-template hipError_t prep_weight<bf16, 2>(const float*, bf16*, long long, int, int, int, long long, long long, hipStream_t);
-template hipError_t prep_weight<f16, 1>(const float*, f16*, long long, int, int, int, long long, long long, hipStream_t);
+template hipError_t prep_weight<bf16, 2>(const float*, bf16*, long long, int, int, int, long long, long long, int, hipStream_t);
+template hipError_t prep_weight<f16, 1>(const float*, f16*, long long, int, int, int, long long, long long, int, hipStream_t);
 
 // Earth-specific bias gathered from the compact (3312, types, heads) table into the attention
 // kernel's accumulator order [type][head][qf][kf][lane][r]:
@@ -95,6 +96,25 @@ hipError_t prep_reciprocal(const float* src, float* dst, int n, hipStream_t s) {
     hipLaunchKernelGGL(prep_reciprocal_kernel, dim3((n + 255) / 256), dim3(256), 0, s, src, dst, n);
     return hipGetLastError();
 }
+
+// fp32 -> 16-bit hi/lo planes (shadow of a residual stream handed in through the stage-level API)
+template <class T, int NPL>
+__global__ void split_planes_kernel(const float* __restrict__ x, T* __restrict__ planes, long long plane, long long n4, int C) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    const float vv[4] = {v.x, v.y, v.z, v.w};
+    const long long e = i * 4, row = e / C;
+    store4_planes<T, NPL>(planes + blk_off(row, (int)(e - row * C), C), plane, vv);
+}
+template <class T, int NPL>
+hipError_t split_planes(const float* x, T* planes, long long plane, long long n, int C, hipStream_t s) {
+    const long long n4 = n / 4;
+    hipLaunchKernelGGL((split_planes_kernel<T, NPL>), dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, x, planes, plane, n4, C);
+    return hipGetLastError();
+}
+template hipError_t split_planes<bf16, 2>(const float*, bf16*, long long, long long, int, hipStream_t);
+template hipError_t split_planes<f16, 1>(const float*, f16*, long long, long long, int, hipStream_t);
 
 // DownSample LayerNorm(4C) statistics of the 2x2-merged rows: one wavefront per merged row
 // (z, h', w'); the 4 source tokens are 4 x C contiguous floats (the one below the grid is zero padding).

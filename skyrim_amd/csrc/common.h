@@ -87,6 +87,23 @@ __device__ __forceinline__ void store4(S* p, const float (&v)[4]) {
     }
 }
 
+// Blocked operand layout of everything the DMA GEMMs read: a [R][K] matrix (R % 16 == 0, K % 32 == 0) is stored as
+// [R/16][K/32] blocks of 16 rows x 32 columns (1 KiB of 16-bit elements), so that one LDS-DMA instruction
+// (64 lanes x 16 B) reads ONE contiguous, fully used 1 KiB block -- measured 43 B/clk/CU from L2 vs 21-24 B/clk/CU
+// for the same bytes fetched as 16 rows x 64 B out of a row-major matrix (tools/micro/dma_bw.hip).
+__device__ __host__ __forceinline__ long long blk_off(long long row, int col, int K) {
+    return (((row >> 4) * (K >> 5) + (col >> 5)) << 9) + ((row & 15) << 5) + (col & 31);
+}
+
+// store 4 consecutive values as NP 16-bit planes (hi at p, lo at p + plane)
+template <class T, int NP>
+__device__ __forceinline__ void store4_planes(T* p, long long plane, const float (&v)[4]) {
+    uint2 o[NP];
+    split4<T, NP>(v, o);
+    *reinterpret_cast<uint2*>(p) = o[0];
+    if constexpr (NP == 2) *reinterpret_cast<uint2*>(p + plane) = o[1];
+}
+
 // ---- LDS tile addressing --------------------------------------------------- //
 // A [rows][BK] tile of 16-bit elements is stored as 16-byte slots; slot s of row r lives at
 // physical slot s ^ f(r) so that the 16-lane groups of ds_read_b128 (rows l&15, k-group l>>4)

@@ -10,13 +10,16 @@
 namespace skp {
 
 // ---- bias + plain fp32 store (PatchEmbedding, DownSample, UpSample.linear2) ---- //
+template <class T, int NPL>
 struct EpStoreF32 {
     static constexpr bool kDualOrder = false;
     float* out;
     const float* bias;      // nullable
     int ld, row_off;
+    T* shadow;              // 16-bit hi/lo planes of the same rows (consumed by the DMA GEMMs)
+    long long plane;
     template <class TC, bool SWAP>
-    __device__ __forceinline__ void run(f32x4 (&acc)[TC::FM][TC::FN], int m0w, int n0w, int lane, int, int, char*, int M, int N) const {
+    __device__ __forceinline__ void run(f32x4 (&acc)[TC::FM][TC::FN], int m0w, int n0w, int lane, int, int, char*, int M, int N, int) const {
         static_assert(SWAP, "swapped order only");
         const int lm = lane & 15, ln = (lane >> 4) * 4;
 #pragma unroll
@@ -34,27 +37,30 @@ struct EpStoreF32 {
                     v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
                 }
                 *reinterpret_cast<float4*>(orow + n) = v;
+                const float vv[4] = {v.x, v.y, v.z, v.w};
+                store4_planes<T, NPL>(shadow + blk_off(m + row_off, n, ld), plane, vv);
             }
         }
     }
 };
 
 // ---- bias + GELU -> activation store (MLP fc1) ------------------------------- //
-template <class S>
+template <class T, int NPL>
 struct EpGelu {
     static constexpr bool kDualOrder = false;
-    S* out;
+    T* out;                 // hi/lo planes
+    long long plane;
     const float* bias;
     int ld;
     template <class TC, bool SWAP>
-    __device__ __forceinline__ void run(f32x4 (&acc)[TC::FM][TC::FN], int m0w, int n0w, int lane, int, int, char*, int M, int N) const {
+    __device__ __forceinline__ void run(f32x4 (&acc)[TC::FM][TC::FN], int m0w, int n0w, int lane, int, int, char*, int M, int N, int) const {
         static_assert(SWAP, "swapped order only");
         const int lm = lane & 15, ln = (lane >> 4) * 4;
 #pragma unroll
         for (int a = 0; a < TC::FM; ++a) {
             const int m = m0w + a * 16 + lm;
             if (m >= M) continue;
-            S* orow = out + (long long)m * ld;
+
 #pragma unroll
             for (int b = 0; b < TC::FN; ++b) {
                 const int n = n0w + b * 16 + ln;
@@ -62,7 +68,7 @@ struct EpGelu {
                 const float4 bb = *reinterpret_cast<const float4*>(bias + n);
                 float v[4] = {gelu_erf(acc[a][b][0] + bb.x), gelu_erf(acc[a][b][1] + bb.y),
                               gelu_erf(acc[a][b][2] + bb.z), gelu_erf(acc[a][b][3] + bb.w)};
-                store4<S>(orow + n, v);
+                store4_planes<T, NPL>(out + blk_off(m, n, ld), plane, v);
             }
         }
     }
@@ -81,7 +87,7 @@ struct EpQKV {
     float scale;
     __device__ __forceinline__ bool unswapped(int n0) const { return n0 >= 2 * C; }
     template <class TC, bool SWAP>
-    __device__ __forceinline__ void run(f32x4 (&acc)[TC::FM][TC::FN], int m0w, int n0w, int lane, int, int, char*, int M, int N) const {
+    __device__ __forceinline__ void run(f32x4 (&acc)[TC::FM][TC::FN], int m0w, int n0w, int lane, int, int, char*, int M, int N, int) const {
         const int l15 = lane & 15, l4 = (lane >> 4) * 4;
         if constexpr (SWAP) {
 #pragma unroll
@@ -150,20 +156,26 @@ struct RowMapPixelShuffle {     // UpSample: (z,h,w) of the coarse grid, quadran
         return ((long long)z * H1 + hf) * W1 + wf;
     }
 };
-struct SinkResidual {           // x[dest][c..c+3] += y
+template <class T, int NPL>
+struct SinkResidual {           // x[dest][c..c+3] += y  (fp32 master) and refresh the 16-bit shadow planes
     float* x;
+    T* shadow;
+    long long plane;
     __device__ __forceinline__ void put(long long row, int ld, int c, const float (&y)[4]) const {
         float4* p = reinterpret_cast<float4*>(x + row * ld + c);
         float4 o = *p;
         o.x += y[0]; o.y += y[1]; o.z += y[2]; o.w += y[3];
         *p = o;
+        const float v[4] = {o.x, o.y, o.z, o.w};
+        store4_planes<T, NPL>(shadow + blk_off(row, c, ld), plane, v);
     }
 };
-template <class S>
-struct SinkStore {              // out[dest][c..c+3] = y
-    S* out;
+template <class T, int NPL>
+struct SinkStore {              // out[dest][c..c+3] = y as hi/lo planes
+    T* out;
+    long long plane;
     __device__ __forceinline__ void put(long long row, int ld, int c, const float (&y)[4]) const {
-        store4<S>(out + row * ld + c, y);
+        store4_planes<T, NPL>(out + blk_off(row, c, ld), plane, y);
     }
 };
 
@@ -177,11 +189,10 @@ struct EpLayerNorm {
     const float* beta;       // [BN]
     float eps;
     template <class TC, bool SWAP>
-    __device__ __forceinline__ void run(f32x4 (&acc)[TC::FM][TC::FN], int m0w, int n0w, int lane, int wm, int wn, char* smem, int M, int N) const {
+    __device__ __forceinline__ void run(f32x4 (&acc)[TC::FM][TC::FN], int m0w, int n0w, int lane, int wm, int wn, char* smem, int M, int N, int ntile) const {
         static_assert(SWAP, "swapped order only");
         constexpr int FM = TC::FM, FN = TC::FN, WN = TC::WN, BM = TC::BM, BN = TC::BN;
         const int l15 = lane & 15, l4 = (lane >> 4) * 4;
-        const int ntile = blockIdx.x;
         const int nloc0 = n0w - ntile * BN;          // column of this wave inside the LN group
         float* red = reinterpret_cast<float*>(smem);  // [2][BM][WN]
         if (bias != nullptr) {
@@ -263,7 +274,7 @@ struct EpRecover {
     const float* std;        // [69]
     int n_lat, n_lon, lat_top, H1, W1, n_levels, surface, surf0;
     template <class TC, bool SWAP>
-    __device__ __forceinline__ void run(f32x4 (&acc)[TC::FM][TC::FN], int m0w, int n0w, int lane, int, int, char*, int M, int N) const {
+    __device__ __forceinline__ void run(f32x4 (&acc)[TC::FM][TC::FN], int m0w, int n0w, int lane, int, int, char*, int M, int N, int) const {
         static_assert(SWAP, "swapped order only");
         const int l15 = lane & 15, l4 = (lane >> 4) * 4;
         const int hw = H1 * W1;

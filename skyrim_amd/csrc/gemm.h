@@ -172,7 +172,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs<P, AL, EP>& g, char* sm
         }
         __syncthreads();
     }
-    g.ep.template run<TC, SWAP>(acc, m0 + wm * TC::WTM, n0 + wn * TC::WTN, lane, wm, wn, smem, g.M, g.N);
+    g.ep.template run<TC, SWAP>(acc, m0 + wm * TC::WTM, n0 + wn * TC::WTN, lane, wm, wn, smem, g.M, g.N, (int)blockIdx.x);
 }
 
 template <class P, class TC, class AL, class EP>

@@ -43,10 +43,14 @@ template <class P>
 struct Work {
     typedef typename P::T T;
     typedef typename ActT<P>::type S;
-    float *X1, *X2, *X4;
+    float *X1, *X2, *X4;     // fp32 residual streams (masters)
+    T *X1s, *X2s, *X4s;      // their 16-bit hi/lo shadow planes (A operands of the DMA GEMMs); lo at + xs_plane[res]
+    long long xs_plane[2];
     T *q, *k, *vt;           // planes: + qkv_plane
     long long qkv_plane;
-    S *ao, *hid, *u;
+    T *ao, *hid, *u;         // hi/lo planes: + ao_plane / hid_plane / u_plane
+    long long ao_plane, hid_plane, u_plane;
+    const T* zrow;           // zeros (padding rows of the DMA GEMMs)
     float2* stats;
 };
 
@@ -55,7 +59,8 @@ struct AttnArgs {
     const typename P::T *q, *k, *vt;
     long long plane;
     const f16* bias_exp;
-    typename ActT<P>::type* out;
+    typename P::T* out;
+    long long out_plane;
     int ld_out, n_win, nW, heads;
 };
 
@@ -66,18 +71,20 @@ inline int layer_heads(int layer) { return layer_res(layer) == 0 ? 6 : 12; }
 
 template <class P> hipError_t launch_attention(const AttnArgs<P>&, hipStream_t);
 
-template <class P> hipError_t op_embed(const Geom&, const ModelW<typename P::T>&, const float* state, float* X1, hipStream_t);
-template <class P> hipError_t op_recover(const Geom&, const ModelW<typename P::T>&, const float* skip, const float* x4, float* state, hipStream_t);
-template <class P> hipError_t op_qkv(const Geom&, const BlockW<typename P::T>&, const int* widx, int res, const float* X, const Work<P>&, hipStream_t);
-template <class P> hipError_t op_proj(const Geom&, const BlockW<typename P::T>&, const int* widx, int res, float* X, const Work<P>&, hipStream_t);
-template <class P> hipError_t op_fc1(const Geom&, const BlockW<typename P::T>&, int res, const float* X, const Work<P>&, hipStream_t);
-template <class P> hipError_t op_fc2(const Geom&, const BlockW<typename P::T>&, int res, float* X, const Work<P>&, hipStream_t);
-template <class P> hipError_t op_down(const Geom&, const ModelW<typename P::T>&, const float* X1, float* X2, const Work<P>&, hipStream_t);
-template <class P> hipError_t op_up(const Geom&, const ModelW<typename P::T>&, const float* X2, float* X4, const Work<P>&, hipStream_t);
+// Every residual stream travels as a pair: fp32 master X + 16-bit shadow planes Xs (kept in sync by the epilogues).
+template <class P> hipError_t op_embed(const Geom&, const ModelW<typename P::T>&, const float* state, float* X1, typename P::T* X1s, const Work<P>&, hipStream_t);
+template <class P> hipError_t op_recover(const Geom&, const ModelW<typename P::T>&, const typename P::T* skip_s, const typename P::T* x4_s, float* state, const Work<P>&, hipStream_t);
+template <class P> hipError_t op_qkv(const Geom&, const BlockW<typename P::T>&, const int* widx, int res, const typename P::T* Xs, const Work<P>&, hipStream_t);
+template <class P> hipError_t op_proj(const Geom&, const BlockW<typename P::T>&, const int* widx, int res, float* X, typename P::T* Xs, const Work<P>&, hipStream_t);
+template <class P> hipError_t op_fc1(const Geom&, const BlockW<typename P::T>&, int res, const typename P::T* Xs, const Work<P>&, hipStream_t);
+template <class P> hipError_t op_fc2(const Geom&, const BlockW<typename P::T>&, int res, float* X, typename P::T* Xs, const Work<P>&, hipStream_t);
+template <class P> hipError_t op_down(const Geom&, const ModelW<typename P::T>&, const float* X1, float* X2, typename P::T* X2s, const Work<P>&, hipStream_t);
+template <class P> hipError_t op_up(const Geom&, const ModelW<typename P::T>&, const typename P::T* X2s, float* X4, typename P::T* X4s, const Work<P>&, hipStream_t);
+template <class T, int NPL> hipError_t split_planes(const float* x, T* planes, long long plane, long long n, int C, hipStream_t);
 
 // prepare-time helpers (aux.hip)
 template <class T, int NW>
-hipError_t prep_weight(const float* src, T* dst, long long plane, int N, int K, int ldd, long long sn, long long sk, hipStream_t);
+hipError_t prep_weight(const float* src, T* dst, long long plane, int N, int K, int ldd, long long sn, long long sk, int blocked, hipStream_t);
 hipError_t prep_bias_expand(const float* table, f16* out, int types, int heads, int nH, int roll, hipStream_t);
 hipError_t prep_window_index(int* idx, int Z, int H, int W, int Hp, int top, int roll, hipStream_t);
 hipError_t prep_reciprocal(const float* src, float* dst, int n, hipStream_t);

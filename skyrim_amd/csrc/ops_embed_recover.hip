@@ -1,25 +1,28 @@
-// PatchEmbedding (Conv3d/Conv2d with stride = kernel as im2col GEMMs) and PatchRecovery
-// (ConvTranspose3d/2d as GEMMs with a scatter + crop + de-normalise epilogue).
+// PatchEmbedding (Conv3d/Conv2d with stride = kernel as im2col GEMMs, fp32 source -> register-staged GEMM)
+// and PatchRecovery (ConvTranspose3d/2d as DMA GEMMs over concat(skip, x) with a scatter + crop +
+// de-normalise epilogue).
 #include "tiles.h"
 
 namespace skp {
 
 template <class P>
-hipError_t op_embed(const Geom& g, const ModelW<typename P::T>& w, const float* state, float* X1, hipStream_t s) {
+hipError_t op_embed(const Geom& g, const ModelW<typename P::T>& w, const float* state, float* X1, typename P::T* X1s, const Work<P>& wk, hipStream_t s) {
+    typedef typename P::T T;
     typedef typename Tiles<P>::L192 TC;
+    typedef EpStoreF32<T, P::NA> EP;
     const int hw = g.H1 * g.W1;
     {   // surface slab -> token level 0
-        GemmArgs<P, ALIm2colSurface, EpStoreF32> a;
+        GemmArgs<P, ALIm2colSurface, EP> a;
         a.al = ALIm2colSurface{state, w.masks, w.mean, w.istd, g.n_lat, g.n_lon, g.lat_top, g.H1, g.W1, g.surf0, hw};
-        a.ep = EpStoreF32{X1, w.embed_s_b, 192, 0};
+        a.ep = EP{X1, w.embed_s_b, 192, 0, X1s, wk.xs_plane[0]};
         a.W = w.embed_s.w; a.w_plane = w.embed_s.plane; a.ldw = w.embed_s.ldw;
         a.M = hw; a.N = 192; a.K = 128;
         SKP_CHECK((launch_gemm<P, TC>(a, s)));
     }
     {   // upper air -> token levels 1..7
-        GemmArgs<P, ALIm2colUpper, EpStoreF32> a;
+        GemmArgs<P, ALIm2colUpper, EP> a;
         a.al = ALIm2colUpper{state, w.mean, w.istd, g.n_lat, g.n_lon, g.lat_top, g.H1, g.W1, g.n_levels, (g.Z - 1) * hw};
-        a.ep = EpStoreF32{X1, w.embed_u_b, 192, hw};
+        a.ep = EP{X1, w.embed_u_b, 192, hw, X1s, wk.xs_plane[0]};
         a.W = w.embed_u.w; a.w_plane = w.embed_u.plane; a.ldw = w.embed_u.ldw;
         a.M = (g.Z - 1) * hw; a.N = 192; a.K = 160;
         SKP_CHECK((launch_gemm<P, TC>(a, s)));
@@ -28,30 +31,32 @@ hipError_t op_embed(const Geom& g, const ModelW<typename P::T>& w, const float* 
 }
 
 template <class P>
-hipError_t op_recover(const Geom& g, const ModelW<typename P::T>& w, const float* skip, const float* x4, float* state, hipStream_t s) {
+hipError_t op_recover(const Geom& g, const ModelW<typename P::T>& w, const typename P::T* skip_s, const typename P::T* x4_s, float* state,
+                      const Work<P>& wk, hipStream_t s) {
+    typedef typename P::T T;
     const int hw = g.H1 * g.W1;
     {
-        GemmArgs<P, ALConcat2, EpRecover> a;
-        a.al = ALConcat2{skip, x4, 192, hw, 0};
+        DmaArgs<P, AConcatPlanes<T>, EpRecover> a;
+        a.as = AConcatPlanes<T>{skip_s, x4_s, wk.xs_plane[0], 192, hw, 0};
         a.ep = EpRecover{state, w.rec_s_b, w.mean, w.std, g.n_lat, g.n_lon, g.lat_top, g.H1, g.W1, g.n_levels, 1, g.surf0};
-        a.W = w.rec_s.w; a.w_plane = w.rec_s.plane; a.ldw = w.rec_s.ldw;
+        a.W = w.rec_s.w; a.w_plane = w.rec_s.plane; a.ldw = w.rec_s.ldw; a.zrow = wk.zrow;
         a.M = hw; a.N = 64; a.K = 384;
-        SKP_CHECK((launch_gemm<P, typename Tiles<P>::N64>(a, s)));
+        SKP_CHECK((launch_gemm_dma<P, typename Tiles<P>::N64>(a, s)));
     }
     {
-        GemmArgs<P, ALConcat2, EpRecover> a;
-        a.al = ALConcat2{skip, x4, 192, (g.Z - 1) * hw, hw};
+        DmaArgs<P, AConcatPlanes<T>, EpRecover> a;
+        a.as = AConcatPlanes<T>{skip_s, x4_s, wk.xs_plane[0], 192, (g.Z - 1) * hw, hw};
         a.ep = EpRecover{state, w.rec_u_b, w.mean, w.std, g.n_lat, g.n_lon, g.lat_top, g.H1, g.W1, g.n_levels, 0, g.surf0};
-        a.W = w.rec_u.w; a.w_plane = w.rec_u.plane; a.ldw = w.rec_u.ldw;
+        a.W = w.rec_u.w; a.w_plane = w.rec_u.plane; a.ldw = w.rec_u.ldw; a.zrow = wk.zrow;
         a.M = (g.Z - 1) * hw; a.N = 160; a.K = 384;
-        SKP_CHECK((launch_gemm<P, typename Tiles<P>::L192>(a, s)));
+        SKP_CHECK((launch_gemm_dma<P, typename Tiles<P>::D192>(a, s)));
     }
     return hipSuccess;
 }
 
-template hipError_t op_embed<PrecBF16x3>(const Geom&, const ModelW<bf16>&, const float*, float*, hipStream_t);
-template hipError_t op_embed<PrecF16>(const Geom&, const ModelW<f16>&, const float*, float*, hipStream_t);
-template hipError_t op_recover<PrecBF16x3>(const Geom&, const ModelW<bf16>&, const float*, const float*, float*, hipStream_t);
-template hipError_t op_recover<PrecF16>(const Geom&, const ModelW<f16>&, const float*, const float*, float*, hipStream_t);
+template hipError_t op_embed<PrecBF16x3>(const Geom&, const ModelW<bf16>&, const float*, float*, bf16*, const Work<PrecBF16x3>&, hipStream_t);
+template hipError_t op_embed<PrecF16>(const Geom&, const ModelW<f16>&, const float*, float*, f16*, const Work<PrecF16>&, hipStream_t);
+template hipError_t op_recover<PrecBF16x3>(const Geom&, const ModelW<bf16>&, const bf16*, const bf16*, float*, const Work<PrecBF16x3>&, hipStream_t);
+template hipError_t op_recover<PrecF16>(const Geom&, const ModelW<f16>&, const f16*, const f16*, float*, const Work<PrecF16>&, hipStream_t);
 
 }  // namespace skp

@@ -1,48 +1,50 @@
-// DownSample (2x2 merge + LayerNorm(768) prologue + Linear 768->384) and UpSample
+// DownSample (2x2 merge + LayerNorm(768) prologue over the fp32 stream + Linear 768->384) and UpSample
 // (Linear 384->768 + pixel shuffle + crop + LayerNorm(192) epilogue, then Linear 192->192).
 #include "tiles.h"
 
 namespace skp {
 
 template <class P>
-hipError_t op_down(const Geom& g, const ModelW<typename P::T>& w, const float* X1, float* X2, const Work<P>& wk, hipStream_t s) {
+hipError_t op_down(const Geom& g, const ModelW<typename P::T>& w, const float* X1, float* X2, typename P::T* X2s, const Work<P>& wk, hipStream_t s) {
+    typedef typename P::T T;
+    typedef EpStoreF32<T, P::NA> EP;
     SKP_CHECK(merge_stats(X1, wk.stats, g.Z, g.H1, g.W1, g.H2, g.W2, 192, 1e-5f, s));
-    GemmArgs<P, ALMergeLN, EpStoreF32> a;
+    GemmArgs<P, ALMergeLN, EP> a;
     a.al = ALMergeLN{X1, wk.stats, w.down_g, w.down_b, g.H1, g.W1, g.H2, g.W2, 192, g.ntok[1]};
-    a.ep = EpStoreF32{X2, nullptr, 384, 0};
+    a.ep = EP{X2, nullptr, 384, 0, X2s, wk.xs_plane[1]};
     a.W = w.down.w; a.w_plane = w.down.plane; a.ldw = w.down.ldw;
     a.M = g.ntok[1]; a.N = 384; a.K = 768;
     return launch_gemm<P, typename Tiles<P>::G128>(a, s);
 }
 
 template <class P>
-hipError_t op_up(const Geom& g, const ModelW<typename P::T>& w, const float* X2, float* X4, const Work<P>& wk, hipStream_t s) {
-    typedef typename ActT<P>::type S;
-    typedef typename Tiles<P>::L192 TC;
+hipError_t op_up(const Geom& g, const ModelW<typename P::T>& w, const typename P::T* X2s, float* X4, typename P::T* X4s, const Work<P>& wk, hipStream_t s) {
+    typedef typename P::T T;
+    typedef typename Tiles<P>::D192 TC;
     {
-        typedef EpLayerNorm<RowMapPixelShuffle, SinkStore<S>> EP;
-        GemmArgs<P, ALRowsF32, EP> a;
-        a.al = ALRowsF32{X2, nullptr, 384, g.ntok[1], 384, 0};
-        a.ep = EP{RowMapPixelShuffle{g.H1, g.W1, g.H2, g.W2}, SinkStore<S>{wk.u}, nullptr, w.up_g, w.up_b, 1e-5f};
-        a.W = w.up1.w; a.w_plane = w.up1.plane; a.ldw = w.up1.ldw;
+        typedef EpLayerNorm<RowMapPixelShuffle, SinkStore<T, P::NA>> EP;
+        DmaArgs<P, APlanes<T>, EP> a;
+        a.as = APlanes<T>{X2s, wk.xs_plane[1], 384, nullptr, g.ntok[1]};
+        a.ep = EP{RowMapPixelShuffle{g.H1, g.W1, g.H2, g.W2}, SinkStore<T, P::NA>{wk.u, wk.u_plane}, nullptr, w.up_g, w.up_b, 1e-5f};
+        a.W = w.up1.w; a.w_plane = w.up1.plane; a.ldw = w.up1.ldw; a.zrow = wk.zrow;
         a.M = g.ntok[1]; a.N = 768; a.K = 384;
-        SKP_CHECK((launch_gemm<P, TC>(a, s)));
+        SKP_CHECK((launch_gemm_dma<P, TC>(a, s)));
     }
     {
-        typedef ALRowsAct<P, S> ALF;
-        GemmArgs<P, typename ALF::type, EpStoreF32> a;
-        a.al = ALF::make(wk.u, 192, g.ntok[0], 192);
-        a.ep = EpStoreF32{X4, nullptr, 192, 0};
-        a.W = w.up2.w; a.w_plane = w.up2.plane; a.ldw = w.up2.ldw;
+        typedef EpStoreF32<T, P::NA> EP;
+        DmaArgs<P, APlanes<T>, EP> a;
+        a.as = APlanes<T>{wk.u, wk.u_plane, 192, nullptr, g.ntok[0]};
+        a.ep = EP{X4, nullptr, 192, 0, X4s, wk.xs_plane[0]};
+        a.W = w.up2.w; a.w_plane = w.up2.plane; a.ldw = w.up2.ldw; a.zrow = wk.zrow;
         a.M = g.ntok[0]; a.N = 192; a.K = 192;
-        SKP_CHECK((launch_gemm<P, TC>(a, s)));
+        SKP_CHECK((launch_gemm_dma<P, TC>(a, s)));
     }
     return hipSuccess;
 }
 
-template hipError_t op_down<PrecBF16x3>(const Geom&, const ModelW<bf16>&, const float*, float*, const Work<PrecBF16x3>&, hipStream_t);
-template hipError_t op_down<PrecF16>(const Geom&, const ModelW<f16>&, const float*, float*, const Work<PrecF16>&, hipStream_t);
-template hipError_t op_up<PrecBF16x3>(const Geom&, const ModelW<bf16>&, const float*, float*, const Work<PrecBF16x3>&, hipStream_t);
-template hipError_t op_up<PrecF16>(const Geom&, const ModelW<f16>&, const float*, float*, const Work<PrecF16>&, hipStream_t);
+template hipError_t op_down<PrecBF16x3>(const Geom&, const ModelW<bf16>&, const float*, float*, bf16*, const Work<PrecBF16x3>&, hipStream_t);
+template hipError_t op_down<PrecF16>(const Geom&, const ModelW<f16>&, const float*, float*, f16*, const Work<PrecF16>&, hipStream_t);
+template hipError_t op_up<PrecBF16x3>(const Geom&, const ModelW<bf16>&, const bf16*, float*, bf16*, const Work<PrecBF16x3>&, hipStream_t);
+template hipError_t op_up<PrecF16>(const Geom&, const ModelW<f16>&, const f16*, float*, f16*, const Work<PrecF16>&, hipStream_t);
 
 }  // namespace skp

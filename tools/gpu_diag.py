@@ -37,6 +37,11 @@ def planes(buf, n, npl, dtype):
     return out
 
 
+def unblock(flat, rows, cols):
+    """[rows/16][cols/32][16][32] blocked planes -> [rows][cols]"""
+    return flat[:rows * cols].reshape(rows // 16, cols // 32, 16, 32).permute(0, 2, 1, 3).reshape(rows, cols)
+
+
 def block_reference(p, x, res, heads, roll):
     """oracle block with intermediates (q,k,v per window/head, attention output, hidden, result)"""
     Z, H, W = res
@@ -122,8 +127,8 @@ def run(prec, g, params, x):
         for name in ("q", "k", "vt"):
             got = planes(eng.debug_buffer(name, torch.uint8), nq, npl, t16)
             report(name, got, ref[name])
-        report("ao", eng.debug_buffer("ao", act)[:ref["ao"].numel()].float().reshape(ref["ao"].shape), ref["ao"])
-        report("hid", eng.debug_buffer("hid", act)[:ref["hid"].numel()].float().reshape(ref["hid"].shape), ref["hid"])
+        report("ao", unblock(planes(eng.debug_buffer("ao", torch.uint8), ref["ao"].numel(), npl, t16), *ref["ao"].shape), ref["ao"])
+        report("hid", unblock(planes(eng.debug_buffer("hid", torch.uint8), ref["hid"].numel(), npl, t16), *ref["hid"].shape), ref["hid"])
         report("block out", yb, ref["y"])
     d = eng.downsample(taps["layer1.block1"].to(dev))
     report("downsample", d, taps["down"])
