@@ -158,9 +158,9 @@ struct Engine : IEngine {
         for (int r = 0; r < 2; ++r) {
             const double C = r == 0 ? 192 : 384, mw = g.mwin[r], nt = g.ntok[r], heads = C / 32, wb = 2.0 * NW;
             const int o = r == 0 ? 0 : 5;
-            fl[C_QKV0 + o] = 2 * mw * C * 3 * C;      by[C_QKV0 + o] = nt * C * 4 + 3 * mw * C * 2 * NPL + 3 * C * C * wb;
+            fl[C_QKV0 + o] = 2 * mw * C * 3 * C;      by[C_QKV0 + o] = nt * C * sa + 3 * mw * C * 2 + 3 * C * C * wb;
             fl[C_ATTN0 + o] = g.nwin[r] * heads * 4.0 * 144 * 144 * 32;
-            by[C_ATTN0 + o] = 3 * mw * C * 2 * NPL + mw * C * sa + (double)g.types[r] * heads * 81 * 256 * 2;
+            by[C_ATTN0 + o] = 3 * mw * C * 2 + mw * C * sa + (double)g.types[r] * heads * 81 * 256 * 2;
             fl[C_PROJ0 + o] = 2 * mw * C * C;          by[C_PROJ0 + o] = mw * C * sa + 2 * nt * C * 4 + C * C * wb;
             fl[C_FC1_0 + o] = 2 * nt * C * 4 * C;      by[C_FC1_0 + o] = nt * C * 4 + nt * 4 * C * sa + 4 * C * C * wb;
             fl[C_FC2_0 + o] = 2 * nt * C * 4 * C;      by[C_FC2_0 + o] = nt * 4 * C * sa + 2 * nt * C * 4 + 4 * C * C * wb;
@@ -233,7 +233,7 @@ struct Engine : IEngine {
         const size_t m0 = (size_t)g.mwin[0] * 192, m1 = (size_t)g.mwin[1] * 384;
         q_elems = m0 > m1 ? m0 : m1;
         wk.qkv_plane = (long long)q_elems;
-        wk.q = a.take<T>(q_elems * NPL); wk.k = a.take<T>(q_elems * NPL); wk.vt = a.take<T>(q_elems * NPL);
+        wk.q = a.take<f16>(q_elems); wk.k = a.take<f16>(q_elems); wk.vt = a.take<f16>(q_elems);
         ao_elems = q_elems;
         wk.ao_plane = (long long)ao_elems;
         wk.ao = a.take<T>(ao_elems * NPL);
@@ -389,9 +389,9 @@ struct Engine : IEngine {
 
     bool debug(const std::string& n, void** p, size_t* bytes) override {
         auto set = [&](const void* ptr, size_t b) { *p = const_cast<void*>(ptr); *bytes = b; return true; };
-        if (n == "q") return set(wk.q, q_elems * NPL * sizeof(T));
-        if (n == "k") return set(wk.k, q_elems * NPL * sizeof(T));
-        if (n == "vt") return set(wk.vt, q_elems * NPL * sizeof(T));
+        if (n == "q") return set(wk.q, q_elems * sizeof(f16));
+        if (n == "k") return set(wk.k, q_elems * sizeof(f16));
+        if (n == "vt") return set(wk.vt, q_elems * sizeof(f16));
         if (n == "ao") return set(wk.ao, ao_elems * NPL * sizeof(T));
         if (n == "hid") return set(wk.hid, hid_elems * NPL * sizeof(T));
         if (n == "u") return set(wk.u, (size_t)g.ntok[0] * 192 * NPL * sizeof(T));

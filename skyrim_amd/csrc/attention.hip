@@ -18,11 +18,17 @@
 
 namespace skp {
 
-template <class T, int NPL>
-__global__ void __launch_bounds__(256) earth_attention_kernel(const T* __restrict__ q, const T* __restrict__ k,
-                                                              const T* __restrict__ vt, long long plane,
-                                                              const f16* __restrict__ bias_exp, T* __restrict__ out, long long out_plane,
+// Q, K, V and the softmax output P are single fp16 planes in EVERY precision mode: attention is the least
+// rounding-sensitive part of the network (measured on the oracle: fp16 q/k/v -> 7e-5, fp16 P -> 4e-5 per-channel
+// error, vs 3.3e-4 / 3.6e-4 for the attention output / MLP hidden, which therefore stay hi/lo split), so
+// QK^T and PV are one MFMA term each and the Q/K/V round trip through HBM is 2 bytes per element.
+template <class TO, int NPL_O>
+__global__ void __launch_bounds__(256) earth_attention_kernel(const f16* __restrict__ q, const f16* __restrict__ k,
+                                                              const f16* __restrict__ vt, long long plane,
+                                                              const f16* __restrict__ bias_exp, TO* __restrict__ out, long long out_plane,
                                                               int ld_out, int n_win, int nW, int heads) {
+    typedef f16 T;
+    constexpr int NPL = 1;
     const int lane = threadIdx.x & 63;
     const long long wg = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (wg >= (long long)n_win * heads) return;
@@ -124,22 +130,21 @@ __global__ void __launch_bounds__(256) earth_attention_kernel(const T* __restric
             }
         }
         // blocked [row/16][col/32][16][32] layout: this head's 32 columns are exactly one column block
-        T* orow = out + blk_off((long long)win * WIN_TOKENS + qf * 16 + l15, head * HEAD_DIM, ld_out) + g * 4;
+        TO* orow = out + blk_off((long long)win * WIN_TOKENS + qf * 16 + l15, head * HEAD_DIM, ld_out) + g * 4;
 #pragma unroll
         for (int df = 0; df < 2; ++df) {
             const float y[4] = {o[df][0] * inv, o[df][1] * inv, o[df][2] * inv, o[df][3] * inv};
-            store4_planes<T, NPL>(orow + df * 16, out_plane, y);
+            store4_planes<TO, NPL_O>(orow + df * 16, out_plane, y);
         }
     }
 }
 
 template <class P>
 hipError_t launch_attention(const AttnArgs<P>& a, hipStream_t stream) {
-    typedef typename P::T T;
-    constexpr int NPL = (P::NA > P::NW ? P::NA : P::NW);
+    constexpr int NPL_O = (P::NA > P::NW ? P::NA : P::NW);
     const long long waves = (long long)a.n_win * a.heads;
     const unsigned blocks = (unsigned)((waves + 3) / 4);
-    hipLaunchKernelGGL((earth_attention_kernel<T, NPL>), dim3(blocks), dim3(256), 0, stream,
+    hipLaunchKernelGGL((earth_attention_kernel<typename P::T, NPL_O>), dim3(blocks), dim3(256), 0, stream,
                        a.q, a.k, a.vt, a.plane, a.bias_exp, a.out, a.out_plane, a.ld_out, a.n_win, a.nW, a.heads);
     return hipGetLastError();
 }

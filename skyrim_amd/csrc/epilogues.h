@@ -161,12 +161,11 @@ struct SinkResidual {           // x[dest][c..c+3] += y  (fp32 master) and refre
     float* x;
     T* shadow;
     long long plane;
-    __device__ __forceinline__ void put(long long row, int ld, int c, const float (&y)[4]) const {
-        float4* p = reinterpret_cast<float4*>(x + row * ld + c);
-        float4 o = *p;
-        o.x += y[0]; o.y += y[1]; o.z += y[2]; o.w += y[3];
-        *p = o;
-        const float v[4] = {o.x, o.y, o.z, o.w};
+    static constexpr bool kLoads = true;
+    __device__ __forceinline__ float4 load(long long row, int ld, int c) const { return *reinterpret_cast<const float4*>(x + row * ld + c); }
+    __device__ __forceinline__ void put(long long row, int ld, int c, const float (&y)[4], const float4& old) const {
+        const float v[4] = {old.x + y[0], old.y + y[1], old.z + y[2], old.w + y[3]};
+        *reinterpret_cast<float4*>(x + row * ld + c) = make_float4(v[0], v[1], v[2], v[3]);
         store4_planes<T, NPL>(shadow + blk_off(row, c, ld), plane, v);
     }
 };
@@ -174,7 +173,9 @@ template <class T, int NPL>
 struct SinkStore {              // out[dest][c..c+3] = y as hi/lo planes
     T* out;
     long long plane;
-    __device__ __forceinline__ void put(long long row, int ld, int c, const float (&y)[4]) const {
+    static constexpr bool kLoads = false;
+    __device__ __forceinline__ float4 load(long long, int, int) const { return make_float4(0.f, 0.f, 0.f, 0.f); }
+    __device__ __forceinline__ void put(long long row, int ld, int c, const float (&y)[4], const float4&) const {
         store4_planes<T, NPL>(out + blk_off(row, c, ld), plane, y);
     }
 };
@@ -202,6 +203,25 @@ struct EpLayerNorm {
 #pragma unroll
                 for (int a = 0; a < FM; ++a) { acc[a][b][0] += bb.x; acc[a][b][1] += bb.y; acc[a][b][2] += bb.z; acc[a][b][3] += bb.w; }
             }
+        }
+        // destination rows first (the table lookups overlap the LayerNorm reductions below); rows that do not exist
+        // (window padding / crop / M tail) are redirected to row 0 for the loads and skipped for the stores
+        long long drow[FM];
+        bool ok[FM];
+#pragma unroll
+        for (int a = 0; a < FM; ++a) {
+            const int m = m0w + a * 16 + l15;
+            const long long r = m < M ? map.dest(m, ntile) : -1;
+            ok[a] = r >= 0;
+            drow[a] = ok[a] ? r : 0;
+        }
+        // all residual loads in flight at once (one HBM round trip instead of FM*FN dependent ones)
+        float4 old[Sink::kLoads ? FM : 1][Sink::kLoads ? FN : 1];
+        if constexpr (Sink::kLoads) {
+#pragma unroll
+            for (int a = 0; a < FM; ++a)
+#pragma unroll
+                for (int b = 0; b < FN; ++b) old[a][b] = sink.load(drow[a], BN, nloc0 + b * 16 + l4);
         }
         float mean[FM], rstd[FM];
         // pass 1: mean
@@ -245,19 +265,15 @@ struct EpLayerNorm {
             rstd[a] = rsqrtf(s * (1.0f / BN) + eps);
         }
 #pragma unroll
-        for (int a = 0; a < FM; ++a) {
-            const int m = m0w + a * 16 + l15;
-            if (m >= M) continue;
-            const long long row = map.dest(m, ntile);
-            if (row < 0) continue;
+        for (int b = 0; b < FN; ++b) {
+            const int c = nloc0 + b * 16 + l4;
+            const float4 g = *reinterpret_cast<const float4*>(gamma + c);
+            const float4 be = *reinterpret_cast<const float4*>(beta + c);
 #pragma unroll
-            for (int b = 0; b < FN; ++b) {
-                const int c = nloc0 + b * 16 + l4;
-                const float4 g = *reinterpret_cast<const float4*>(gamma + c);
-                const float4 be = *reinterpret_cast<const float4*>(beta + c);
+            for (int a = 0; a < FM; ++a) {
                 const float y[4] = {(acc[a][b][0] - mean[a]) * rstd[a] * g.x + be.x, (acc[a][b][1] - mean[a]) * rstd[a] * g.y + be.y,
                                     (acc[a][b][2] - mean[a]) * rstd[a] * g.z + be.z, (acc[a][b][3] - mean[a]) * rstd[a] * g.w + be.w};
-                sink.put(row, BN, c, y);
+                if (ok[a]) sink.put(drow[a], BN, c, y, Sink::kLoads ? old[a][b] : old[0][0]);
             }
         }
     }

@@ -46,7 +46,7 @@ struct Work {
     float *X1, *X2, *X4;     // fp32 residual streams (masters)
     T *X1s, *X2s, *X4s;      // their 16-bit hi/lo shadow planes (A operands of the DMA GEMMs); lo at + xs_plane[res]
     long long xs_plane[2];
-    T *q, *k, *vt;           // planes: + qkv_plane
+    f16 *q, *k, *vt;         // single fp16 planes in every mode (attention.hip)
     long long qkv_plane;
     T *ao, *hid, *u;         // hi/lo planes: + ao_plane / hid_plane / u_plane
     long long ao_plane, hid_plane, u_plane;
@@ -56,7 +56,7 @@ struct Work {
 
 template <class P>
 struct AttnArgs {
-    const typename P::T *q, *k, *vt;
+    const f16 *q, *k, *vt;
     long long plane;
     const f16* bias_exp;
     typename P::T* out;

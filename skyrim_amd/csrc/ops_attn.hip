@@ -8,11 +8,10 @@ namespace skp {
 template <class P>
 hipError_t op_qkv(const Geom& g, const BlockW<typename P::T>& b, const int* widx, int res, const typename P::T* Xs, const Work<P>& wk, hipStream_t s) {
     typedef typename P::T T;
-    constexpr int NPL = planes_of<P>();
     const int C = res == 0 ? 192 : 384, heads = C / HEAD_DIM;
-    DmaArgs<P, APlanes<T>, EpQKV<T, NPL>> a;
+    DmaArgs<P, APlanes<T>, EpQKV<f16, 1>> a;
     a.as = APlanes<T>{Xs, wk.xs_plane[res], C, widx, g.mwin[res]};
-    a.ep = EpQKV<T, NPL>{wk.q, wk.k, wk.vt, wk.qkv_plane, b.qkv_b, C, heads, 0.17677669529663687f};
+    a.ep = EpQKV<f16, 1>{wk.q, wk.k, wk.vt, wk.qkv_plane, b.qkv_b, C, heads, 0.17677669529663687f};
     a.W = b.qkv.w; a.w_plane = b.qkv.plane; a.ldw = b.qkv.ldw; a.zrow = wk.zrow;
     a.M = g.mwin[res]; a.N = 3 * C; a.K = C;
     return launch_gemm_dma<P, typename Tiles<P>::D192>(a, s);

@@ -125,7 +125,7 @@ def run(prec, g, params, x):
         ki = (torch.arange(9)[None, :, None, None] * 16 + (4 * (lane >> 4))[None, None, :, None] + torch.arange(4)[None, None, None, :]).expand(9, 9, 64, 4)
         report("bias_exp", be, full[:, :, qi, ki])
         for name in ("q", "k", "vt"):
-            got = planes(eng.debug_buffer(name, torch.uint8), nq, npl, t16)
+            got = planes(eng.debug_buffer(name, torch.uint8), nq, 1, torch.float16)
             report(name, got, ref[name])
         report("ao", unblock(planes(eng.debug_buffer("ao", torch.uint8), ref["ao"].numel(), npl, t16), *ref["ao"].shape), ref["ao"])
         report("hid", unblock(planes(eng.debug_buffer("hid", torch.uint8), ref["hid"].numel(), npl, t16), *ref["hid"].shape), ref["hid"])
