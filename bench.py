@@ -76,7 +76,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "f16"])
+    ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "f16", "bf16x3h"])
     ap.add_argument("--n-lat", type=int, default=721)
     ap.add_argument("--n-lon", type=int, default=1440)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -149,13 +149,14 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "bf16" if args.precision == "bf16x3" else "f16",
+            "dtype": "f16" if args.precision == "f16" else "bf16",
             "data": "synthetic",
             "config": {
                 "workload": f"Pangu 6-h autoregressive rollout, {args.n_lat}x{args.n_lon}x69 state "
                             "(13 levels x 5 vars + 4 surface), random-init weights (64 M params), "
                             "state resident in HBM, 1 ensemble member per GPU",
                 "precision": {"bf16x3": "bf16 MFMA, hi/lo operand split (3 terms), fp32 accumulate, fp32 residual stream",
+                              "bf16x3h": "bf16 MFMA hi/lo split (3 terms) with the MLP hidden stored as one fp16 plane (fc2: 2 fp16 terms); attention single-term fp16",
                               "f16": "fp16 MFMA single term, fp32 accumulate, fp32 residual stream"}[args.precision],
                 "parallelism": f"member-parallel x{world}" if world > 1 else "single GPU",
                 "finite": finite,

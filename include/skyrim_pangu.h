@@ -32,6 +32,7 @@ extern "C" {
 /* precision modes: how each matrix product is formed on the MFMA pipe */
 #define SKPANGU_PREC_BF16X3 0 /* bf16 hi/lo split, 3 MFMA terms, fp32-class results (default; meets the 1e-3 bar) */
 #define SKPANGU_PREC_F16    1 /* single fp16 term (fast; ~1e-3 relative error per step) */
+#define SKPANGU_PREC_BF16X3_H16 2 /* bf16x3, but the MLP hidden activation is stored as one fp16 plane (~4e-4) */
 
 #define SKPANGU_E_ARG        (-1) /* bad argument / unsupported geometry */
 #define SKPANGU_E_SIZE       (-2) /* a caller buffer is too small */

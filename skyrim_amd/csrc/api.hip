@@ -116,6 +116,7 @@ struct Engine : IEngine {
     size_t prep_bytes = 0, ws_bytes = 0;
     size_t bias_exp_elems[16];
     size_t q_elems = 0, ao_elems = 0, hid_elems = 0;
+    int hid16 = 0;            // fp16-hidden mode (bf16x3 engines only)
     T* zrow = nullptr;
 
     // ---- per-stage timing with HIP events on the launch stream (bench.py roofline leg) ---- //
@@ -202,6 +203,8 @@ struct Engine : IEngine {
                 BlockW<T>& bw = w.blk[b];
                 bw.qkv = take_lin(a, 3 * c, c); bw.proj = take_lin(a, c, c);
                 bw.fc1 = take_lin(a, 4 * c, c); bw.fc2 = take_lin(a, c, 4 * c);
+                bw.fc2h = LinW<f16>{nullptr, 0, 4 * c};
+                if (hid16) { bw.fc2h.plane = (long long)c * 4 * c; bw.fc2h.w = a.take<f16>((size_t)bw.fc2h.plane * 2); }
                 bw.qkv_b = a.take<float>(3 * c); bw.proj_b = a.take<float>(c);
                 bw.fc1_b = a.take<float>(4 * c); bw.fc2_b = a.take<float>(c);
                 bw.n1_g = a.take<float>(c); bw.n1_b = a.take<float>(c);
@@ -247,7 +250,8 @@ struct Engine : IEngine {
         ws_bytes = (a.off + 255) / 256 * 256;
     }
 
-    explicit Engine(const Geom& geom) : g(geom) {
+    explicit Engine(const Geom& geom, int hid16_ = 0) : g(geom), hid16(hid16_) {
+        wk.hid16 = hid16_;
         params = build_params(g, nullptr);
         plan_prepared(nullptr);
         plan_workspace(nullptr);
@@ -291,6 +295,7 @@ struct Engine : IEngine {
                 CK(lin(bw.proj, P_(m, p + "attn.proj.weight"), c, c, c, 1, s));
                 CK(lin(bw.fc1, P_(m, p + "mlp.fc1.weight"), 4 * c, c, c, 1, s));
                 CK(lin(bw.fc2, P_(m, p + "mlp.fc2.weight"), c, 4 * c, 4 * c, 1, s));
+                if (hid16) CK((prep_weight<f16, 2>(P_(m, p + "mlp.fc2.weight"), const_cast<f16*>(bw.fc2h.w), bw.fc2h.plane, c, 4 * c, 4 * c, 4 * c, 1, 1, s)));
                 CK(copyf(bw.qkv_b, P_(m, p + "attn.qkv.bias"), 3 * c, s));
                 CK(copyf(bw.proj_b, P_(m, p + "attn.proj.bias"), c, s));
                 CK(copyf(bw.fc1_b, P_(m, p + "mlp.fc1.bias"), 4 * c, s));
@@ -416,6 +421,7 @@ IEngine* make_engine(const skpangu_config& cfg, const Geom& g) {
     switch (cfg.precision) {
         case SKPANGU_PREC_BF16X3: return new Engine<PrecBF16x3>(g);
         case SKPANGU_PREC_F16: return new Engine<PrecF16>(g);
+        case SKPANGU_PREC_BF16X3_H16: return new Engine<PrecBF16x3>(g, 1);
         default: return nullptr;
     }
 }
@@ -483,7 +489,7 @@ int skpangu_create(const skpangu_config* cfg, void* prepared_dev, size_t prepare
     if (!e) return SKPANGU_E_ARG;
     if (prepared_bytes < e->prepared_bytes() || workspace_bytes < e->workspace_bytes()) { delete e; return SKPANGU_E_SIZE; }
     if (((uintptr_t)prepared_dev & 255) || ((uintptr_t)workspace_dev & 255)) { delete e; return SKPANGU_E_ARG; }
-    if (cfg->precision == SKPANGU_PREC_BF16X3) {
+    if (cfg->precision == SKPANGU_PREC_BF16X3 || cfg->precision == SKPANGU_PREC_BF16X3_H16) {
         auto* t = static_cast<Engine<PrecBF16x3>*>(e);
         t->plan_prepared((char*)prepared_dev); t->plan_workspace((char*)workspace_dev);
     } else {

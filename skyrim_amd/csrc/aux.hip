@@ -28,6 +28,7 @@ hipError_t prep_weight(const float* src, T* dst, long long plane, int N, int K, 
 }
 template hipError_t prep_weight<bf16, 2>(const float*, bf16*, long long, int, int, int, long long, long long, int, hipStream_t);
 template hipError_t prep_weight<f16, 1>(const float*, f16*, long long, int, int, int, long long, long long, int, hipStream_t);
+template hipError_t prep_weight<f16, 2>(const float*, f16*, long long, int, int, int, long long, long long, int, hipStream_t);
 
 // Earth-specific bias gathered from the compact (3312, types, heads) table into the attention
 // kernel's accumulator order [type][head][qf][kf][lane][r]:

@@ -39,6 +39,8 @@ __device__ __forceinline__ typename OpT<T>::v8 as_v8(const uint4& u) {
 // bf16x3 carries 16 significand bits per operand: fp32-class results on the bf16 MFMA pipe.
 struct PrecBF16x3 { typedef bf16 T; static constexpr int NA = 2, NW = 2; };
 struct PrecF16    { typedef f16 T;  static constexpr int NA = 1, NW = 1; };
+// fc2 of the "fp16 hidden" mode: A = single fp16 plane (the GELU output), W = fp16 hi/lo planes, 2 MFMA terms
+struct PrecF16x2W { typedef f16 T;  static constexpr int NA = 1, NW = 2; };
 
 // storage type of inter-kernel activations: fp32 when the consumer splits hi/lo, else T
 template <class P> struct ActT { typedef typename P::T type; };
@@ -118,12 +120,12 @@ __device__ __forceinline__ int lds_off(int row, int slot) {
 // instructions instead of libm erff's branchy ~50: the fc1 epilogue evaluates 2e8 of these per launch.
 __device__ __forceinline__ float gelu_erf(float x) {
     const float ax = fabsf(x) * 0.70710678118654752440f;
-    const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));   // v_rcp_f32 (1 ulp), not the IEEE division sequence
     float p = fmaf(t, 1.061405429f, -1.453152027f);
     p = fmaf(t, p, 1.421413741f);
     p = fmaf(t, p, -0.284496736f);
     p = fmaf(t, p, 0.254829592f);
-    const float e = __expf(-ax * ax);
+    const float e = __builtin_amdgcn_exp2f(ax * ax * -1.4426950408889634f);
     const float erf_abs = fmaf(-p * t, e, 1.0f);
     return 0.5f * x * (1.0f + copysignf(erf_abs, x));
 }

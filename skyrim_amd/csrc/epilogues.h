@@ -66,8 +66,15 @@ struct EpGelu {
                 const int n = n0w + b * 16 + ln;
                 if (n >= N) continue;
                 const float4 bb = *reinterpret_cast<const float4*>(bias + n);
+#ifdef SKP_DEBUG_NOGELU
+                float v[4] = {acc[a][b][0] + bb.x, acc[a][b][1] + bb.y, acc[a][b][2] + bb.z, acc[a][b][3] + bb.w};
+#else
                 float v[4] = {gelu_erf(acc[a][b][0] + bb.x), gelu_erf(acc[a][b][1] + bb.y),
                               gelu_erf(acc[a][b][2] + bb.z), gelu_erf(acc[a][b][3] + bb.w)};
+#endif
+#ifdef SKP_DEBUG_NOSTORE
+                if (v[0] == 123.456f)
+#endif
                 store4_planes<T, NPL>(out + blk_off(m, n, ld), plane, v);
             }
         }

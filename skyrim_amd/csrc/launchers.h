@@ -20,6 +20,7 @@ struct LinW { const T* w; long long plane; int ldw; };   // [N][ldw] hi plane (+
 template <class T>
 struct BlockW {
     LinW<T> qkv, proj, fc1, fc2;
+    LinW<f16> fc2h;          // fc2 weight as fp16 hi/lo planes (only in the fp16-hidden mode)
     const float *qkv_b, *proj_b, *fc1_b, *fc2_b, *n1_g, *n1_b, *n2_g, *n2_b;
     const f16* bias_exp;     // [types][heads][9][9][64][4] (+ shifted-window mask on odd blocks)
 };
@@ -51,6 +52,7 @@ struct Work {
     T *ao, *hid, *u;         // hi/lo planes: + ao_plane / hid_plane / u_plane
     long long ao_plane, hid_plane, u_plane;
     const T* zrow;           // zeros (padding rows of the DMA GEMMs)
+    int hid16;               // 1: MLP hidden stored as ONE fp16 plane (hid reinterpreted as f16*), fc2 runs 2-term fp16
     float2* stats;
 };
 

@@ -16,7 +16,8 @@ from .spec import PanguGeometry
 
 PREC_BF16X3 = 0
 PREC_F16 = 1
-PRECISIONS = {"bf16x3": PREC_BF16X3, "f16": PREC_F16}
+PREC_BF16X3_H16 = 2
+PRECISIONS = {"bf16x3": PREC_BF16X3, "f16": PREC_F16, "bf16x3h": PREC_BF16X3_H16}
 
 _LIB_PATH = Path(__file__).resolve().parent.parent / "lib" / "libskyrim_pangu.so"
 

@@ -87,8 +87,9 @@ def run(prec, g, params, x):
     eng = PanguEngine(g, prec)
     eng.load_params(params)
     dev = eng.device
-    npl = 2 if prec == "bf16x3" else 1
-    t16 = torch.bfloat16 if prec == "bf16x3" else torch.float16
+    npl = 2 if prec.startswith("bf16x3") else 1
+    t16 = torch.bfloat16 if prec.startswith("bf16x3") else torch.float16
+    hnpl, ht16 = (npl, t16) if prec == "bf16x3" else (1, torch.float16)
     act = torch.float32 if prec == "bf16x3" else torch.float16
 
     xd = x.to(dev)
@@ -128,7 +129,7 @@ def run(prec, g, params, x):
             got = planes(eng.debug_buffer(name, torch.uint8), nq, 1, torch.float16)
             report(name, got, ref[name])
         report("ao", unblock(planes(eng.debug_buffer("ao", torch.uint8), ref["ao"].numel(), npl, t16), *ref["ao"].shape), ref["ao"])
-        report("hid", unblock(planes(eng.debug_buffer("hid", torch.uint8), ref["hid"].numel(), npl, t16), *ref["hid"].shape), ref["hid"])
+        report("hid", unblock(planes(eng.debug_buffer("hid", torch.uint8)[:ref["hid"].numel() * 2 * hnpl] if hnpl == 1 else eng.debug_buffer("hid", torch.uint8), ref["hid"].numel(), hnpl, ht16), *ref["hid"].shape), ref["hid"])
         report("block out", yb, ref["y"])
     d = eng.downsample(taps["layer1.block1"].to(dev))
     report("downsample", d, taps["down"])
@@ -165,7 +166,7 @@ if __name__ == "__main__":
     g = PanguGeometry(nlat, nlon)
     params = init_synthetic(g, 0)
     x = synthetic_state(g, 0)
-    for prec in (sys.argv[3:] or ["bf16x3", "f16"]):
+    for prec in (sys.argv[3:] or ["bf16x3", "bf16x3h", "f16"]):
         try:
             run(prec, g, params, x)
         except Exception:
