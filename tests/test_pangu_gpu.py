@@ -1,8 +1,10 @@
 """GPU parity tests: the HIP engine, called through the C ABI, against the CPU oracle.
 
-Tolerances (floating point; stated per the north star): per-channel max|y - ref| / max|ref| <= 1e-3
-for the default bf16x3 mode on a full step (observed ~2e-5); the single-term fp16 mode is a speed
-mode and is held to 5e-3 (observed ~1.2e-3).  Stage-level tests use max-abs / max-abs-ref.
+Tolerances (floating point; stated per the north star): per-channel max|y - ref| / max|ref| <= 1e-3.
+Modes: "bf16x3" (default: bf16 hi/lo split GEMMs, fp16 single-term attention; observed ~8e-5 -> asserted
+<= 3e-4), "bf16x3h" (additionally the MLP hidden as one fp16 plane; observed ~4.5e-4 -> asserted <= 1e-3),
+"f16" (single-term speed mode, observed ~1.2e-3, does NOT meet the bar -> held to 5e-3).
+Stage-level tests use max-abs / max-abs-ref.
 """
 import numpy as np
 import pytest
@@ -13,8 +15,8 @@ from skyrim_amd.pangu.spec import PanguGeometry, init_synthetic, synthetic_state
 
 pytestmark = pytest.mark.gpu
 
-STAGE_TOL = {"bf16x3": 1e-4, "f16": 4e-3}
-STEP_TOL = {"bf16x3": 1e-4, "f16": 5e-3}       # bf16x3 is asserted 10x inside the 1e-3 bar
+STAGE_TOL = {"bf16x3": 5e-4, "bf16x3h": 2e-3, "f16": 4e-3}
+STEP_TOL = {"bf16x3": 3e-4, "bf16x3h": 1e-3, "f16": 5e-3}       # bf16x3 is asserted 3x inside the 1e-3 bar
 
 
 def rel(a, b):
@@ -30,7 +32,7 @@ def ref(toy):
     return taps, y
 
 
-@pytest.fixture(scope="module", params=["bf16x3", "f16"])
+@pytest.fixture(scope="module", params=["bf16x3", "bf16x3h", "f16"])
 def eng(request, toy):
     from skyrim_amd.pangu.engine import PanguEngine
     g, params, x = toy
@@ -98,7 +100,7 @@ def test_rollout_4_steps_in_place(eng, toy):
         eng.step(xs, xs)
         xr = O.forward(params, xr)
     e = O.per_channel_rel_err(xs.cpu(), xr)
-    assert e.max().item() < 2 * STEP_TOL[eng.precision]
+    assert e.max().item() < (1e-3 if eng.precision != "f16" else 1e-2)
 
 
 def test_deterministic(eng, toy):
@@ -165,7 +167,7 @@ def test_full_size_step_vs_oracle(full):
     err = O.per_channel_rel_err(y.cpu(), want)
     assert torch.isfinite(y).all()
     assert err.max().item() < 1e-3, err
-    assert err.max().item() < 1e-4, err          # what bf16x3 actually delivers
+    assert err.max().item() < 3e-4, err          # what bf16x3 actually delivers (~1e-4)
 
 
 @pytest.mark.timeout(900)
@@ -179,7 +181,7 @@ def test_full_size_longitude_shift_equivariance_and_fp16_mode(full):
     e2 = PanguEngine(g, "bf16x3", "cuda:0")
     e2.load_params(p2)
     y2 = e2.step(torch.roll(x, 480, dims=-1).cuda())
-    assert O.per_channel_rel_err(torch.roll(y2, -480, dims=-1).cpu(), y.cpu()).max().item() < 2e-4
+    assert O.per_channel_rel_err(torch.roll(y2, -480, dims=-1).cpu(), y.cpu()).max().item() < 5e-4
     del e2
     e3 = PanguEngine(g, "f16", "cuda:0")
     e3.load_params(params)
