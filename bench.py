@@ -71,6 +71,36 @@ def toy_parity(precision):
     return {"grid": "49x192", "max_rel_err": O.per_channel_rel_err(y, O.forward(p, x)).max().item(), "bar": 1e-3}
 
 
+def pmc_traffic(kernel: str):
+    """HBM bytes per launch of ``kernel`` from the committed rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE collected in
+    separate runs, FETCH doubled per MI355X_MICROARCH.md 'HBM'); profiles/r01_pmc_traffic.json is produced by
+    tools/pmc_traffic.py.  None when no PMC summary exists for this kernel."""
+    f = ROOT / "profiles" / "r01_pmc_traffic.json"
+    if not f.exists():
+        return None
+    try:
+        return json.loads(f.read_text()).get(kernel, {}).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
+def quick_mode(precision, geom, params, x_host, dev, steps=3):
+    """Short run of another precision mode (same workload) for the 'modes' table."""
+    from skyrim_amd.pangu.engine import PanguEngine
+    eng = PanguEngine(geom, precision, dev)
+    eng.load_params(params)
+    x = x_host.to(dev)
+    eng.step(x, x)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        eng.step(x, x)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    del eng
+    return {"ms_per_step": 1e3 * dt, "steps_per_s": 1.0 / dt}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -81,6 +111,7 @@ def main():
     ap.add_argument("--n-lon", type=int, default=1440)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--no-alt-modes", action="store_true", help="skip the short runs of the other precision modes")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -163,7 +194,7 @@ def main():
             },
             "roofline": {
                 "bound": "mfma", "kernel": dom["name"], "achieved": achieved / 1e12, "peak": PEAK_MFMA_BF16 / 1e12,
-                "unit": "TFLOP/s", "frac": achieved / PEAK_MFMA_BF16, "traffic": None,
+                "unit": "TFLOP/s", "frac": achieved / PEAK_MFMA_BF16, "traffic": pmc_traffic(dom["name"]),
                 "avg_launch_ms": dom_ms, "alg_flops_per_launch": dom["flops"],
                 "step": {"alg_tflop": F_ALG_STEP / 1e12, "gpu_ms": gpu_ms,
                          "mfma_frac": F_ALG_STEP / (gpu_ms * 1e-3) / PEAK_MFMA_BF16,
@@ -179,6 +210,13 @@ def main():
             out["cpu_baseline"] = cpu_baseline(params, geom, x_host)
         if world == 1 and not args.no_parity:
             out["parity"] = toy_parity(args.precision)
+        if world == 1 and not args.no_alt_modes:
+            del eng
+            torch.cuda.empty_cache()
+            notes = {"bf16x3": "default; meets the 1e-3 bar (~8e-5)", "bf16x3h": "fp16 MLP hidden; meets the bar (~4.5e-4)",
+                     "f16": "single-term fp16; does NOT meet the bar (~1.2e-3)"}
+            out["modes"] = {m: dict(quick_mode(m, geom, params, x_host, dev), note=notes[m])
+                            for m in ("bf16x3", "bf16x3h", "f16") if m != args.precision}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
