@@ -112,6 +112,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-alt-modes", action="store_true", help="skip the short runs of the other precision modes")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo only to "
+                    "exercise the multi-rank control flow on a box with fewer GPUs than ranks)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -120,10 +122,19 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run")
     import torch.distributed as dist
+    n_dev = torch.cuda.device_count()
+    if n_dev == 0:
+        raise SystemExit("bench.py needs an MI355X: the Pangu hot path has no CPU fallback")
+    if world > n_dev and args.backend == "nccl":
+        raise SystemExit(f"{world} ranks but {n_dev} GPUs visible (RCCL needs one GPU per rank)")
+    local_rank %= n_dev
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
 
     from skyrim_amd.pangu.engine import PanguEngine
     from skyrim_amd.pangu.ensemble import ensemble_mean_spread
