@@ -54,3 +54,51 @@ def rollout_members(step_fn, initial_states: list[torch.Tensor], n_steps: int) -
             x = step_fn(x)
         out.append(x)
     return out
+
+
+def perturbed_member(x0: torch.Tensor, std: torch.Tensor, member: int, scale: float = 1e-3) -> torch.Tensor:
+    """Member ``i`` of a perturbed-initial-condition ensemble: x0 + scale * std_c * N(0,1; seed 1000+i)
+    (SURVEY.md 8(d), config 5).  Member 0 is the unperturbed control.  Deterministic per device type."""
+    if member == 0:
+        return x0.clone()
+    gen = torch.Generator(device=x0.device).manual_seed(1000 + member)
+    noise = torch.randn(x0.shape, generator=gen, device=x0.device, dtype=x0.dtype)
+    return x0 + scale * std.to(x0.device, x0.dtype)[:, None, None] * noise
+
+
+class MemberParallelEnsemble:
+    """N-member ensemble of one model, members sharded round-robin over the ranks of the default process group
+    (one process per GPU).  ``step_fn`` advances one member by one model step on this rank's device."""
+
+    def __init__(self, step_fn, n_members: int, channel_std: torch.Tensor, perturb_scale: float = 1e-3):
+        self.step_fn = step_fn
+        self.n_members = n_members
+        self.std = channel_std
+        self.scale = perturb_scale
+        self.rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+        self.world = _world()
+        if self.world > n_members:
+            raise ValueError("more ranks than ensemble members")
+        self.members = member_shard(n_members, self.rank, self.world)
+
+    def run(self, x0: torch.Tensor, n_steps: int, gather: bool = False) -> dict:
+        """Roll every local member ``n_steps`` forward.  Returns the ensemble mean and spread of the final states
+        (identical on every rank) and, with ``gather``, all member states ordered by member id (all-gather)."""
+        ics = [perturbed_member(x0, self.std, m, self.scale) for m in self.members]
+        finals = rollout_members(self.step_fn, ics, n_steps)
+        mean, spread = ensemble_mean_spread(finals, self.n_members)
+        out = {"mean": mean, "spread": spread, "local_members": self.members, "local_states": finals}
+        if gather:
+            per = (self.n_members + self.world - 1) // self.world
+            local = torch.stack(finals + [torch.zeros_like(finals[0])] * (per - len(finals)))
+            if self.world > 1:
+                buf = [torch.empty_like(local) for _ in range(self.world)]
+                dist.all_gather(buf, local)
+            else:
+                buf = [local]
+            states = [None] * self.n_members
+            for r in range(self.world):
+                for j, m in enumerate(member_shard(self.n_members, r, self.world)):
+                    states[m] = buf[r][j]
+            out["members"] = torch.stack(states)
+        return out

@@ -41,13 +41,24 @@ class PanguTimeLoop:
     out_channel_names = list(CHANNELS)
 
     def __init__(self, params: dict | None = None, geom: PanguGeometry | None = None, precision: str = "bf16x3",
-                 device: str | torch.device = "cuda:0", seed: int = 0):
+                 device: str | torch.device = "cuda:0", seed: int = 0, params24: dict | None = None):
+        """``params``: 6-h network (default: ``SKYRIM_PANGU_WEIGHTS`` state dict or seeded random init).
+        ``params24`` (optional, or ``SKYRIM_PANGU_WEIGHTS_24``): the 24-h network; when present a multi-step
+        generator interleaves the two like earth2mip's Pangu loop does (every 4th step is a 24-h step from the state
+        24 h earlier, the 6-h network fills in between) -- what ``GlobalModel.forecast`` sees in the reference
+        (base.py:105-107); ``rollout`` re-creates the loop every step and therefore only ever uses the 6-h network."""
         self.geom = geom or PanguGeometry()
         self.engine = PanguEngine(self.geom, precision, device)
         if params is None:
             path = os.environ.get("SKYRIM_PANGU_WEIGHTS")
             params = torch.load(path, map_location="cpu") if path else init_synthetic(self.geom, seed)
         self.engine.load_params(params)
+        if params24 is None and os.environ.get("SKYRIM_PANGU_WEIGHTS_24"):
+            params24 = torch.load(os.environ["SKYRIM_PANGU_WEIGHTS_24"], map_location="cpu")
+        self.engine24 = None
+        if params24 is not None:
+            self.engine24 = PanguEngine(self.geom, precision, device)
+            self.engine24.load_params(params24)
         self.grid = Grid(self.geom.lat, self.geom.lon)
 
     @property
@@ -64,7 +75,12 @@ class PanguTimeLoop:
             raise ValueError(f"expected x of shape (1, 1, {', '.join(map(str, self.engine.state_shape))}), got {tuple(x.shape)}")
         state = x[0, 0].to(self.device, torch.float32).contiguous()
         yield time, state.unsqueeze(0).clone(), restart
+        state24, k = state, 0
         while True:
-            state = self.engine.step(state)          # new buffer each step: the caller keeps the yielded one
+            k += 1
+            if self.engine24 is not None and k % 4 == 0:
+                state = state24 = self.engine24.step(state24)      # 24-h step from the state 24 h earlier
+            else:
+                state = self.engine.step(state)                    # new buffer each step: the caller keeps the yielded one
             time = time + self.time_step
             yield time, state.unsqueeze(0), restart

@@ -7,7 +7,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from skyrim_amd.pangu.ensemble import ensemble_mean_spread, member_shard, rollout_members
+from skyrim_amd.pangu.ensemble import (MemberParallelEnsemble, ensemble_mean_spread, member_shard, perturbed_member,
+                                       rollout_members)
 
 
 def test_member_shard_round_robin():
@@ -67,3 +68,47 @@ def test_two_rank_gloo_matches_single_process():
         assert torch.allclose(mean.double(), ref_mean, rtol=1e-6)
         assert torch.allclose(spread.double(), ref_spread, rtol=5e-3)
     assert torch.equal(got[0][1], got[1][1])
+
+
+def test_perturbed_members_are_seeded_and_small():
+    x0 = torch.ones(3, 8, 16) * 100.0
+    std = torch.tensor([1.0, 10.0, 100.0])
+    a, b = perturbed_member(x0, std, 3), perturbed_member(x0, std, 3)
+    assert torch.equal(a, b) and torch.equal(perturbed_member(x0, std, 0), x0)
+    d = (perturbed_member(x0, std, 4) - x0).flatten(1).std(1)
+    assert torch.allclose(d, 1e-3 * std, rtol=0.3)
+
+
+def _ens_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        x0 = torch.arange(2 * 4 * 6, dtype=torch.float32).reshape(2, 4, 6)
+        ens = MemberParallelEnsemble(lambda x: 0.5 * x + 1.0, 5, torch.tensor([1.0, 2.0]), perturb_scale=0.1)
+        out = ens.run(x0, 2, gather=True)
+        q.put((rank, out["mean"], out["spread"], out["members"], out["local_members"]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_member_parallel_ensemble_two_ranks_equals_one_process():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ens_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=100) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    x0 = torch.arange(2 * 4 * 6, dtype=torch.float32).reshape(2, 4, 6)
+    single = MemberParallelEnsemble(lambda x: 0.5 * x + 1.0, 5, torch.tensor([1.0, 2.0]), perturb_scale=0.1).run(x0, 2, gather=True)
+    assert got[0][4] == [0, 2, 4] and got[1][4] == [1, 3]
+    for rank, mean, spread, members, _ in got:
+        assert torch.allclose(mean, single["mean"], rtol=1e-6)
+        assert torch.allclose(spread, single["spread"], rtol=1e-4, atol=1e-6)
+        assert torch.equal(members, single["members"])

@@ -206,3 +206,21 @@ def test_synthetic_source_is_deterministic_and_era5_sized():
     a, b = src[T0], src[T0]
     assert a.shape == (69, 9, 96) and np.array_equal(a, b) and not np.array_equal(a, src[T0 + datetime.timedelta(hours=6)])
     assert 2.0e5 > a[CHANNELS.index("z500")].mean() > 4.0e4 and 330 > a[CHANNELS.index("t2m")].mean() > 230
+
+
+def test_forecast_cli_mirrors_reference_options(boring_registry, tmp_path, monkeypatch):
+    """/root/reference/skyrim/forecast.py:59-101: same option names and defaults; tests/core/test_skyrim.py:6-10 asserts exit code 0."""
+    from click.testing import CliRunner
+    from skyrim_amd import common, forecast
+    monkeypatch.setattr(common, "AVAILABLE_MODELS", common.AVAILABLE_MODELS + ["boring"])
+    opts = {p.name: p for p in forecast.main.params}
+    assert set(opts) == {"model_name", "date", "time", "lead_time", "list_models", "initial_conditions", "output_dir", "filter_vars", "modal"}
+    assert opts["model_name"].default == "pangu" and opts["lead_time"].default == 6 and opts["initial_conditions"].default == "gfs"
+    assert opts["time"].default == "0000" and "-lm" in opts["list_models"].opts
+    res = CliRunner().invoke(forecast.main, ["--list_models"])
+    assert res.exit_code == 0 and "pangu" in res.output
+    paths = forecast.run_forecast("boring", "20240513", "1800", 12, False, "gfs", str(tmp_path), "t2m")
+    assert len(paths) == 2 and all(Path(p).exists() for p in paths)
+    assert open_dataarray(paths[0]).channel.values.tolist() == ["t2m"]
+    res = CliRunner().invoke(forecast.main, ["--modal"])
+    assert res.exit_code != 0

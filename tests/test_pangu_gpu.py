@@ -217,6 +217,44 @@ def test_pangu_model_rollout_through_reference_api(toy, tmp_path):
     assert np.allclose(fc.values[2, 0], pred.values[1, 68], rtol=1e-4, atol=1e-3)
 
 
+def test_forecast_interleaves_6h_and_24h_networks(toy):
+    """Multi-step generator with a 24-h parameter set: step 4 comes from the 24-h network applied to the initial
+    state, steps 1-3 and 5 from the 6-h network (earth2mip's Pangu schedule, what GlobalModel.forecast drives)."""
+    import datetime
+    from skyrim_amd.pangu.timeloop import PanguTimeLoop
+    g, params, x = toy
+    p24 = init_synthetic(g, 24)
+    loop = PanguTimeLoop(params, g, params24=p24)
+    t0 = datetime.datetime(2024, 1, 1)
+    outs = []
+    for k, (t, y, _) in enumerate(loop(t0, x[None, None].cuda())):
+        outs.append((t, y[0].cpu()))
+        if k == 5:
+            break
+    assert [o[0] for o in outs] == [t0 + datetime.timedelta(hours=6 * k) for k in range(6)]
+    assert torch.equal(outs[0][1], x)
+    want = [x]
+    for k in range(1, 6):
+        want.append(O.forward(p24, x) if k == 4 else O.forward(params, want[k - 1]))
+    for k in range(1, 6):
+        assert O.per_channel_rel_err(outs[k][1], want[k]).max().item() < 1e-3, k
+
+
+def test_member_parallel_ensemble_single_gpu(toy):
+    """config[4] semantics on one GPU: perturbed members, mean / spread, gathered member states."""
+    from skyrim_amd.pangu.engine import PanguEngine
+    from skyrim_amd.pangu.ensemble import MemberParallelEnsemble, perturbed_member
+    g, params, x = toy
+    eng = PanguEngine(g, "bf16x3", "cuda:0")
+    eng.load_params(params)
+    ens = MemberParallelEnsemble(eng.step, 3, params["norm.std"], perturb_scale=1e-2)
+    out = ens.run(x.cuda(), 2, gather=True)
+    assert out["members"].shape == (3, 69, g.n_lat, g.n_lon)
+    ref = torch.stack([O.rollout(params, perturbed_member(x.cuda(), params["norm.std"], m, 1e-2).cpu(), 2)[-1] for m in range(3)])
+    assert O.per_channel_rel_err(out["mean"].cpu(), ref.mean(0)).max().item() < 1e-3
+    assert torch.allclose(out["spread"].cpu(), ref.std(0, unbiased=False), rtol=0.05, atol=1e-3 * ref.abs().max().item())
+
+
 @pytest.mark.timeout(600)
 def test_skyrim_facade_default_grid():
     """config[0] plumbing on the real grid: Skyrim('pangu').predict(6 h) -> GlobalPrediction (2, 69, 721, 1440)."""
