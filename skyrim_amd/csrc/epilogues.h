@@ -4,15 +4,25 @@
 //
 // Swapped order (default):  acc[a][b][r] = C[m = m0w + 16a + (lane&15)][n = n0w + 16b + 4(lane>>4) + r]
 // Un-swapped order:         acc[a][b][r] = C[m = m0w + 16a + 4(lane>>4) + r][n = n0w + 16b + (lane&15)]
+// Rule for every epilogue (measured): on gfx950 stores share the VMEM counter with loads, so a load that
+// sits between two stores makes hipcc wait `vmcnt(0)` -- i.e. for the write acknowledgement of every store issued so far.
+// All global loads of an epilogue are therefore issued BEFORE its first store, and the small per-column tables
+// (bias, gamma, beta, mean/std) are staged into LDS by init() at kernel start and read back with ds_read.
 #pragma once
 #include "common.h"
 
 namespace skp {
 
+constexpr int kEpiReduceBytes = 4096;    // LayerNorm cross-wave reductions
+constexpr int kEpiTableBytes = 8192;     // per-column tables staged by init()
+constexpr int kEpiScratch = kEpiReduceBytes + kEpiTableBytes;
+
+
 // ---- bias + plain fp32 store (PatchEmbedding, DownSample, UpSample.linear2) ---- //
 template <class T, int NPL>
 struct EpStoreF32 {
     static constexpr bool kDualOrder = false;
+    template <class TC> __device__ __forceinline__ void init(char*, int, int) const {}
     float* out;
     const float* bias;      // nullable
     int ld, row_off;
@@ -22,6 +32,12 @@ struct EpStoreF32 {
     __device__ __forceinline__ void run(f32x4 (&acc)[TC::FM][TC::FN], int m0w, int n0w, int lane, int, int, char*, int M, int N, int) const {
         static_assert(SWAP, "swapped order only");
         const int lm = lane & 15, ln = (lane >> 4) * 4;
+        float4 bbv[TC::FN];
+#pragma unroll
+        for (int b = 0; b < TC::FN; ++b) {
+            const int n = n0w + b * 16 + ln;
+            bbv[b] = (bias != nullptr && n < N) ? *reinterpret_cast<const float4*>(bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
 #pragma unroll
         for (int a = 0; a < TC::FM; ++a) {
             const int m = m0w + a * 16 + lm;
@@ -32,8 +48,8 @@ struct EpStoreF32 {
                 const int n = n0w + b * 16 + ln;
                 if (n >= N) continue;
                 float4 v = make_float4(acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]);
-                if (bias != nullptr) {
-                    const float4 bb = *reinterpret_cast<const float4*>(bias + n);
+                {
+                    const float4 bb = bbv[b];
                     v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
                 }
                 *reinterpret_cast<float4*>(orow + n) = v;
@@ -48,6 +64,7 @@ struct EpStoreF32 {
 template <class T, int NPL>
 struct EpGelu {
     static constexpr bool kDualOrder = false;
+    template <class TC> __device__ __forceinline__ void init(char*, int, int) const {}
     T* out;                 // hi/lo planes
     long long plane;
     const float* bias;
@@ -56,16 +73,21 @@ struct EpGelu {
     __device__ __forceinline__ void run(f32x4 (&acc)[TC::FM][TC::FN], int m0w, int n0w, int lane, int, int, char*, int M, int N, int) const {
         static_assert(SWAP, "swapped order only");
         const int lm = lane & 15, ln = (lane >> 4) * 4;
+        float4 bbv[TC::FN];
+#pragma unroll
+        for (int b = 0; b < TC::FN; ++b) {
+            const int n = n0w + b * 16 + ln;
+            bbv[b] = *reinterpret_cast<const float4*>(bias + (n < N ? n : 0));
+        }
 #pragma unroll
         for (int a = 0; a < TC::FM; ++a) {
             const int m = m0w + a * 16 + lm;
             if (m >= M) continue;
-
 #pragma unroll
             for (int b = 0; b < TC::FN; ++b) {
                 const int n = n0w + b * 16 + ln;
                 if (n >= N) continue;
-                const float4 bb = *reinterpret_cast<const float4*>(bias + n);
+                const float4 bb = bbv[b];
 #ifdef SKP_DEBUG_NOGELU
                 float v[4] = {acc[a][b][0] + bb.x, acc[a][b][1] + bb.y, acc[a][b][2] + bb.z, acc[a][b][3] + bb.w};
 #else
@@ -87,6 +109,7 @@ struct EpGelu {
 template <class T, int NPL>
 struct EpQKV {
     static constexpr bool kDualOrder = true;
+    template <class TC> __device__ __forceinline__ void init(char*, int, int) const {}
     T* q; T* k; T* vt;          // hi planes; lo plane at + plane
     long long plane;
     const float* bias;          // [3C]
@@ -97,6 +120,12 @@ struct EpQKV {
     __device__ __forceinline__ void run(f32x4 (&acc)[TC::FM][TC::FN], int m0w, int n0w, int lane, int, int, char*, int M, int N, int) const {
         const int l15 = lane & 15, l4 = (lane >> 4) * 4;
         if constexpr (SWAP) {
+            float4 bbv[TC::FN];
+#pragma unroll
+            for (int b = 0; b < TC::FN; ++b) {
+                const int n = n0w + b * 16 + l4;
+                bbv[b] = *reinterpret_cast<const float4*>(bias + (n < N ? n : 0));
+            }
 #pragma unroll
             for (int a = 0; a < TC::FM; ++a) {
                 const int m = m0w + a * 16 + l15;
@@ -109,7 +138,7 @@ struct EpQKV {
                     const int which = n >= C ? 1 : 0;
                     const int c = n - which * C;
                     const int head = c >> 5, d = c & 31;
-                    const float4 bb = *reinterpret_cast<const float4*>(bias + n);
+                    const float4 bb = bbv[b];
                     const float s = which == 0 ? scale : 1.0f;
                     const float v[4] = {(acc[a][b][0] + bb.x) * s, (acc[a][b][1] + bb.y) * s,
                                         (acc[a][b][2] + bb.z) * s, (acc[a][b][3] + bb.w) * s};
@@ -121,6 +150,12 @@ struct EpQKV {
                 }
             }
         } else {
+            float bbs[TC::FN];
+#pragma unroll
+            for (int b = 0; b < TC::FN; ++b) {
+                const int n = n0w + b * 16 + l15;
+                bbs[b] = bias[n < N ? n : 0];
+            }
 #pragma unroll
             for (int a = 0; a < TC::FM; ++a) {
                 const int m = m0w + a * 16 + l4;
@@ -132,7 +167,7 @@ struct EpQKV {
                     if (n >= N) continue;
                     const int c = n - 2 * C;
                     const int head = c >> 5, d = c & 31;
-                    const float bb = bias[n];
+                    const float bb = bbs[b];
                     const float v[4] = {acc[a][b][0] + bb, acc[a][b][1] + bb, acc[a][b][2] + bb, acc[a][b][3] + bb};
                     uint2 o[NPL];
                     split4<T, NPL>(v, o);
@@ -190,6 +225,15 @@ struct SinkStore {              // out[dest][c..c+3] = y as hi/lo planes
 template <class RowMap, class Sink>
 struct EpLayerNorm {
     static constexpr bool kDualOrder = false;
+    // gamma | beta | bias of this tile's BN columns -> LDS (read back with ds_read: no VMEM load between the stores)
+    template <class TC> __device__ __forceinline__ void init(char* tab, int tid, int n0) const {
+        float* t = reinterpret_cast<float*>(tab);
+        for (int i = tid; i < TC::BN; i += TC::THREADS) {
+            t[i] = gamma[i];
+            t[TC::BN + i] = beta[i];
+            t[2 * TC::BN + i] = bias != nullptr ? bias[n0 + i] : 0.f;
+        }
+    }
     RowMap map;
     Sink sink;
     const float* bias;       // nullable, [N]
@@ -203,13 +247,13 @@ struct EpLayerNorm {
         const int l15 = lane & 15, l4 = (lane >> 4) * 4;
         const int nloc0 = n0w - ntile * BN;          // column of this wave inside the LN group
         float* red = reinterpret_cast<float*>(smem);  // [2][BM][WN]
-        if (bias != nullptr) {
+        const float* tab = reinterpret_cast<const float*>(smem + kEpiReduceBytes);   // gamma | beta | bias (init())
+        static_assert(3 * BN * 4 <= kEpiTableBytes && 2 * BM * WN * 4 <= kEpiReduceBytes, "epilogue LDS scratch");
 #pragma unroll
-            for (int b = 0; b < FN; ++b) {
-                const float4 bb = *reinterpret_cast<const float4*>(bias + n0w + b * 16 + l4);
+        for (int b = 0; b < FN; ++b) {
+            const float4 bb = *reinterpret_cast<const float4*>(tab + 2 * BN + nloc0 + b * 16 + l4);
 #pragma unroll
-                for (int a = 0; a < FM; ++a) { acc[a][b][0] += bb.x; acc[a][b][1] += bb.y; acc[a][b][2] += bb.z; acc[a][b][3] += bb.w; }
-            }
+            for (int a = 0; a < FM; ++a) { acc[a][b][0] += bb.x; acc[a][b][1] += bb.y; acc[a][b][2] += bb.z; acc[a][b][3] += bb.w; }
         }
         // destination rows first (the table lookups overlap the LayerNorm reductions below); rows that do not exist
         // (window padding / crop / M tail) are redirected to row 0 for the loads and skipped for the stores
@@ -218,15 +262,18 @@ struct EpLayerNorm {
 #pragma unroll
         for (int a = 0; a < FM; ++a) {
             const int m = m0w + a * 16 + l15;
-            const long long r = m < M ? map.dest(m, ntile) : -1;
-            ok[a] = r >= 0;
+            const long long r = map.dest(m < M ? m : 0, ntile);     // branch-free: the FM table lookups go out back to back
+            ok[a] = m < M && r >= 0;
             drow[a] = ok[a] ? r : 0;
         }
-        // all residual loads in flight at once (one HBM round trip instead of FM*FN dependent ones)
+        // residual loads: the first PRE 16-row groups go out now (their round trip hides under the LayerNorm
+        // reductions); the last one is issued after group 0 has been stored, when its accumulators are dead --
+        // all FM*FN loads at once spill next to the FM*FN accumulators
+        constexpr int PRE = FM < 3 ? FM : 3;
         float4 old[Sink::kLoads ? FM : 1][Sink::kLoads ? FN : 1];
         if constexpr (Sink::kLoads) {
 #pragma unroll
-            for (int a = 0; a < FM; ++a)
+            for (int a = 0; a < PRE; ++a)
 #pragma unroll
                 for (int b = 0; b < FN; ++b) old[a][b] = sink.load(drow[a], BN, nloc0 + b * 16 + l4);
         }
@@ -272,15 +319,21 @@ struct EpLayerNorm {
             rstd[a] = rsqrtf(s * (1.0f / BN) + eps);
         }
 #pragma unroll
-        for (int b = 0; b < FN; ++b) {
-            const int c = nloc0 + b * 16 + l4;
-            const float4 g = *reinterpret_cast<const float4*>(gamma + c);
-            const float4 be = *reinterpret_cast<const float4*>(beta + c);
+        for (int a = 0; a < FM; ++a) {
 #pragma unroll
-            for (int a = 0; a < FM; ++a) {
+            for (int b = 0; b < FN; ++b) {
+                const int c = nloc0 + b * 16 + l4;
+                const float4 g = *reinterpret_cast<const float4*>(tab + c);
+                const float4 be = *reinterpret_cast<const float4*>(tab + BN + c);
                 const float y[4] = {(acc[a][b][0] - mean[a]) * rstd[a] * g.x + be.x, (acc[a][b][1] - mean[a]) * rstd[a] * g.y + be.y,
                                     (acc[a][b][2] - mean[a]) * rstd[a] * g.z + be.z, (acc[a][b][3] - mean[a]) * rstd[a] * g.w + be.w};
                 if (ok[a]) sink.put(drow[a], BN, c, y, Sink::kLoads ? old[a][b] : old[0][0]);
+            }
+            if constexpr (Sink::kLoads) {
+                if (a + PRE < FM) {
+#pragma unroll
+                    for (int b = 0; b < FN; ++b) old[a + PRE][b] = sink.load(drow[a + PRE], BN, nloc0 + b * 16 + l4);
+                }
             }
         }
     }
@@ -291,16 +344,23 @@ struct EpLayerNorm {
 // Surface:   token (h,w),    n = (v*4+dh)*4+dw       -> state[surf0+v][4h+dh-top][4w+dw]
 struct EpRecover {
     static constexpr bool kDualOrder = false;
+    // mean[0..68] | std[72..140] | bias[144..151] -> LDS
+    template <class TC> __device__ __forceinline__ void init(char* tab, int tid, int) const {
+        float* t = reinterpret_cast<float*>(tab);
+        if (tid < 69) { t[tid] = mean[tid]; t[72 + tid] = std[tid]; }
+        if (tid < 8) t[144 + tid] = tid < (surface ? 4 : 5) ? bias[tid] : 0.f;
+    }
     float* state;            // [69][n_lat][n_lon]
     const float* bias;       // [n_vars]
     const float* mean;       // [69]
     const float* std;        // [69]
     int n_lat, n_lon, lat_top, H1, W1, n_levels, surface, surf0;
     template <class TC, bool SWAP>
-    __device__ __forceinline__ void run(f32x4 (&acc)[TC::FM][TC::FN], int m0w, int n0w, int lane, int, int, char*, int M, int N, int) const {
+    __device__ __forceinline__ void run(f32x4 (&acc)[TC::FM][TC::FN], int m0w, int n0w, int lane, int, int, char* smem, int M, int N, int) const {
         static_assert(SWAP, "swapped order only");
         const int l15 = lane & 15, l4 = (lane >> 4) * 4;
         const int hw = H1 * W1;
+        const float* tab = reinterpret_cast<const float*>(smem + kEpiReduceBytes);
 #pragma unroll
         for (int a = 0; a < TC::FM; ++a) {
             const int m = m0w + a * 16 + l15;
@@ -322,7 +382,7 @@ struct EpRecover {
                 }
                 const int lat = 4 * h + dh - lat_top;
                 if (lat < 0 || lat >= n_lat) continue;
-                const float bb = bias[v], sd = std[ch], mu = mean[ch];
+                const float bb = tab[144 + v], sd = tab[72 + ch], mu = tab[ch];
                 const float4 o = make_float4((acc[a][b][0] + bb) * sd + mu, (acc[a][b][1] + bb) * sd + mu,
                                              (acc[a][b][2] + bb) * sd + mu, (acc[a][b][3] + bb) * sd + mu);
                 *reinterpret_cast<float4*>(state + ((long long)ch * n_lat + lat) * n_lon + 4 * w) = o;

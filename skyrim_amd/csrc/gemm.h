@@ -16,6 +16,7 @@
 // buffer, two barriers per k-tile; several blocks per CU hide the rest.
 #pragma once
 #include "common.h"
+#include "epilogues.h"
 
 namespace skp {
 
@@ -131,6 +132,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs<P, AL, EP>& g, char* sm
     const int nk = (g.K + BK - 1) / BK;
     const int fr_row = lane & 15, fr_grp = lane >> 4;
     load_tile(0);
+    g.ep.template init<TC>(smem + gemm_smem_bytes<P, TC>() + kEpiReduceBytes, tid, n0);   // ordered by the loop's first barrier
     for (int kt = 0; kt < nk; ++kt) {
         stage_tile();
         __syncthreads();
@@ -172,7 +174,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs<P, AL, EP>& g, char* sm
         }
         __syncthreads();
     }
-    g.ep.template run<TC, SWAP>(acc, m0 + wm * TC::WTM, n0 + wn * TC::WTN, lane, wm, wn, smem, g.M, g.N, (int)blockIdx.x);
+    g.ep.template run<TC, SWAP>(acc, m0 + wm * TC::WTM, n0 + wn * TC::WTN, lane, wm, wn, smem + gemm_smem_bytes<P, TC>(), g.M, g.N, (int)blockIdx.x);
 }
 
 template <class P, class TC, class AL, class EP>
@@ -191,7 +193,7 @@ template <class P, class TC, class AL, class EP>
 inline hipError_t launch_gemm(const GemmArgs<P, AL, EP>& g, hipStream_t stream) {
     dim3 grid((g.N + TC::BN - 1) / TC::BN, (g.M + TC::BM - 1) / TC::BM);
     if (grid.x == 0 || grid.y == 0) return hipSuccess;
-    constexpr int smem = gemm_smem_bytes<P, TC>();
+    constexpr int smem = gemm_smem_bytes<P, TC>() + kEpiScratch;
     static_assert(smem <= 64 * 1024, "LDS per block");
     hipLaunchKernelGGL((gemm_kernel<P, TC, AL, EP>), grid, dim3(TC::THREADS), smem, stream, g);
     return hipGetLastError();

@@ -199,6 +199,7 @@ __device__ __forceinline__ void gemm_dma_body(const DmaArgs<P, AS, EP>& g, char*
 
     const int nk = g.K / BK;
     issue(0, 0);
+    g.ep.template init<TC>(smem + 2 * STAGE + kEpiReduceBytes, tid, n0);     // LDS tables; ordered by the loop's first barrier
     for (int kt = 0; kt < nk; ++kt) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -214,7 +215,7 @@ __device__ __forceinline__ void gemm_dma_body(const DmaArgs<P, AS, EP>& g, char*
 #ifdef SKP_DEBUG_NOEPI
     if (acc[0][0][0] != 123.456f) return;
 #endif
-    g.ep.template run<TC, SWAP>(acc, m0 + wm * TC::WTM, n0 + wn * TC::WTN, lane, wm, wn, smem, g.M, g.N, n_tile);
+    g.ep.template run<TC, SWAP>(acc, m0 + wm * TC::WTM, n0 + wn * TC::WTN, lane, wm, wn, smem + 2 * STAGE, g.M, g.N, n_tile);
 }
 
 template <class P, class TC, class AS, class EP>
@@ -241,7 +242,7 @@ inline hipError_t launch_gemm_dma(DmaArgs<P, AS, EP> g, hipStream_t stream) {
     g.nN = (g.N + TC::BN - 1) / TC::BN;
     if (g.nM == 0 || g.nN == 0) return hipSuccess;
     if (g.K % TC::BK != 0) return hipErrorInvalidValue;
-    constexpr int smem = 2 * dma_stage_bytes<P, TC>();
+    constexpr int smem = 2 * dma_stage_bytes<P, TC>() + kEpiScratch;
     static_assert(smem <= 160 * 1024, "LDS per block");
     auto kern = gemm_dma_kernel<P, TC, AS, EP>;
     if (smem > 64 * 1024) {
