@@ -13,6 +13,9 @@
 
 namespace skp {
 
+// keeps a value materialised HERE: stops LLVM from sinking the bias add into the masked store branches
+__device__ __forceinline__ void pin(f32x4& v) { asm volatile("" : "+v"(v)); }
+
 constexpr int kEpiReduceBytes = 4096;    // LayerNorm cross-wave reductions
 constexpr int kEpiTableBytes = 8192;     // per-column tables staged by init()
 constexpr int kEpiScratch = kEpiReduceBytes + kEpiTableBytes;
@@ -32,11 +35,14 @@ struct EpStoreF32 {
     __device__ __forceinline__ void run(f32x4 (&acc)[TC::FM][TC::FN], int m0w, int n0w, int lane, int, int, char*, int M, int N, int) const {
         static_assert(SWAP, "swapped order only");
         const int lm = lane & 15, ln = (lane >> 4) * 4;
-        float4 bbv[TC::FN];
+        // bias is added to every accumulator in straight-line code BEFORE the (masked, hence branchy) store loop: a loaded
+        // register first used inside a branch makes hipcc emit vmcnt(0) there, which also waits for every earlier store
 #pragma unroll
         for (int b = 0; b < TC::FN; ++b) {
             const int n = n0w + b * 16 + ln;
-            bbv[b] = (bias != nullptr && n < N) ? *reinterpret_cast<const float4*>(bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 bb = (bias != nullptr) ? *reinterpret_cast<const float4*>(bias + (n < N ? n : 0)) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int a = 0; a < TC::FM; ++a) { acc[a][b][0] += bb.x; acc[a][b][1] += bb.y; acc[a][b][2] += bb.z; acc[a][b][3] += bb.w; pin(acc[a][b]); }
         }
 #pragma unroll
         for (int a = 0; a < TC::FM; ++a) {
@@ -47,11 +53,7 @@ struct EpStoreF32 {
             for (int b = 0; b < TC::FN; ++b) {
                 const int n = n0w + b * 16 + ln;
                 if (n >= N) continue;
-                float4 v = make_float4(acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]);
-                {
-                    const float4 bb = bbv[b];
-                    v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
-                }
+                const float4 v = make_float4(acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]);
                 *reinterpret_cast<float4*>(orow + n) = v;
                 const float vv[4] = {v.x, v.y, v.z, v.w};
                 store4_planes<T, NPL>(shadow + blk_off(m + row_off, n, ld), plane, vv);
@@ -73,11 +75,12 @@ struct EpGelu {
     __device__ __forceinline__ void run(f32x4 (&acc)[TC::FM][TC::FN], int m0w, int n0w, int lane, int, int, char*, int M, int N, int) const {
         static_assert(SWAP, "swapped order only");
         const int lm = lane & 15, ln = (lane >> 4) * 4;
-        float4 bbv[TC::FN];
 #pragma unroll
-        for (int b = 0; b < TC::FN; ++b) {
+        for (int b = 0; b < TC::FN; ++b) {      // straight-line bias add first (see EpStoreF32)
             const int n = n0w + b * 16 + ln;
-            bbv[b] = *reinterpret_cast<const float4*>(bias + (n < N ? n : 0));
+            const float4 bb = *reinterpret_cast<const float4*>(bias + (n < N ? n : 0));
+#pragma unroll
+            for (int a = 0; a < TC::FM; ++a) { acc[a][b][0] += bb.x; acc[a][b][1] += bb.y; acc[a][b][2] += bb.z; acc[a][b][3] += bb.w; pin(acc[a][b]); }
         }
 #pragma unroll
         for (int a = 0; a < TC::FM; ++a) {
@@ -87,7 +90,7 @@ struct EpGelu {
             for (int b = 0; b < TC::FN; ++b) {
                 const int n = n0w + b * 16 + ln;
                 if (n >= N) continue;
-                const float4 bb = bbv[b];
+                const float4 bb = make_float4(0.f, 0.f, 0.f, 0.f);
 #ifdef SKP_DEBUG_NOGELU
                 float v[4] = {acc[a][b][0] + bb.x, acc[a][b][1] + bb.y, acc[a][b][2] + bb.z, acc[a][b][3] + bb.w};
 #else
@@ -120,11 +123,12 @@ struct EpQKV {
     __device__ __forceinline__ void run(f32x4 (&acc)[TC::FM][TC::FN], int m0w, int n0w, int lane, int, int, char*, int M, int N, int) const {
         const int l15 = lane & 15, l4 = (lane >> 4) * 4;
         if constexpr (SWAP) {
-            float4 bbv[TC::FN];
 #pragma unroll
-            for (int b = 0; b < TC::FN; ++b) {
+            for (int b = 0; b < TC::FN; ++b) {      // straight-line bias add first (see EpStoreF32)
                 const int n = n0w + b * 16 + l4;
-                bbv[b] = *reinterpret_cast<const float4*>(bias + (n < N ? n : 0));
+                const float4 bb = *reinterpret_cast<const float4*>(bias + (n < N ? n : 0));
+#pragma unroll
+                for (int a = 0; a < TC::FM; ++a) { acc[a][b][0] += bb.x; acc[a][b][1] += bb.y; acc[a][b][2] += bb.z; acc[a][b][3] += bb.w; pin(acc[a][b]); }
             }
 #pragma unroll
             for (int a = 0; a < TC::FM; ++a) {
@@ -138,7 +142,7 @@ struct EpQKV {
                     const int which = n >= C ? 1 : 0;
                     const int c = n - which * C;
                     const int head = c >> 5, d = c & 31;
-                    const float4 bb = bbv[b];
+                    const float4 bb = make_float4(0.f, 0.f, 0.f, 0.f);
                     const float s = which == 0 ? scale : 1.0f;
                     const float v[4] = {(acc[a][b][0] + bb.x) * s, (acc[a][b][1] + bb.y) * s,
                                         (acc[a][b][2] + bb.z) * s, (acc[a][b][3] + bb.w) * s};
@@ -150,11 +154,12 @@ struct EpQKV {
                 }
             }
         } else {
-            float bbs[TC::FN];
 #pragma unroll
             for (int b = 0; b < TC::FN; ++b) {
                 const int n = n0w + b * 16 + l15;
-                bbs[b] = bias[n < N ? n : 0];
+                const float bb = bias[n < N ? n : 0];
+#pragma unroll
+                for (int a = 0; a < TC::FM; ++a) { acc[a][b][0] += bb; acc[a][b][1] += bb; acc[a][b][2] += bb; acc[a][b][3] += bb; pin(acc[a][b]); }
             }
 #pragma unroll
             for (int a = 0; a < TC::FM; ++a) {
@@ -167,7 +172,7 @@ struct EpQKV {
                     if (n >= N) continue;
                     const int c = n - 2 * C;
                     const int head = c >> 5, d = c & 31;
-                    const float bb = bbs[b];
+                    const float bb = 0.f;
                     const float v[4] = {acc[a][b][0] + bb, acc[a][b][1] + bb, acc[a][b][2] + bb, acc[a][b][3] + bb};
                     uint2 o[NPL];
                     split4<T, NPL>(v, o);
