@@ -154,16 +154,16 @@ struct Engine : IEngine {
             if (e != hipSuccess) return e;
             ms[prof_cat[i]] += t; cnt[prof_cat[i]]++;
         }
-        const double sa = 2.0 * NPL, hw = (double)g.H1 * g.W1;
+        const double sa = 2.0 * NPL, hw = (double)g.H1 * g.W1, NA_ = P::NA;
         double fl[C_COUNT], by[C_COUNT];
         for (int r = 0; r < 2; ++r) {
             const double C = r == 0 ? 192 : 384, mw = g.mwin[r], nt = g.ntok[r], heads = C / 32, wb = 2.0 * NW;
             const int o = r == 0 ? 0 : 5;
-            fl[C_QKV0 + o] = 2 * mw * C * 3 * C;      by[C_QKV0 + o] = nt * C * sa + 3 * mw * C * 2 + 3 * C * C * wb;
+            fl[C_QKV0 + o] = 2 * mw * C * 3 * C;      by[C_QKV0 + o] = nt * C * 2 * NA_ + 3 * mw * C * 2 + 3 * C * C * wb;
             fl[C_ATTN0 + o] = g.nwin[r] * heads * 4.0 * 144 * 144 * 32;
             by[C_ATTN0 + o] = 3 * mw * C * 2 + mw * C * sa + (double)g.types[r] * heads * 81 * 256 * 2;
-            fl[C_PROJ0 + o] = 2 * mw * C * C;          by[C_PROJ0 + o] = mw * C * sa + 2 * nt * C * 4 + C * C * wb;
-            fl[C_FC1_0 + o] = 2 * nt * C * 4 * C;      by[C_FC1_0 + o] = nt * C * 4 + nt * 4 * C * sa + 4 * C * C * wb;
+            fl[C_PROJ0 + o] = 2 * mw * C * C;          by[C_PROJ0 + o] = mw * C * sa + 2 * nt * C * 4 + C * C * wb;   // stream: 4 B/elem read + 4 B/elem written
+            fl[C_FC1_0 + o] = 2 * nt * C * 4 * C;      by[C_FC1_0 + o] = nt * C * 2 * NA_ + nt * 4 * C * sa + 4 * C * C * wb;
             fl[C_FC2_0 + o] = 2 * nt * C * 4 * C;      by[C_FC2_0 + o] = nt * 4 * C * sa + 2 * nt * C * 4 + 4 * C * C * wb;
         }
         fl[C_EMBED] = 2 * hw * 112 * 192 + 2 * 7 * hw * 160 * 192; by[C_EMBED] = (69.0 + 3) * g.n_lat * g.n_lon * 4 + g.ntok[0] * 192.0 * 4;
@@ -228,11 +228,8 @@ struct Engine : IEngine {
     void plan_workspace(char* base) {
         Arena a{base, 0};
         const size_t n0 = (size_t)g.ntok[0] * 192, n1 = (size_t)g.ntok[1] * 384;
-        wk.X1 = a.take<float>(n0);
-        wk.X2 = a.take<float>(n1);
-        wk.X4 = a.take<float>(n0);
         wk.xs_plane[0] = (long long)n0; wk.xs_plane[1] = (long long)n1;
-        wk.X1s = a.take<T>(n0 * NPL); wk.X2s = a.take<T>(n1 * NPL); wk.X4s = a.take<T>(n0 * NPL);
+        wk.X1s = a.take<T>(n0 * 2); wk.X2s = a.take<T>(n1 * 2); wk.X4s = a.take<T>(n0 * 2);     // always hi + lo
         const size_t m0 = (size_t)g.mwin[0] * 192, m1 = (size_t)g.mwin[1] * 384;
         q_elems = m0 > m1 ? m0 : m1;
         wk.qkv_plane = (long long)q_elems;
@@ -332,8 +329,8 @@ struct Engine : IEngine {
         return b + i;
     }
 
-    // one EarthSpecificBlock on the (fp32 master, 16-bit shadow) pair
-    hipError_t block_pair(int layer0, int i, float* x, T* xs, hipStream_t s) {
+    // one EarthSpecificBlock on a residual stream (hi/lo planes)
+    hipError_t block_planes(int layer0, int i, T* xs, hipStream_t s) {
         const int res = layer_res(layer0), C = layer_dim(layer0), heads = layer_heads(layer0);
         const BlockW<T>& bw = w.blk[block_index(layer0, i)];
         const int* widx = w.widx[res][i & 1];
@@ -344,29 +341,41 @@ struct Engine : IEngine {
         AttnArgs<P> a{wk.q, wk.k, wk.vt, wk.qkv_plane, bw.bias_exp, wk.ao, wk.ao_plane, C, g.nwin[res], g.nW[res], heads};
         CK(launch_attention<P>(a, s));
         mark(C_PROJ0 + o, s);
-        CK((op_proj<P>(g, bw, widx, res, x, xs, wk, s)));
+        CK((op_proj<P>(g, bw, widx, res, xs, wk, s)));
         mark(C_FC1_0 + o, s);
         CK((op_fc1<P>(g, bw, res, xs, wk, s)));
         mark(C_FC2_0 + o, s);
-        CK((op_fc2<P>(g, bw, res, x, xs, wk, s)));
+        CK((op_fc2<P>(g, bw, res, xs, wk, s)));
         mark(-1, s);
         return hipSuccess;
     }
+    // stage-level API: the caller hands / receives fp32 row-major tensors; they are converted to / from planes here
     hipError_t to_planes(const float* x, T* xs, int res, hipStream_t s) {
-        return split_planes<T, NPL>(x, xs, wk.xs_plane[res], wk.xs_plane[res], res == 0 ? 192 : 384, s);
+        return split_planes<T, 2>(x, xs, wk.xs_plane[res], wk.xs_plane[res], res == 0 ? 192 : 384, s);
     }
-    // stage-level API: the caller hands fp32 tensors; shadows are (re)built here
+    hipError_t from_planes(const T* xs, float* x, int res, hipStream_t s) {
+        return merge_planes<T>(xs, wk.xs_plane[res], x, wk.xs_plane[res], res == 0 ? 192 : 384, s);
+    }
     hipError_t block(int layer0, int i, float* x, hipStream_t s) override {
         const int res = layer_res(layer0);
         T* xs = res == 0 ? wk.X1s : wk.X2s;
         CK(to_planes(x, xs, res, s));
-        return block_pair(layer0, i, x, xs, s);
+        CK(block_planes(layer0, i, xs, s));
+        return from_planes(xs, x, res, s);
     }
-    hipError_t embed(const float* in, float* x1, hipStream_t s) override { return op_embed<P>(g, w, in, x1, wk.X1s, wk, s); }
-    hipError_t down(const float* x1, float* x2, hipStream_t s) override { return op_down<P>(g, w, x1, x2, wk.X2s, wk, s); }
+    hipError_t embed(const float* in, float* x1, hipStream_t s) override {
+        CK((op_embed<P>(g, w, in, wk.X1s, wk, s)));
+        return from_planes(wk.X1s, x1, 0, s);
+    }
+    hipError_t down(const float* x1, float* x2, hipStream_t s) override {
+        CK(to_planes(x1, wk.X1s, 0, s));
+        CK((op_down<P>(g, w, wk.X1s, wk.X2s, wk, s)));
+        return from_planes(wk.X2s, x2, 1, s);
+    }
     hipError_t up(const float* x2, float* x4, hipStream_t s) override {
         CK(to_planes(x2, wk.X2s, 1, s));
-        return op_up<P>(g, w, wk.X2s, x4, wk.X4s, wk, s);
+        CK((op_up<P>(g, w, wk.X2s, wk.X4s, wk, s)));
+        return from_planes(wk.X4s, x4, 0, s);
     }
     hipError_t recover(const float* skip, const float* x4, float* out, hipStream_t s) override {
         CK(to_planes(skip, wk.X1s, 0, s));
@@ -376,15 +385,15 @@ struct Engine : IEngine {
 
     hipError_t step(const float* in, float* out, hipStream_t s) override {
         mark(C_EMBED, s);
-        CK((op_embed<P>(g, w, in, wk.X1, wk.X1s, wk, s)));
-        for (int i = 0; i < kDepths[0]; ++i) CK(block_pair(0, i, wk.X1, wk.X1s, s));
+        CK((op_embed<P>(g, w, in, wk.X1s, wk, s)));
+        for (int i = 0; i < kDepths[0]; ++i) CK(block_planes(0, i, wk.X1s, s));
         mark(C_DOWN, s);
-        CK((op_down<P>(g, w, wk.X1, wk.X2, wk.X2s, wk, s)));
-        for (int i = 0; i < kDepths[1]; ++i) CK(block_pair(1, i, wk.X2, wk.X2s, s));
-        for (int i = 0; i < kDepths[2]; ++i) CK(block_pair(2, i, wk.X2, wk.X2s, s));
+        CK((op_down<P>(g, w, wk.X1s, wk.X2s, wk, s)));
+        for (int i = 0; i < kDepths[1]; ++i) CK(block_planes(1, i, wk.X2s, s));
+        for (int i = 0; i < kDepths[2]; ++i) CK(block_planes(2, i, wk.X2s, s));
         mark(C_UP, s);
-        CK((op_up<P>(g, w, wk.X2s, wk.X4, wk.X4s, wk, s)));
-        for (int i = 0; i < kDepths[3]; ++i) CK(block_pair(3, i, wk.X4, wk.X4s, s));
+        CK((op_up<P>(g, w, wk.X2s, wk.X4s, wk, s)));
+        for (int i = 0; i < kDepths[3]; ++i) CK(block_planes(3, i, wk.X4s, s));
         mark(C_RECOVER, s);
         CK((op_recover<P>(g, w, wk.X1s, wk.X4s, out, wk, s)));
         mark(-1, s);
@@ -400,9 +409,9 @@ struct Engine : IEngine {
         if (n == "ao") return set(wk.ao, ao_elems * NPL * sizeof(T));
         if (n == "hid") return set(wk.hid, hid_elems * NPL * sizeof(T));
         if (n == "u") return set(wk.u, (size_t)g.ntok[0] * 192 * NPL * sizeof(T));
-        if (n == "x1") return set(wk.X1, (size_t)g.ntok[0] * 192 * 4);
-        if (n == "x2") return set(wk.X2, (size_t)g.ntok[1] * 384 * 4);
-        if (n == "x4") return set(wk.X4, (size_t)g.ntok[0] * 192 * 4);
+        if (n == "x1") return set(wk.X1s, (size_t)g.ntok[0] * 192 * 2 * sizeof(T));
+        if (n == "x2") return set(wk.X2s, (size_t)g.ntok[1] * 384 * 2 * sizeof(T));
+        if (n == "x4") return set(wk.X4s, (size_t)g.ntok[0] * 192 * 2 * sizeof(T));
         if (n.rfind("widx", 0) == 0 && n.size() == 6) {
             const int r = n[4] - '0', roll = n[5] - '0';
             if (r < 0 || r > 1 || roll < 0 || roll > 1) return false;

@@ -116,11 +116,34 @@ hipError_t split_planes(const float* x, T* planes, long long plane, long long n,
 }
 template hipError_t split_planes<bf16, 2>(const float*, bf16*, long long, long long, int, hipStream_t);
 template hipError_t split_planes<f16, 1>(const float*, f16*, long long, long long, int, hipStream_t);
+template hipError_t split_planes<f16, 2>(const float*, f16*, long long, long long, int, hipStream_t);
 
-// DownSample LayerNorm(4C) statistics of the 2x2-merged rows: one wavefront per merged row
-// (z, h', w'); the 4 source tokens are 4 x C contiguous floats (the one below the grid is zero padding).
-__global__ void __launch_bounds__(256) merge_stats_kernel(const float* __restrict__ x, float2* __restrict__ stats, int Z, int H1, int W1,
-                                                           int H2, int W2, int C, float eps) {
+// planes -> fp32 row-major (stage-level API / tests only: the step itself never materialises an fp32 stream)
+template <class T>
+__global__ void merge_planes_kernel(const T* __restrict__ planes, long long plane, float* __restrict__ x, long long n4, int C) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    typedef T t4 __attribute__((ext_vector_type(4)));
+    const long long e = i * 4, row = e / C;
+    const T* p = planes + blk_off(row, (int)(e - row * C), C);
+    const t4 h = __builtin_bit_cast(t4, *reinterpret_cast<const uint2*>(p));
+    const t4 l = __builtin_bit_cast(t4, *reinterpret_cast<const uint2*>(p + plane));
+    reinterpret_cast<float4*>(x)[i] = make_float4((float)h[0] + (float)l[0], (float)h[1] + (float)l[1], (float)h[2] + (float)l[2], (float)h[3] + (float)l[3]);
+}
+template <class T>
+hipError_t merge_planes(const T* planes, long long plane, float* x, long long n, int C, hipStream_t s) {
+    const long long n4 = n / 4;
+    hipLaunchKernelGGL((merge_planes_kernel<T>), dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, planes, plane, x, n4, C);
+    return hipGetLastError();
+}
+template hipError_t merge_planes<bf16>(const bf16*, long long, float*, long long, int, hipStream_t);
+template hipError_t merge_planes<f16>(const f16*, long long, float*, long long, int, hipStream_t);
+
+// DownSample LayerNorm(4C) statistics of the 2x2-merged rows: one wavefront per merged row (z, h', w'); the 4 source
+// tokens are read from the residual planes (hi + lo) in 8-element chunks (the one below the grid is zero padding).
+template <class T>
+__global__ void __launch_bounds__(256) merge_stats_kernel(const T* __restrict__ x, long long plane, float2* __restrict__ stats, int Z, int H1,
+                                                           int W1, int H2, int W2, int C, float eps) {
     const int lane = threadIdx.x & 63;
     const long long m = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const long long M = (long long)Z * H2 * W2;
@@ -128,21 +151,25 @@ __global__ void __launch_bounds__(256) merge_stats_kernel(const float* __restric
     const int hw = H2 * W2;
     const int z = (int)(m / hw), rem = (int)(m - (long long)z * hw);
     const int h = rem / W2, w = rem - h * W2;
-    const int c4 = C / 4;                      // float4 per token
-    float vals[4][3][4];                       // [quadrant][iteration][4]  (C/4 <= 192 float4 -> 3 iterations of 64 lanes)
+    const int c8 = C / 8;                      // 16-byte chunks per token
+    const int nchunks = 4 * c8;                // per merged row (<= 384 -> up to 6 chunks per lane)
+    float vals[6][8];
     float s = 0.f;
 #pragma unroll
-    for (int qd = 0; qd < 4; ++qd) {
-        const int hf = 2 * h + (qd >> 1), wf = 2 * w + (qd & 1);
-        const bool ok = hf < H1;
-        const float4* p = reinterpret_cast<const float4*>(x + (((long long)z * H1 + hf) * W1 + wf) * C);
+    for (int it = 0; it < 6; ++it) {
+        const int j = it * 64 + lane;
 #pragma unroll
-        for (int it = 0; it < 3; ++it) {
-            const int j = it * 64 + lane;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ok && j < c4) v = p[j];
-            vals[qd][it][0] = v.x; vals[qd][it][1] = v.y; vals[qd][it][2] = v.z; vals[qd][it][3] = v.w;
-            s += (v.x + v.y) + (v.z + v.w);
+        for (int e = 0; e < 8; ++e) vals[it][e] = 0.f;
+        if (j < nchunks) {
+            const int qd = j / c8, c = (j - qd * c8) * 8;
+            const int hf = 2 * h + (qd >> 1), wf = 2 * w + (qd & 1);
+            if (hf < H1) {
+                const T* p = x + blk_off(((long long)z * H1 + hf) * W1 + wf, c, C);
+                const typename OpT<T>::v8 hi = as_v8<T>(*reinterpret_cast<const uint4*>(p));
+                const typename OpT<T>::v8 lo = as_v8<T>(*reinterpret_cast<const uint4*>(p + plane));
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { vals[it][e] = (float)hi[e] + (float)lo[e]; s += vals[it][e]; }
+            }
         }
     }
 #pragma unroll
@@ -150,24 +177,24 @@ __global__ void __launch_bounds__(256) merge_stats_kernel(const float* __restric
     const float mean = s / (4.0f * C);
     float ss = 0.f;
 #pragma unroll
-    for (int qd = 0; qd < 4; ++qd)
+    for (int it = 0; it < 6; ++it) {
+        if (it * 64 + lane < nchunks) {
 #pragma unroll
-        for (int it = 0; it < 3; ++it) {
-            const int j = it * 64 + lane;
-            if (j < c4) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { const float d = vals[qd][it][e] - mean; ss += d * d; }
-            }
+            for (int e = 0; e < 8; ++e) { const float d = vals[it][e] - mean; ss += d * d; }
         }
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
     if (lane == 0) stats[m] = make_float2(mean, rsqrtf(ss / (4.0f * C) + eps));
 }
 
-hipError_t merge_stats(const float* x, float2* stats, int Z, int H1, int W1, int H2, int W2, int C, float eps, hipStream_t s) {
+template <class T>
+hipError_t merge_stats(const T* x, long long plane, float2* stats, int Z, int H1, int W1, int H2, int W2, int C, float eps, hipStream_t s) {
     const long long M = (long long)Z * H2 * W2;
-    hipLaunchKernelGGL(merge_stats_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, x, stats, Z, H1, W1, H2, W2, C, eps);
+    hipLaunchKernelGGL((merge_stats_kernel<T>), dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, x, plane, stats, Z, H1, W1, H2, W2, C, eps);
     return hipGetLastError();
 }
+template hipError_t merge_stats<bf16>(const bf16*, long long, float2*, int, int, int, int, int, int, float, hipStream_t);
+template hipError_t merge_stats<f16>(const f16*, long long, float2*, int, int, int, int, int, int, float, hipStream_t);
 
 }  // namespace skp

@@ -21,15 +21,16 @@ constexpr int kEpiTableBytes = 8192;     // per-column tables staged by init()
 constexpr int kEpiScratch = kEpiReduceBytes + kEpiTableBytes;
 
 
-// ---- bias + plain fp32 store (PatchEmbedding, DownSample, UpSample.linear2) ---- //
-template <class T, int NPL>
-struct EpStoreF32 {
+// ---- bias + store as residual-stream planes (PatchEmbedding, DownSample, UpSample.linear2) ---- //
+// The residual stream has no fp32 copy: it lives as hi/lo 16-bit planes in the blocked operand layout (always two
+// planes = 16 significand bits for bf16, 22 for fp16), which is what both its producers and its consumers want.
+template <class T>
+struct EpStorePlanes {
     static constexpr bool kDualOrder = false;
     template <class TC> __device__ __forceinline__ void init(char*, int, int) const {}
-    float* out;
     const float* bias;      // nullable
     int ld, row_off;
-    T* shadow;              // 16-bit hi/lo planes of the same rows (consumed by the DMA GEMMs)
+    T* out;                 // hi/lo planes, blocked layout
     long long plane;
     template <class TC, bool SWAP>
     __device__ __forceinline__ void run(f32x4 (&acc)[TC::FM][TC::FN], int m0w, int n0w, int lane, int, int, char*, int M, int N, int) const {
@@ -48,15 +49,13 @@ struct EpStoreF32 {
         for (int a = 0; a < TC::FM; ++a) {
             const int m = m0w + a * 16 + lm;
             if (m >= M) continue;
-            float* orow = out + (long long)(m + row_off) * ld;
 #pragma unroll
             for (int b = 0; b < TC::FN; ++b) {
                 const int n = n0w + b * 16 + ln;
                 if (n >= N) continue;
                 const float4 v = make_float4(acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]);
-                *reinterpret_cast<float4*>(orow + n) = v;
                 const float vv[4] = {v.x, v.y, v.z, v.w};
-                store4_planes<T, NPL>(shadow + blk_off(m + row_off, n, ld), plane, vv);
+                store4_planes<T, 2>(out + blk_off(m + row_off, n, ld), plane, vv);
             }
         }
     }
@@ -203,17 +202,21 @@ struct RowMapPixelShuffle {     // UpSample: (z,h,w) of the coarse grid, quadran
         return ((long long)z * H1 + hf) * W1 + wf;
     }
 };
-template <class T, int NPL>
-struct SinkResidual {           // x[dest][c..c+3] += y  (fp32 master) and refresh the 16-bit shadow planes
-    float* x;
-    T* shadow;
+template <class T>
+struct SinkResidual {           // xs[dest][c..c+3] += y on the hi/lo planes of the residual stream
+    T* xs;
     long long plane;
     static constexpr bool kLoads = true;
-    __device__ __forceinline__ float4 load(long long row, int ld, int c) const { return *reinterpret_cast<const float4*>(x + row * ld + c); }
+    __device__ __forceinline__ float4 load(long long row, int ld, int c) const {
+        typedef T t4 __attribute__((ext_vector_type(4)));
+        const T* p = xs + blk_off(row, c, ld);
+        const t4 h = __builtin_bit_cast(t4, *reinterpret_cast<const uint2*>(p));
+        const t4 l = __builtin_bit_cast(t4, *reinterpret_cast<const uint2*>(p + plane));
+        return make_float4((float)h[0] + (float)l[0], (float)h[1] + (float)l[1], (float)h[2] + (float)l[2], (float)h[3] + (float)l[3]);
+    }
     __device__ __forceinline__ void put(long long row, int ld, int c, const float (&y)[4], const float4& old) const {
         const float v[4] = {old.x + y[0], old.y + y[1], old.z + y[2], old.w + y[3]};
-        *reinterpret_cast<float4*>(x + row * ld + c) = make_float4(v[0], v[1], v[2], v[3]);
-        store4_planes<T, NPL>(shadow + blk_off(row, c, ld), plane, v);
+        store4_planes<T, 2>(xs + blk_off(row, c, ld), plane, v);
     }
 };
 template <class T, int NPL>

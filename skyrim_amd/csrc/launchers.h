@@ -44,8 +44,7 @@ template <class P>
 struct Work {
     typedef typename P::T T;
     typedef typename ActT<P>::type S;
-    float *X1, *X2, *X4;     // fp32 residual streams (masters)
-    T *X1s, *X2s, *X4s;      // their 16-bit hi/lo shadow planes (A operands of the DMA GEMMs); lo at + xs_plane[res]
+    T *X1s, *X2s, *X4s;      // residual streams: hi/lo planes, blocked layout (always two planes); lo at + xs_plane[res]
     long long xs_plane[2];
     f16 *q, *k, *vt;         // single fp16 planes in every mode (attention.hip)
     long long qkv_plane;
@@ -73,16 +72,18 @@ inline int layer_heads(int layer) { return layer_res(layer) == 0 ? 6 : 12; }
 
 template <class P> hipError_t launch_attention(const AttnArgs<P>&, hipStream_t);
 
-// Every residual stream travels as a pair: fp32 master X + 16-bit shadow planes Xs (kept in sync by the epilogues).
-template <class P> hipError_t op_embed(const Geom&, const ModelW<typename P::T>&, const float* state, float* X1, typename P::T* X1s, const Work<P>&, hipStream_t);
+// A residual stream is one buffer of hi/lo planes (no fp32 copy): read by the next GEMM's DMA, read-modify-written by the
+// LayerNorm epilogues.
+template <class P> hipError_t op_embed(const Geom&, const ModelW<typename P::T>&, const float* state, typename P::T* X1s, const Work<P>&, hipStream_t);
 template <class P> hipError_t op_recover(const Geom&, const ModelW<typename P::T>&, const typename P::T* skip_s, const typename P::T* x4_s, float* state, const Work<P>&, hipStream_t);
 template <class P> hipError_t op_qkv(const Geom&, const BlockW<typename P::T>&, const int* widx, int res, const typename P::T* Xs, const Work<P>&, hipStream_t);
-template <class P> hipError_t op_proj(const Geom&, const BlockW<typename P::T>&, const int* widx, int res, float* X, typename P::T* Xs, const Work<P>&, hipStream_t);
+template <class P> hipError_t op_proj(const Geom&, const BlockW<typename P::T>&, const int* widx, int res, typename P::T* Xs, const Work<P>&, hipStream_t);
 template <class P> hipError_t op_fc1(const Geom&, const BlockW<typename P::T>&, int res, const typename P::T* Xs, const Work<P>&, hipStream_t);
-template <class P> hipError_t op_fc2(const Geom&, const BlockW<typename P::T>&, int res, float* X, typename P::T* Xs, const Work<P>&, hipStream_t);
-template <class P> hipError_t op_down(const Geom&, const ModelW<typename P::T>&, const float* X1, float* X2, typename P::T* X2s, const Work<P>&, hipStream_t);
-template <class P> hipError_t op_up(const Geom&, const ModelW<typename P::T>&, const typename P::T* X2s, float* X4, typename P::T* X4s, const Work<P>&, hipStream_t);
+template <class P> hipError_t op_fc2(const Geom&, const BlockW<typename P::T>&, int res, typename P::T* Xs, const Work<P>&, hipStream_t);
+template <class P> hipError_t op_down(const Geom&, const ModelW<typename P::T>&, const typename P::T* X1s, typename P::T* X2s, const Work<P>&, hipStream_t);
+template <class P> hipError_t op_up(const Geom&, const ModelW<typename P::T>&, const typename P::T* X2s, typename P::T* X4s, const Work<P>&, hipStream_t);
 template <class T, int NPL> hipError_t split_planes(const float* x, T* planes, long long plane, long long n, int C, hipStream_t);
+template <class T> hipError_t merge_planes(const T* planes, long long plane, float* x, long long n, int C, hipStream_t);
 
 // prepare-time helpers (aux.hip)
 template <class T, int NW>
@@ -90,6 +91,6 @@ hipError_t prep_weight(const float* src, T* dst, long long plane, int N, int K, 
 hipError_t prep_bias_expand(const float* table, f16* out, int types, int heads, int nH, int roll, hipStream_t);
 hipError_t prep_window_index(int* idx, int Z, int H, int W, int Hp, int top, int roll, hipStream_t);
 hipError_t prep_reciprocal(const float* src, float* dst, int n, hipStream_t);
-hipError_t merge_stats(const float* x, float2* stats, int Z, int H1, int W1, int H2, int W2, int C, float eps, hipStream_t);
+template <class T> hipError_t merge_stats(const T* x, long long plane, float2* stats, int Z, int H1, int W1, int H2, int W2, int C, float eps, hipStream_t);
 
 }  // namespace skp

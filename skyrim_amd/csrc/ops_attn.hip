@@ -18,13 +18,13 @@ hipError_t op_qkv(const Geom& g, const BlockW<typename P::T>& b, const int* widx
 }
 
 template <class P>
-hipError_t op_proj(const Geom& g, const BlockW<typename P::T>& b, const int* widx, int res, float* X, typename P::T* Xs, const Work<P>& wk, hipStream_t s) {
+hipError_t op_proj(const Geom& g, const BlockW<typename P::T>& b, const int* widx, int res, typename P::T* Xs, const Work<P>& wk, hipStream_t s) {
     typedef typename P::T T;
-    typedef EpLayerNorm<RowMapIndexed, SinkResidual<T, P::NA>> EP;
+    typedef EpLayerNorm<RowMapIndexed, SinkResidual<T>> EP;
     const int C = res == 0 ? 192 : 384;
     DmaArgs<P, APlanes<T>, EP> a;
     a.as = APlanes<T>{wk.ao, wk.ao_plane, C, nullptr, g.mwin[res]};
-    a.ep = EP{RowMapIndexed{widx}, SinkResidual<T, P::NA>{X, Xs, wk.xs_plane[res]}, b.proj_b, b.n1_g, b.n1_b, 1e-5f};
+    a.ep = EP{RowMapIndexed{widx}, SinkResidual<T>{Xs, wk.xs_plane[res]}, b.proj_b, b.n1_g, b.n1_b, 1e-5f};
     a.W = b.proj.w; a.w_plane = b.proj.plane; a.ldw = b.proj.ldw; a.zrow = wk.zrow;
     a.M = g.mwin[res]; a.N = C; a.K = C;
     if (res == 0) return launch_gemm_dma<P, typename Tiles<P>::D192>(a, s);
@@ -33,7 +33,7 @@ hipError_t op_proj(const Geom& g, const BlockW<typename P::T>& b, const int* wid
 
 template hipError_t op_qkv<PrecBF16x3>(const Geom&, const BlockW<bf16>&, const int*, int, const bf16*, const Work<PrecBF16x3>&, hipStream_t);
 template hipError_t op_qkv<PrecF16>(const Geom&, const BlockW<f16>&, const int*, int, const f16*, const Work<PrecF16>&, hipStream_t);
-template hipError_t op_proj<PrecBF16x3>(const Geom&, const BlockW<bf16>&, const int*, int, float*, bf16*, const Work<PrecBF16x3>&, hipStream_t);
-template hipError_t op_proj<PrecF16>(const Geom&, const BlockW<f16>&, const int*, int, float*, f16*, const Work<PrecF16>&, hipStream_t);
+template hipError_t op_proj<PrecBF16x3>(const Geom&, const BlockW<bf16>&, const int*, int, bf16*, const Work<PrecBF16x3>&, hipStream_t);
+template hipError_t op_proj<PrecF16>(const Geom&, const BlockW<f16>&, const int*, int, f16*, const Work<PrecF16>&, hipStream_t);
 
 }  // namespace skp

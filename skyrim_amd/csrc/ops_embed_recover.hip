@@ -6,15 +6,15 @@
 namespace skp {
 
 template <class P>
-hipError_t op_embed(const Geom& g, const ModelW<typename P::T>& w, const float* state, float* X1, typename P::T* X1s, const Work<P>& wk, hipStream_t s) {
+hipError_t op_embed(const Geom& g, const ModelW<typename P::T>& w, const float* state, typename P::T* X1s, const Work<P>& wk, hipStream_t s) {
     typedef typename P::T T;
     typedef typename Tiles<P>::L192 TC;
-    typedef EpStoreF32<T, P::NA> EP;
+    typedef EpStorePlanes<T> EP;
     const int hw = g.H1 * g.W1;
     {   // surface slab -> token level 0
         GemmArgs<P, ALIm2colSurface, EP> a;
         a.al = ALIm2colSurface{state, w.masks, w.mean, w.istd, g.n_lat, g.n_lon, g.lat_top, g.H1, g.W1, g.surf0, hw};
-        a.ep = EP{X1, w.embed_s_b, 192, 0, X1s, wk.xs_plane[0]};
+        a.ep = EP{w.embed_s_b, 192, 0, X1s, wk.xs_plane[0]};
         a.W = w.embed_s.w; a.w_plane = w.embed_s.plane; a.ldw = w.embed_s.ldw;
         a.M = hw; a.N = 192; a.K = 128;
         SKP_CHECK((launch_gemm<P, TC>(a, s)));
@@ -22,7 +22,7 @@ hipError_t op_embed(const Geom& g, const ModelW<typename P::T>& w, const float* 
     {   // upper air -> token levels 1..7
         GemmArgs<P, ALIm2colUpper, EP> a;
         a.al = ALIm2colUpper{state, w.mean, w.istd, g.n_lat, g.n_lon, g.lat_top, g.H1, g.W1, g.n_levels, (g.Z - 1) * hw};
-        a.ep = EP{X1, w.embed_u_b, 192, hw, X1s, wk.xs_plane[0]};
+        a.ep = EP{w.embed_u_b, 192, hw, X1s, wk.xs_plane[0]};
         a.W = w.embed_u.w; a.w_plane = w.embed_u.plane; a.ldw = w.embed_u.ldw;
         a.M = (g.Z - 1) * hw; a.N = 192; a.K = 160;
         SKP_CHECK((launch_gemm<P, TC>(a, s)));
@@ -54,8 +54,8 @@ hipError_t op_recover(const Geom& g, const ModelW<typename P::T>& w, const typen
     return hipSuccess;
 }
 
-template hipError_t op_embed<PrecBF16x3>(const Geom&, const ModelW<bf16>&, const float*, float*, bf16*, const Work<PrecBF16x3>&, hipStream_t);
-template hipError_t op_embed<PrecF16>(const Geom&, const ModelW<f16>&, const float*, float*, f16*, const Work<PrecF16>&, hipStream_t);
+template hipError_t op_embed<PrecBF16x3>(const Geom&, const ModelW<bf16>&, const float*, bf16*, const Work<PrecBF16x3>&, hipStream_t);
+template hipError_t op_embed<PrecF16>(const Geom&, const ModelW<f16>&, const float*, f16*, const Work<PrecF16>&, hipStream_t);
 template hipError_t op_recover<PrecBF16x3>(const Geom&, const ModelW<bf16>&, const bf16*, const bf16*, float*, const Work<PrecBF16x3>&, hipStream_t);
 template hipError_t op_recover<PrecF16>(const Geom&, const ModelW<f16>&, const f16*, const f16*, float*, const Work<PrecF16>&, hipStream_t);
 

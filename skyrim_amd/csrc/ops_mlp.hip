@@ -28,16 +28,16 @@ hipError_t op_fc1(const Geom& g, const BlockW<typename P::T>& b, int res, const 
 }
 
 template <class P>
-hipError_t op_fc2(const Geom& g, const BlockW<typename P::T>& b, int res, float* X, typename P::T* Xs, const Work<P>& wk, hipStream_t s) {
+hipError_t op_fc2(const Geom& g, const BlockW<typename P::T>& b, int res, typename P::T* Xs, const Work<P>& wk, hipStream_t s) {
     typedef typename P::T T;
-    typedef EpLayerNorm<RowMapIndexed, SinkResidual<T, P::NA>> EP;
+    typedef EpLayerNorm<RowMapIndexed, SinkResidual<T>> EP;
     const int C = res == 0 ? 192 : 384;
     if constexpr (P::NA == 2) {
         if (wk.hid16) {
             typedef PrecF16x2W P2;
             DmaArgs<P2, APlanes<f16>, EP> a;
             a.as = APlanes<f16>{reinterpret_cast<const f16*>(wk.hid), 0, 4 * C, nullptr, g.ntok[res]};
-            a.ep = EP{RowMapIndexed{nullptr}, SinkResidual<T, P::NA>{X, Xs, wk.xs_plane[res]}, b.fc2_b, b.n2_g, b.n2_b, 1e-5f};
+            a.ep = EP{RowMapIndexed{nullptr}, SinkResidual<T>{Xs, wk.xs_plane[res]}, b.fc2_b, b.n2_g, b.n2_b, 1e-5f};
             a.W = b.fc2h.w; a.w_plane = b.fc2h.plane; a.ldw = b.fc2h.ldw; a.zrow = reinterpret_cast<const f16*>(wk.zrow);
             a.M = g.ntok[res]; a.N = C; a.K = 4 * C;
             if (res == 0) return launch_gemm_dma<P2, typename Tiles<P2>::D192>(a, s);
@@ -46,7 +46,7 @@ hipError_t op_fc2(const Geom& g, const BlockW<typename P::T>& b, int res, float*
     }
     DmaArgs<P, APlanes<T>, EP> a;
     a.as = APlanes<T>{wk.hid, wk.hid_plane, 4 * C, nullptr, g.ntok[res]};
-    a.ep = EP{RowMapIndexed{nullptr}, SinkResidual<T, P::NA>{X, Xs, wk.xs_plane[res]}, b.fc2_b, b.n2_g, b.n2_b, 1e-5f};
+    a.ep = EP{RowMapIndexed{nullptr}, SinkResidual<T>{Xs, wk.xs_plane[res]}, b.fc2_b, b.n2_g, b.n2_b, 1e-5f};
     a.W = b.fc2.w; a.w_plane = b.fc2.plane; a.ldw = b.fc2.ldw; a.zrow = wk.zrow;
     a.M = g.ntok[res]; a.N = C; a.K = 4 * C;
     if (res == 0) return launch_gemm_dma<P, typename Tiles<P>::D192>(a, s);
@@ -55,7 +55,7 @@ hipError_t op_fc2(const Geom& g, const BlockW<typename P::T>& b, int res, float*
 
 template hipError_t op_fc1<PrecBF16x3>(const Geom&, const BlockW<bf16>&, int, const bf16*, const Work<PrecBF16x3>&, hipStream_t);
 template hipError_t op_fc1<PrecF16>(const Geom&, const BlockW<f16>&, int, const f16*, const Work<PrecF16>&, hipStream_t);
-template hipError_t op_fc2<PrecBF16x3>(const Geom&, const BlockW<bf16>&, int, float*, bf16*, const Work<PrecBF16x3>&, hipStream_t);
-template hipError_t op_fc2<PrecF16>(const Geom&, const BlockW<f16>&, int, float*, f16*, const Work<PrecF16>&, hipStream_t);
+template hipError_t op_fc2<PrecBF16x3>(const Geom&, const BlockW<bf16>&, int, bf16*, const Work<PrecBF16x3>&, hipStream_t);
+template hipError_t op_fc2<PrecF16>(const Geom&, const BlockW<f16>&, int, f16*, const Work<PrecF16>&, hipStream_t);
 
 }  // namespace skp

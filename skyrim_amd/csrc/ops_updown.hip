@@ -5,20 +5,20 @@
 namespace skp {
 
 template <class P>
-hipError_t op_down(const Geom& g, const ModelW<typename P::T>& w, const float* X1, float* X2, typename P::T* X2s, const Work<P>& wk, hipStream_t s) {
+hipError_t op_down(const Geom& g, const ModelW<typename P::T>& w, const typename P::T* X1s, typename P::T* X2s, const Work<P>& wk, hipStream_t s) {
     typedef typename P::T T;
-    typedef EpStoreF32<T, P::NA> EP;
-    SKP_CHECK(merge_stats(X1, wk.stats, g.Z, g.H1, g.W1, g.H2, g.W2, 192, 1e-5f, s));
-    GemmArgs<P, ALMergeLN, EP> a;
-    a.al = ALMergeLN{X1, wk.stats, w.down_g, w.down_b, g.H1, g.W1, g.H2, g.W2, 192, g.ntok[1]};
-    a.ep = EP{X2, nullptr, 384, 0, X2s, wk.xs_plane[1]};
+    typedef EpStorePlanes<T> EP;
+    SKP_CHECK((merge_stats<T>(X1s, wk.xs_plane[0], wk.stats, g.Z, g.H1, g.W1, g.H2, g.W2, 192, 1e-5f, s)));
+    GemmArgs<P, ALMergeLN<T>, EP> a;
+    a.al = ALMergeLN<T>{X1s, wk.xs_plane[0], wk.stats, w.down_g, w.down_b, g.H1, g.W1, g.H2, g.W2, 192, g.ntok[1]};
+    a.ep = EP{nullptr, 384, 0, X2s, wk.xs_plane[1]};
     a.W = w.down.w; a.w_plane = w.down.plane; a.ldw = w.down.ldw;
     a.M = g.ntok[1]; a.N = 384; a.K = 768;
     return launch_gemm<P, typename Tiles<P>::G128>(a, s);
 }
 
 template <class P>
-hipError_t op_up(const Geom& g, const ModelW<typename P::T>& w, const typename P::T* X2s, float* X4, typename P::T* X4s, const Work<P>& wk, hipStream_t s) {
+hipError_t op_up(const Geom& g, const ModelW<typename P::T>& w, const typename P::T* X2s, typename P::T* X4s, const Work<P>& wk, hipStream_t s) {
     typedef typename P::T T;
     typedef typename Tiles<P>::D192 TC;
     {
@@ -31,10 +31,10 @@ hipError_t op_up(const Geom& g, const ModelW<typename P::T>& w, const typename P
         SKP_CHECK((launch_gemm_dma<P, TC>(a, s)));
     }
     {
-        typedef EpStoreF32<T, P::NA> EP;
+        typedef EpStorePlanes<T> EP;
         DmaArgs<P, APlanes<T>, EP> a;
         a.as = APlanes<T>{wk.u, wk.u_plane, 192, nullptr, g.ntok[0]};
-        a.ep = EP{X4, nullptr, 192, 0, X4s, wk.xs_plane[0]};
+        a.ep = EP{nullptr, 192, 0, X4s, wk.xs_plane[0]};
         a.W = w.up2.w; a.w_plane = w.up2.plane; a.ldw = w.up2.ldw; a.zrow = wk.zrow;
         a.M = g.ntok[0]; a.N = 192; a.K = 192;
         SKP_CHECK((launch_gemm_dma<P, TC>(a, s)));
@@ -42,9 +42,9 @@ hipError_t op_up(const Geom& g, const ModelW<typename P::T>& w, const typename P
     return hipSuccess;
 }
 
-template hipError_t op_down<PrecBF16x3>(const Geom&, const ModelW<bf16>&, const float*, float*, bf16*, const Work<PrecBF16x3>&, hipStream_t);
-template hipError_t op_down<PrecF16>(const Geom&, const ModelW<f16>&, const float*, float*, f16*, const Work<PrecF16>&, hipStream_t);
-template hipError_t op_up<PrecBF16x3>(const Geom&, const ModelW<bf16>&, const bf16*, float*, bf16*, const Work<PrecBF16x3>&, hipStream_t);
-template hipError_t op_up<PrecF16>(const Geom&, const ModelW<f16>&, const f16*, float*, f16*, const Work<PrecF16>&, hipStream_t);
+template hipError_t op_down<PrecBF16x3>(const Geom&, const ModelW<bf16>&, const bf16*, bf16*, const Work<PrecBF16x3>&, hipStream_t);
+template hipError_t op_down<PrecF16>(const Geom&, const ModelW<f16>&, const f16*, f16*, const Work<PrecF16>&, hipStream_t);
+template hipError_t op_up<PrecBF16x3>(const Geom&, const ModelW<bf16>&, const bf16*, bf16*, const Work<PrecBF16x3>&, hipStream_t);
+template hipError_t op_up<PrecF16>(const Geom&, const ModelW<f16>&, const f16*, f16*, const Work<PrecF16>&, hipStream_t);
 
 }  // namespace skp

@@ -42,7 +42,7 @@ def _worker(rank, world, port, n_members, q):
         ics = [base + 1.0 * m for m in members]
         outs = rollout_members(lambda x: x * 1.0 + 0.5, ics, 3)       # fake "step"
         mean, spread = ensemble_mean_spread(outs, n_members)
-        q.put((rank, mean, spread))
+        q.put((rank, mean.numpy(), spread.numpy()))        # by value: the worker may exit before the parent reads
     finally:
         dist.destroy_process_group()
 
@@ -64,6 +64,7 @@ def test_two_rank_gloo_matches_single_process():
     base = 1e5 + torch.randn(4, 6, 8, generator=gen)
     allm = torch.stack(rollout_members(lambda x: x * 1.0 + 0.5, [base + 1.0 * m for m in range(n_members)], 3))
     ref_mean, ref_spread = allm.double().mean(0), allm.double().std(0, unbiased=False)
+    got = [(r, torch.from_numpy(m), torch.from_numpy(s)) for r, m, s in got]
     for rank, mean, spread in got:
         assert torch.allclose(mean.double(), ref_mean, rtol=1e-6)
         assert torch.allclose(spread.double(), ref_spread, rtol=5e-3)
@@ -87,7 +88,7 @@ def _ens_worker(rank, world, port, q):
         x0 = torch.arange(2 * 4 * 6, dtype=torch.float32).reshape(2, 4, 6)
         ens = MemberParallelEnsemble(lambda x: 0.5 * x + 1.0, 5, torch.tensor([1.0, 2.0]), perturb_scale=0.1)
         out = ens.run(x0, 2, gather=True)
-        q.put((rank, out["mean"], out["spread"], out["members"], out["local_members"]))
+        q.put((rank, out["mean"].numpy(), out["spread"].numpy(), out["members"].numpy(), out["local_members"]))
     finally:
         dist.destroy_process_group()
 
@@ -109,6 +110,7 @@ def test_member_parallel_ensemble_two_ranks_equals_one_process():
     single = MemberParallelEnsemble(lambda x: 0.5 * x + 1.0, 5, torch.tensor([1.0, 2.0]), perturb_scale=0.1).run(x0, 2, gather=True)
     assert got[0][4] == [0, 2, 4] and got[1][4] == [1, 3]
     for rank, mean, spread, members, _ in got:
+        mean, spread, members = torch.from_numpy(mean), torch.from_numpy(spread), torch.from_numpy(members)
         assert torch.allclose(mean, single["mean"], rtol=1e-6)
         assert torch.allclose(spread, single["spread"], rtol=1e-4, atol=1e-6)
         assert torch.equal(members, single["members"])
