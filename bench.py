@@ -197,9 +197,9 @@ def main():
                 "workload": f"Pangu 6-h autoregressive rollout, {args.n_lat}x{args.n_lon}x69 state "
                             "(13 levels x 5 vars + 4 surface), random-init weights (64 M params), "
                             "state resident in HBM, 1 ensemble member per GPU",
-                "precision": {"bf16x3": "bf16 MFMA, hi/lo operand split (3 terms), fp32 accumulate, fp32 residual stream",
+                "precision": {"bf16x3": "bf16 MFMA, hi/lo operand split (3 terms), fp32 accumulate, residual stream as bf16 hi+lo planes; attention single-term fp16",
                               "bf16x3h": "bf16 MFMA hi/lo split (3 terms) with the MLP hidden stored as one fp16 plane (fc2: 2 fp16 terms); attention single-term fp16",
-                              "f16": "fp16 MFMA single term, fp32 accumulate, fp32 residual stream"}[args.precision],
+                              "f16": "fp16 MFMA single term, fp32 accumulate, residual stream as fp16 hi+lo planes"}[args.precision],
                 "parallelism": f"member-parallel x{world}" if world > 1 else "single GPU",
                 "finite": finite,
             },
