@@ -3,6 +3,7 @@ HIP-engine TimeLoop instead of ``earth2mip.networks.pangu.load(registry.get_mode
 from __future__ import annotations
 
 from ...pangu.spec import CHANNELS  # noqa: F401  (same list as the reference's pangu.py:6-13)
+from ...pangu.engine import DEFAULT_PRECISION
 from .base import GlobalModel
 
 
@@ -16,7 +17,7 @@ class PanguModel(GlobalModel):
 
     model_name = "pangu"
 
-    def __init__(self, *args, geom=None, precision: str = "bf16x3", device="cuda:0", params=None, **kwargs):
+    def __init__(self, *args, geom=None, precision: str = DEFAULT_PRECISION, device="cuda:0", params=None, **kwargs):
         # extras beyond the reference's signature (all optional): grid geometry (default 721x1440),
         # MFMA precision mode, device, and a parameter dict (default: SKYRIM_PANGU_WEIGHTS or seeded random init)
         self._engine_kw = dict(geom=geom, precision=precision, device=device, params=params)

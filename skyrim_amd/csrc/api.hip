@@ -3,6 +3,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/skyrim_pangu.h"
@@ -100,6 +101,7 @@ struct IEngine {
     virtual hipError_t profile_read(skpangu_stage_stat* out, int cap, int* n) = 0;
     virtual size_t prepared_bytes() const = 0;
     virtual size_t workspace_bytes() const = 0;
+    virtual void bind(char* prepared, char* workspace) = 0;
 };
 
 template <class P>
@@ -204,7 +206,7 @@ struct Engine : IEngine {
                 bw.qkv = take_lin(a, 3 * c, c); bw.proj = take_lin(a, c, c);
                 bw.fc1 = take_lin(a, 4 * c, c); bw.fc2 = take_lin(a, c, 4 * c);
                 bw.fc2h = LinW<f16>{nullptr, 0, 4 * c};
-                if (hid16) { bw.fc2h.plane = (long long)c * 4 * c; bw.fc2h.w = a.take<f16>((size_t)bw.fc2h.plane * 2); }
+                if (hid16 && !std::is_same<T, f16>::value) { bw.fc2h.plane = (long long)c * 4 * c; bw.fc2h.w = a.take<f16>((size_t)bw.fc2h.plane * 2); }
                 bw.qkv_b = a.take<float>(3 * c); bw.proj_b = a.take<float>(c);
                 bw.fc1_b = a.take<float>(4 * c); bw.fc2_b = a.take<float>(c);
                 bw.n1_g = a.take<float>(c); bw.n1_b = a.take<float>(c);
@@ -247,14 +249,16 @@ struct Engine : IEngine {
         ws_bytes = (a.off + 255) / 256 * 256;
     }
 
-    explicit Engine(const Geom& geom, int hid16_ = 0) : g(geom), hid16(hid16_) {
+    explicit Engine(const Geom& geom, int hid16_ = 0, int qkv_a1 = 0) : g(geom), hid16(hid16_) {
         wk.hid16 = hid16_;
+        wk.qkv_a1 = qkv_a1;
         params = build_params(g, nullptr);
         plan_prepared(nullptr);
         plan_workspace(nullptr);
     }
     size_t prepared_bytes() const override { return prep_bytes; }
     size_t workspace_bytes() const override { return ws_bytes; }
+    void bind(char* prepared, char* workspace) override { plan_prepared(prepared); plan_workspace(workspace); }
 
     const float* P_(const float* master, const std::string& name) const {
         for (const Param& p : params)
@@ -265,8 +269,9 @@ struct Engine : IEngine {
         return hipMemcpyAsync(const_cast<float*>(dst), src, n * sizeof(float), hipMemcpyDeviceToDevice, s);
     }
     // blocked = 1 for weights read by the DMA GEMMs, 0 for the register-staged GEMMs (embed, DownSample)
-    hipError_t lin(const LinW<T>& l, const float* src, int N, int K, long long sn, long long sk, hipStream_t s, int blocked = 1) {
-        return prep_weight<T, NW>(src, const_cast<T*>(l.w), l.plane, N, K, l.ldw, sn, sk, blocked, s);
+    // perm = 1: "perm8" row order (common.h) -- every GEMM whose epilogue stores 8 consecutive columns per lane
+    hipError_t lin(const LinW<T>& l, const float* src, int N, int K, long long sn, long long sk, hipStream_t s, int blocked = 1, int perm = 1) {
+        return prep_weight<T, NW>(src, const_cast<T*>(l.w), l.plane, N, K, l.ldw, sn, sk, blocked, perm, s);
     }
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return e_; } while (0)
@@ -292,7 +297,7 @@ struct Engine : IEngine {
                 CK(lin(bw.proj, P_(m, p + "attn.proj.weight"), c, c, c, 1, s));
                 CK(lin(bw.fc1, P_(m, p + "mlp.fc1.weight"), 4 * c, c, c, 1, s));
                 CK(lin(bw.fc2, P_(m, p + "mlp.fc2.weight"), c, 4 * c, 4 * c, 1, s));
-                if (hid16) CK((prep_weight<f16, 2>(P_(m, p + "mlp.fc2.weight"), const_cast<f16*>(bw.fc2h.w), bw.fc2h.plane, c, 4 * c, 4 * c, 4 * c, 1, 1, s)));
+                if (hid16 && !std::is_same<T, f16>::value) CK((prep_weight<f16, 2>(P_(m, p + "mlp.fc2.weight"), const_cast<f16*>(bw.fc2h.w), bw.fc2h.plane, c, 4 * c, 4 * c, 4 * c, 1, 1, 1, s)));
                 CK(copyf(bw.qkv_b, P_(m, p + "attn.qkv.bias"), 3 * c, s));
                 CK(copyf(bw.proj_b, P_(m, p + "attn.proj.bias"), c, s));
                 CK(copyf(bw.fc1_b, P_(m, p + "mlp.fc1.bias"), 4 * c, s));
@@ -312,8 +317,8 @@ struct Engine : IEngine {
         CK(copyf(w.up_g, P_(m, "up.norm.weight"), 192, s));
         CK(copyf(w.up_b, P_(m, "up.norm.bias"), 192, s));
         // ConvTranspose weights are [K = 384][N]; the GEMM wants [N][K]
-        CK(lin(w.rec_u, P_(m, "recover.conv.weight"), 160, 384, 1, 160, s));
-        CK(lin(w.rec_s, P_(m, "recover.conv_surface.weight"), 64, 384, 1, 64, s));
+        CK(lin(w.rec_u, P_(m, "recover.conv.weight"), 160, 384, 1, 160, s, 1, 0));     // EpRecover: 4 = one float4 of longitudes
+        CK(lin(w.rec_s, P_(m, "recover.conv_surface.weight"), 64, 384, 1, 64, s, 1, 0));
         CK(copyf(w.rec_u_b, P_(m, "recover.conv.bias"), 5, s));
         CK(copyf(w.rec_s_b, P_(m, "recover.conv_surface.bias"), 4, s));
         const int H[2] = {g.H1, g.H2}, W[2] = {g.W1, g.W2};
@@ -431,6 +436,9 @@ IEngine* make_engine(const skpangu_config& cfg, const Geom& g) {
         case SKPANGU_PREC_BF16X3: return new Engine<PrecBF16x3>(g);
         case SKPANGU_PREC_F16: return new Engine<PrecF16>(g);
         case SKPANGU_PREC_BF16X3_H16: return new Engine<PrecBF16x3>(g, 1);
+        case SKPANGU_PREC_F16X3: return new Engine<PrecF16x3>(g, 0, 0);
+        case SKPANGU_PREC_F16X3_Q: return new Engine<PrecF16x3>(g, 0, 1);
+        case SKPANGU_PREC_F16X3_QH: return new Engine<PrecF16x3>(g, 1, 1);
         default: return nullptr;
     }
 }
@@ -498,13 +506,7 @@ int skpangu_create(const skpangu_config* cfg, void* prepared_dev, size_t prepare
     if (!e) return SKPANGU_E_ARG;
     if (prepared_bytes < e->prepared_bytes() || workspace_bytes < e->workspace_bytes()) { delete e; return SKPANGU_E_SIZE; }
     if (((uintptr_t)prepared_dev & 255) || ((uintptr_t)workspace_dev & 255)) { delete e; return SKPANGU_E_ARG; }
-    if (cfg->precision == SKPANGU_PREC_BF16X3 || cfg->precision == SKPANGU_PREC_BF16X3_H16) {
-        auto* t = static_cast<Engine<PrecBF16x3>*>(e);
-        t->plan_prepared((char*)prepared_dev); t->plan_workspace((char*)workspace_dev);
-    } else {
-        auto* t = static_cast<Engine<PrecF16>*>(e);
-        t->plan_prepared((char*)prepared_dev); t->plan_workspace((char*)workspace_dev);
-    }
+    e->bind((char*)prepared_dev, (char*)workspace_dev);
     skpangu_ctx* c = new skpangu_ctx{*cfg, g, e, false};
     *out = c;
     return 0;

@@ -168,5 +168,6 @@ hipError_t launch_attention(const AttnArgs<P>& a, hipStream_t stream) {
 
 template hipError_t launch_attention<PrecBF16x3>(const AttnArgs<PrecBF16x3>&, hipStream_t);
 template hipError_t launch_attention<PrecF16>(const AttnArgs<PrecF16>&, hipStream_t);
+template hipError_t launch_attention<PrecF16x3>(const AttnArgs<PrecF16x3>&, hipStream_t);
 
 }  // namespace skp

@@ -9,11 +9,12 @@ namespace skp {
 // plain [N][K] linears (sn=K, sk=1) and the ConvTranspose weights stored [K][N] (sn=1, sk=N).
 template <class T, int NW>
 __global__ void prep_weight_kernel(const float* __restrict__ src, T* __restrict__ dst, long long plane, int N, int K, int ldd,
-                                   long long sn, long long sk, int blocked) {
+                                   long long sn, long long sk, int blocked, int perm) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long long)N * ldd) return;
     const int n = (int)(i / ldd), k = (int)(i - (long long)n * ldd);
-    const float v = k < K ? src[n * sn + k * sk] : 0.f;
+    const int ns = perm ? perm8_col(n) : n;       // prepared row n holds output column ns (common.h, perm8)
+    const float v = k < K ? src[ns * sn + k * sk] : 0.f;
     const T h = (T)v;
     const long long o = blocked ? blk_off(n, k, ldd) : i;     // blocked: the DMA GEMMs' [N/16][K/32][16][32] layout
     dst[o] = h;
@@ -21,14 +22,15 @@ __global__ void prep_weight_kernel(const float* __restrict__ src, T* __restrict_
 }
 
 template <class T, int NW>
-hipError_t prep_weight(const float* src, T* dst, long long plane, int N, int K, int ldd, long long sn, long long sk, int blocked, hipStream_t s) {
+hipError_t prep_weight(const float* src, T* dst, long long plane, int N, int K, int ldd, long long sn, long long sk, int blocked, int perm, hipStream_t s) {
+    if (perm && (N & 31)) return hipErrorInvalidValue;
     const long long total = (long long)N * ldd;
-    hipLaunchKernelGGL((prep_weight_kernel<T, NW>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, dst, plane, N, K, ldd, sn, sk, blocked);
+    hipLaunchKernelGGL((prep_weight_kernel<T, NW>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, dst, plane, N, K, ldd, sn, sk, blocked, perm);
     return hipGetLastError();
 }
-template hipError_t prep_weight<bf16, 2>(const float*, bf16*, long long, int, int, int, long long, long long, int, hipStream_t);
-template hipError_t prep_weight<f16, 1>(const float*, f16*, long long, int, int, int, long long, long long, int, hipStream_t);
-template hipError_t prep_weight<f16, 2>(const float*, f16*, long long, int, int, int, long long, long long, int, hipStream_t);
+template hipError_t prep_weight<bf16, 2>(const float*, bf16*, long long, int, int, int, long long, long long, int, int, hipStream_t);
+template hipError_t prep_weight<f16, 1>(const float*, f16*, long long, int, int, int, long long, long long, int, int, hipStream_t);
+template hipError_t prep_weight<f16, 2>(const float*, f16*, long long, int, int, int, long long, long long, int, int, hipStream_t);
 
 // Earth-specific bias gathered from the compact (3312, types, heads) table into the attention
 // kernel's accumulator order [type][head][qf][kf][lane][r]:

@@ -39,6 +39,8 @@ __device__ __forceinline__ typename OpT<T>::v8 as_v8(const uint4& u) {
 // bf16x3 carries 16 significand bits per operand: fp32-class results on the bf16 MFMA pipe.
 struct PrecBF16x3 { typedef bf16 T; static constexpr int NA = 2, NW = 2; };
 struct PrecF16    { typedef f16 T;  static constexpr int NA = 1, NW = 1; };
+// fp16 hi/lo planes, 3 terms: 22 significand bits per operand (bf16x3: 16); needs |x| < 65504 (activations are O(1..10))
+struct PrecF16x3  { typedef f16 T;  static constexpr int NA = 2, NW = 2; };
 // fc2 of the "fp16 hidden" mode: A = single fp16 plane (the GELU output), W = fp16 hi/lo planes, 2 MFMA terms
 struct PrecF16x2W { typedef f16 T;  static constexpr int NA = 1, NW = 2; };
 
@@ -104,6 +106,26 @@ __device__ __forceinline__ void store4_planes(T* p, long long plane, const float
     split4<T, NP>(v, o);
     *reinterpret_cast<uint2*>(p) = o[0];
     if constexpr (NP == 2) *reinterpret_cast<uint2*>(p + plane) = o[1];
+}
+
+// store 8 consecutive values as NP 16-bit planes: one 16-byte store per plane
+template <class T, int NP>
+__device__ __forceinline__ void store8_planes(T* p, long long plane, const float (&v)[8]) {
+    uint4 o[NP];
+    split8<T, NP>(v, o);
+    *reinterpret_cast<uint4*>(p) = o[0];
+    if constexpr (NP == 2) *reinterpret_cast<uint4*>(p + plane) = o[1];
+}
+
+// "perm8" row order of the prepared weights: inside every aligned group of 32 output columns, prepared row
+// rho = 16 jj + 4 q + i holds output column 8 q + 4 jj + i.  In the swapped MFMA order (lane: row l&15, columns
+// 16 b + 4 (l>>4) + i of fragment b) the accumulators of a fragment pair (2bp, 2bp+1) are then 8 CONSECUTIVE output
+// columns  n0w + 32 bp + 8 (l>>4) + [0..7]:  every activation store / residual load is 16 bytes per lane and one wave
+// instruction covers one whole contiguous 1 KiB block of the blocked layout (8-byte stores are issue-bound at
+// ~7 B/clk/CU, MI355X_MICROARCH.md "attention epilogue store tail").
+__device__ __host__ __forceinline__ int perm8_col(int rho) {
+    const int r = rho & 31;
+    return (rho & ~31) + 8 * ((r >> 2) & 3) + 4 * (r >> 4) + (r & 3);
 }
 
 // ---- LDS tile addressing --------------------------------------------------- //

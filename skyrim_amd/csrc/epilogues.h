@@ -2,8 +2,11 @@
 // everything between "sum over k" and HBM: bias, GELU, LayerNorm + residual, window reverse /
 // un-roll / crop, pixel shuffle, QKV head split (+ V transpose), ConvTranspose scatter + de-normalise.
 //
-// Swapped order (default):  acc[a][b][r] = C[m = m0w + 16a + (lane&15)][n = n0w + 16b + 4(lane>>4) + r]
-// Un-swapped order:         acc[a][b][r] = C[m = m0w + 16a + 4(lane>>4) + r][n = n0w + 16b + (lane&15)]
+// Swapped order (default):  acc[a][b][r] = C[m = m0w + 16a + (lane&15)][n' = n0w + 16b + 4(lane>>4) + r]
+// Un-swapped order:         acc[a][b][r] = C[m = m0w + 16a + 4(lane>>4) + r][n' = n0w + 16b + (lane&15)]
+// n' is the PREPARED weight row; with the perm8 row order (common.h; every GEMM but PatchRecovery) the output column is
+// n = perm8_col(n'), i.e. in swapped order the fragment pair (2bp, 2bp+1) of a lane holds the 8 consecutive columns
+// n0w + 32bp + 8(lane>>4) + [0..7]  (acc[a][2bp][0..3] then acc[a][2bp+1][0..3]).
 // Rule for every epilogue (measured): on gfx950 stores share the VMEM counter with loads, so a load that
 // sits between two stores makes hipcc wait `vmcnt(0)` -- i.e. for the write acknowledgement of every store issued so far.
 // All global loads of an epilogue are therefore issued BEFORE its first store, and the small per-column tables
@@ -15,6 +18,12 @@ namespace skp {
 
 // keeps a value materialised HERE: stops LLVM from sinking the bias add into the masked store branches
 __device__ __forceinline__ void pin(f32x4& v) { asm volatile("" : "+v"(v)); }
+
+// the 8 consecutive columns of fragment pair bp (perm8)
+__device__ __forceinline__ void add8(f32x4& lo, f32x4& hi, const float4& b0, const float4& b1) {
+    lo[0] += b0.x; lo[1] += b0.y; lo[2] += b0.z; lo[3] += b0.w;
+    hi[0] += b1.x; hi[1] += b1.y; hi[2] += b1.z; hi[3] += b1.w;
+}
 
 constexpr int kEpiReduceBytes = 4096;    // LayerNorm cross-wave reductions
 constexpr int kEpiTableBytes = 8192;     // per-column tables staged by init()
@@ -34,28 +43,30 @@ struct EpStorePlanes {
     long long plane;
     template <class TC, bool SWAP>
     __device__ __forceinline__ void run(f32x4 (&acc)[TC::FM][TC::FN], int m0w, int n0w, int lane, int, int, char*, int M, int N, int) const {
-        static_assert(SWAP, "swapped order only");
-        const int lm = lane & 15, ln = (lane >> 4) * 4;
+        static_assert(SWAP && TC::FN % 2 == 0, "swapped order, fragment pairs");
+        const int lm = lane & 15, l8 = (lane >> 4) * 8;
         // bias is added to every accumulator in straight-line code BEFORE the (masked, hence branchy) store loop: a loaded
         // register first used inside a branch makes hipcc emit vmcnt(0) there, which also waits for every earlier store
 #pragma unroll
-        for (int b = 0; b < TC::FN; ++b) {
-            const int n = n0w + b * 16 + ln;
-            const float4 bb = (bias != nullptr) ? *reinterpret_cast<const float4*>(bias + (n < N ? n : 0)) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int bp = 0; bp < TC::FN / 2; ++bp) {
+            const int n = n0w + bp * 32 + l8;
+            const float* bsrc = bias + (n < N ? n : 0);
+            const float4 b0 = (bias != nullptr) ? *reinterpret_cast<const float4*>(bsrc) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 b1 = (bias != nullptr) ? *reinterpret_cast<const float4*>(bsrc + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-            for (int a = 0; a < TC::FM; ++a) { acc[a][b][0] += bb.x; acc[a][b][1] += bb.y; acc[a][b][2] += bb.z; acc[a][b][3] += bb.w; pin(acc[a][b]); }
+            for (int a = 0; a < TC::FM; ++a) { add8(acc[a][2 * bp], acc[a][2 * bp + 1], b0, b1); pin(acc[a][2 * bp]); pin(acc[a][2 * bp + 1]); }
         }
 #pragma unroll
         for (int a = 0; a < TC::FM; ++a) {
             const int m = m0w + a * 16 + lm;
             if (m >= M) continue;
 #pragma unroll
-            for (int b = 0; b < TC::FN; ++b) {
-                const int n = n0w + b * 16 + ln;
+            for (int bp = 0; bp < TC::FN / 2; ++bp) {
+                const int n = n0w + bp * 32 + l8;
                 if (n >= N) continue;
-                const float4 v = make_float4(acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]);
-                const float vv[4] = {v.x, v.y, v.z, v.w};
-                store4_planes<T, 2>(out + blk_off(m + row_off, n, ld), plane, vv);
+                const f32x4 &x = acc[a][2 * bp], &y = acc[a][2 * bp + 1];
+                const float vv[8] = {x[0], x[1], x[2], x[3], y[0], y[1], y[2], y[3]};
+                store8_planes<T, 2>(out + blk_off(m + row_off, n, ld), plane, vv);
             }
         }
     }
@@ -72,34 +83,35 @@ struct EpGelu {
     int ld;
     template <class TC, bool SWAP>
     __device__ __forceinline__ void run(f32x4 (&acc)[TC::FM][TC::FN], int m0w, int n0w, int lane, int, int, char*, int M, int N, int) const {
-        static_assert(SWAP, "swapped order only");
-        const int lm = lane & 15, ln = (lane >> 4) * 4;
+        static_assert(SWAP && TC::FN % 2 == 0, "swapped order, fragment pairs");
+        const int lm = lane & 15, l8 = (lane >> 4) * 8;
 #pragma unroll
-        for (int b = 0; b < TC::FN; ++b) {      // straight-line bias add first (see EpStoreF32)
-            const int n = n0w + b * 16 + ln;
-            const float4 bb = *reinterpret_cast<const float4*>(bias + (n < N ? n : 0));
+        for (int bp = 0; bp < TC::FN / 2; ++bp) {      // straight-line bias add first (see EpStorePlanes)
+            const int n = n0w + bp * 32 + l8;
+            const float* bsrc = bias + (n < N ? n : 0);
+            const float4 b0 = *reinterpret_cast<const float4*>(bsrc), b1 = *reinterpret_cast<const float4*>(bsrc + 4);
 #pragma unroll
-            for (int a = 0; a < TC::FM; ++a) { acc[a][b][0] += bb.x; acc[a][b][1] += bb.y; acc[a][b][2] += bb.z; acc[a][b][3] += bb.w; pin(acc[a][b]); }
+            for (int a = 0; a < TC::FM; ++a) { add8(acc[a][2 * bp], acc[a][2 * bp + 1], b0, b1); pin(acc[a][2 * bp]); pin(acc[a][2 * bp + 1]); }
         }
 #pragma unroll
         for (int a = 0; a < TC::FM; ++a) {
             const int m = m0w + a * 16 + lm;
             if (m >= M) continue;
 #pragma unroll
-            for (int b = 0; b < TC::FN; ++b) {
-                const int n = n0w + b * 16 + ln;
+            for (int bp = 0; bp < TC::FN / 2; ++bp) {
+                const int n = n0w + bp * 32 + l8;
                 if (n >= N) continue;
-                const float4 bb = make_float4(0.f, 0.f, 0.f, 0.f);
+                const f32x4 &x = acc[a][2 * bp], &y = acc[a][2 * bp + 1];
 #ifdef SKP_DEBUG_NOGELU
-                float v[4] = {acc[a][b][0] + bb.x, acc[a][b][1] + bb.y, acc[a][b][2] + bb.z, acc[a][b][3] + bb.w};
+                float v[8] = {x[0], x[1], x[2], x[3], y[0], y[1], y[2], y[3]};
 #else
-                float v[4] = {gelu_erf(acc[a][b][0] + bb.x), gelu_erf(acc[a][b][1] + bb.y),
-                              gelu_erf(acc[a][b][2] + bb.z), gelu_erf(acc[a][b][3] + bb.w)};
+                float v[8] = {gelu_erf(x[0]), gelu_erf(x[1]), gelu_erf(x[2]), gelu_erf(x[3]),
+                              gelu_erf(y[0]), gelu_erf(y[1]), gelu_erf(y[2]), gelu_erf(y[3])};
 #endif
 #ifdef SKP_DEBUG_NOSTORE
                 if (v[0] == 123.456f)
 #endif
-                store4_planes<T, NPL>(out + blk_off(m, n, ld), plane, v);
+                store8_planes<T, NPL>(out + blk_off(m, n, ld), plane, v);
             }
         }
     }
@@ -120,14 +132,16 @@ struct EpQKV {
     __device__ __forceinline__ bool unswapped(int n0) const { return n0 >= 2 * C; }
     template <class TC, bool SWAP>
     __device__ __forceinline__ void run(f32x4 (&acc)[TC::FM][TC::FN], int m0w, int n0w, int lane, int, int, char*, int M, int N, int) const {
-        const int l15 = lane & 15, l4 = (lane >> 4) * 4;
+        static_assert(TC::FN % 2 == 0, "fragment pairs");
+        const int l15 = lane & 15, l4 = (lane >> 4) * 4, l8 = (lane >> 4) * 8;
         if constexpr (SWAP) {
 #pragma unroll
-            for (int b = 0; b < TC::FN; ++b) {      // straight-line bias add first (see EpStoreF32)
-                const int n = n0w + b * 16 + l4;
-                const float4 bb = *reinterpret_cast<const float4*>(bias + (n < N ? n : 0));
+            for (int bp = 0; bp < TC::FN / 2; ++bp) {      // straight-line bias add first (see EpStorePlanes)
+                const int n = n0w + bp * 32 + l8;
+                const float* bsrc = bias + (n < N ? n : 0);
+                const float4 b0 = *reinterpret_cast<const float4*>(bsrc), b1 = *reinterpret_cast<const float4*>(bsrc + 4);
 #pragma unroll
-                for (int a = 0; a < TC::FM; ++a) { acc[a][b][0] += bb.x; acc[a][b][1] += bb.y; acc[a][b][2] += bb.z; acc[a][b][3] += bb.w; pin(acc[a][b]); }
+                for (int a = 0; a < TC::FM; ++a) { add8(acc[a][2 * bp], acc[a][2 * bp + 1], b0, b1); pin(acc[a][2 * bp]); pin(acc[a][2 * bp + 1]); }
             }
 #pragma unroll
             for (int a = 0; a < TC::FM; ++a) {
@@ -135,27 +149,23 @@ struct EpQKV {
                 if (m >= M) continue;
                 const int win = m / WIN_TOKENS, t = m - win * WIN_TOKENS;
 #pragma unroll
-                for (int b = 0; b < TC::FN; ++b) {
-                    const int n = n0w + b * 16 + l4;
+                for (int bp = 0; bp < TC::FN / 2; ++bp) {
+                    const int n = n0w + bp * 32 + l8;       // 8 consecutive d of one head (C % 32 == 0)
                     if (n >= N) continue;
                     const int which = n >= C ? 1 : 0;
                     const int c = n - which * C;
                     const int head = c >> 5, d = c & 31;
-                    const float4 bb = make_float4(0.f, 0.f, 0.f, 0.f);
                     const float s = which == 0 ? scale : 1.0f;
-                    const float v[4] = {(acc[a][b][0] + bb.x) * s, (acc[a][b][1] + bb.y) * s,
-                                        (acc[a][b][2] + bb.z) * s, (acc[a][b][3] + bb.w) * s};
-                    uint2 o[NPL];
-                    split4<T, NPL>(v, o);
+                    const f32x4 &x = acc[a][2 * bp], &y = acc[a][2 * bp + 1];
+                    const float v[8] = {x[0] * s, x[1] * s, x[2] * s, x[3] * s, y[0] * s, y[1] * s, y[2] * s, y[3] * s};
                     T* dst = (which == 0 ? q : k) + (((long long)win * heads + head) * WIN_TOKENS + t) * HEAD_DIM + d;
-#pragma unroll
-                    for (int p = 0; p < NPL; ++p) *reinterpret_cast<uint2*>(dst + p * plane) = o[p];
+                    store8_planes<T, NPL>(dst, plane, v);
                 }
             }
         } else {
 #pragma unroll
             for (int b = 0; b < TC::FN; ++b) {
-                const int n = n0w + b * 16 + l15;
+                const int n = perm8_col(n0w + b * 16 + l15);
                 const float bb = bias[n < N ? n : 0];
 #pragma unroll
                 for (int a = 0; a < TC::FM; ++a) { acc[a][b][0] += bb; acc[a][b][1] += bb; acc[a][b][2] += bb; acc[a][b][3] += bb; pin(acc[a][b]); }
@@ -167,12 +177,11 @@ struct EpQKV {
                 const int win = m / WIN_TOKENS, t = m - win * WIN_TOKENS;
 #pragma unroll
                 for (int b = 0; b < TC::FN; ++b) {
-                    const int n = n0w + b * 16 + l15;
+                    const int n = perm8_col(n0w + b * 16 + l15);
                     if (n >= N) continue;
                     const int c = n - 2 * C;
                     const int head = c >> 5, d = c & 31;
-                    const float bb = 0.f;
-                    const float v[4] = {acc[a][b][0] + bb, acc[a][b][1] + bb, acc[a][b][2] + bb, acc[a][b][3] + bb};
+                    const float v[4] = {acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]};
                     uint2 o[NPL];
                     split4<T, NPL>(v, o);
                     T* dst = vt + (((long long)win * heads + head) * HEAD_DIM + d) * WIN_TOKENS + t;
@@ -202,31 +211,35 @@ struct RowMapPixelShuffle {     // UpSample: (z,h,w) of the coarse grid, quadran
         return ((long long)z * H1 + hf) * W1 + wf;
     }
 };
+struct f32x8 { float4 a, b; };
 template <class T>
-struct SinkResidual {           // xs[dest][c..c+3] += y on the hi/lo planes of the residual stream
+struct SinkResidual {           // xs[dest][c..c+7] += y on the hi/lo planes of the residual stream (16-byte loads / stores)
     T* xs;
     long long plane;
     static constexpr bool kLoads = true;
-    __device__ __forceinline__ float4 load(long long row, int ld, int c) const {
-        typedef T t4 __attribute__((ext_vector_type(4)));
+    __device__ __forceinline__ f32x8 load(long long row, int ld, int c) const {
         const T* p = xs + blk_off(row, c, ld);
-        const t4 h = __builtin_bit_cast(t4, *reinterpret_cast<const uint2*>(p));
-        const t4 l = __builtin_bit_cast(t4, *reinterpret_cast<const uint2*>(p + plane));
-        return make_float4((float)h[0] + (float)l[0], (float)h[1] + (float)l[1], (float)h[2] + (float)l[2], (float)h[3] + (float)l[3]);
+        const typename OpT<T>::v8 h = as_v8<T>(*reinterpret_cast<const uint4*>(p));
+        const typename OpT<T>::v8 l = as_v8<T>(*reinterpret_cast<const uint4*>(p + plane));
+        f32x8 o;
+        o.a = make_float4((float)h[0] + (float)l[0], (float)h[1] + (float)l[1], (float)h[2] + (float)l[2], (float)h[3] + (float)l[3]);
+        o.b = make_float4((float)h[4] + (float)l[4], (float)h[5] + (float)l[5], (float)h[6] + (float)l[6], (float)h[7] + (float)l[7]);
+        return o;
     }
-    __device__ __forceinline__ void put(long long row, int ld, int c, const float (&y)[4], const float4& old) const {
-        const float v[4] = {old.x + y[0], old.y + y[1], old.z + y[2], old.w + y[3]};
-        store4_planes<T, 2>(xs + blk_off(row, c, ld), plane, v);
+    __device__ __forceinline__ void put(long long row, int ld, int c, const float (&y)[8], const f32x8& old) const {
+        const float v[8] = {old.a.x + y[0], old.a.y + y[1], old.a.z + y[2], old.a.w + y[3],
+                            old.b.x + y[4], old.b.y + y[5], old.b.z + y[6], old.b.w + y[7]};
+        store8_planes<T, 2>(xs + blk_off(row, c, ld), plane, v);
     }
 };
 template <class T, int NPL>
-struct SinkStore {              // out[dest][c..c+3] = y as hi/lo planes
+struct SinkStore {              // out[dest][c..c+7] = y as hi/lo planes
     T* out;
     long long plane;
     static constexpr bool kLoads = false;
-    __device__ __forceinline__ float4 load(long long, int, int) const { return make_float4(0.f, 0.f, 0.f, 0.f); }
-    __device__ __forceinline__ void put(long long row, int ld, int c, const float (&y)[4], const float4&) const {
-        store4_planes<T, NPL>(out + blk_off(row, c, ld), plane, y);
+    __device__ __forceinline__ f32x8 load(long long, int, int) const { return f32x8{}; }
+    __device__ __forceinline__ void put(long long row, int ld, int c, const float (&y)[8], const f32x8&) const {
+        store8_planes<T, NPL>(out + blk_off(row, c, ld), plane, y);
     }
 };
 
@@ -250,18 +263,19 @@ struct EpLayerNorm {
     float eps;
     template <class TC, bool SWAP>
     __device__ __forceinline__ void run(f32x4 (&acc)[TC::FM][TC::FN], int m0w, int n0w, int lane, int wm, int wn, char* smem, int M, int N, int ntile) const {
-        static_assert(SWAP, "swapped order only");
-        constexpr int FM = TC::FM, FN = TC::FN, WN = TC::WN, BM = TC::BM, BN = TC::BN;
-        const int l15 = lane & 15, l4 = (lane >> 4) * 4;
+        static_assert(SWAP && TC::FN % 2 == 0, "swapped order, fragment pairs");
+        constexpr int FM = TC::FM, FN = TC::FN, FP = TC::FN / 2, WN = TC::WN, BM = TC::BM, BN = TC::BN;
+        const int l15 = lane & 15, l8 = (lane >> 4) * 8;
         const int nloc0 = n0w - ntile * BN;          // column of this wave inside the LN group
         float* red = reinterpret_cast<float*>(smem);  // [2][BM][WN]
         const float* tab = reinterpret_cast<const float*>(smem + kEpiReduceBytes);   // gamma | beta | bias (init())
         static_assert(3 * BN * 4 <= kEpiTableBytes && 2 * BM * WN * 4 <= kEpiReduceBytes, "epilogue LDS scratch");
 #pragma unroll
-        for (int b = 0; b < FN; ++b) {
-            const float4 bb = *reinterpret_cast<const float4*>(tab + 2 * BN + nloc0 + b * 16 + l4);
+        for (int bp = 0; bp < FP; ++bp) {
+            const float* bsrc = tab + 2 * BN + nloc0 + bp * 32 + l8;
+            const float4 b0 = *reinterpret_cast<const float4*>(bsrc), b1 = *reinterpret_cast<const float4*>(bsrc + 4);
 #pragma unroll
-            for (int a = 0; a < FM; ++a) { acc[a][b][0] += bb.x; acc[a][b][1] += bb.y; acc[a][b][2] += bb.z; acc[a][b][3] += bb.w; }
+            for (int a = 0; a < FM; ++a) add8(acc[a][2 * bp], acc[a][2 * bp + 1], b0, b1);
         }
         // destination rows first (the table lookups overlap the LayerNorm reductions below); rows that do not exist
         // (window padding / crop / M tail) are redirected to row 0 for the loads and skipped for the stores
@@ -278,12 +292,12 @@ struct EpLayerNorm {
         // reductions); the last one is issued after group 0 has been stored, when its accumulators are dead --
         // all FM*FN loads at once spill next to the FM*FN accumulators
         constexpr int PRE = FM < 3 ? FM : 3;
-        float4 old[Sink::kLoads ? FM : 1][Sink::kLoads ? FN : 1];
+        f32x8 old[Sink::kLoads ? FM : 1][Sink::kLoads ? FP : 1];
         if constexpr (Sink::kLoads) {
 #pragma unroll
             for (int a = 0; a < PRE; ++a)
 #pragma unroll
-                for (int b = 0; b < FN; ++b) old[a][b] = sink.load(drow[a], BN, nloc0 + b * 16 + l4);
+                for (int bp = 0; bp < FP; ++bp) old[a][bp] = sink.load(drow[a], BN, nloc0 + bp * 32 + l8);
         }
         float mean[FM], rstd[FM];
         // pass 1: mean
@@ -329,18 +343,20 @@ struct EpLayerNorm {
 #pragma unroll
         for (int a = 0; a < FM; ++a) {
 #pragma unroll
-            for (int b = 0; b < FN; ++b) {
-                const int c = nloc0 + b * 16 + l4;
-                const float4 g = *reinterpret_cast<const float4*>(tab + c);
-                const float4 be = *reinterpret_cast<const float4*>(tab + BN + c);
-                const float y[4] = {(acc[a][b][0] - mean[a]) * rstd[a] * g.x + be.x, (acc[a][b][1] - mean[a]) * rstd[a] * g.y + be.y,
-                                    (acc[a][b][2] - mean[a]) * rstd[a] * g.z + be.z, (acc[a][b][3] - mean[a]) * rstd[a] * g.w + be.w};
-                if (ok[a]) sink.put(drow[a], BN, c, y, Sink::kLoads ? old[a][b] : old[0][0]);
+            for (int bp = 0; bp < FP; ++bp) {
+                const int c = nloc0 + bp * 32 + l8;
+                const float4 g0 = *reinterpret_cast<const float4*>(tab + c), g1 = *reinterpret_cast<const float4*>(tab + c + 4);
+                const float4 e0 = *reinterpret_cast<const float4*>(tab + BN + c), e1 = *reinterpret_cast<const float4*>(tab + BN + c + 4);
+                const f32x4 &x = acc[a][2 * bp], &z = acc[a][2 * bp + 1];
+                const float mu = mean[a], rs = rstd[a];
+                const float y[8] = {(x[0] - mu) * rs * g0.x + e0.x, (x[1] - mu) * rs * g0.y + e0.y, (x[2] - mu) * rs * g0.z + e0.z, (x[3] - mu) * rs * g0.w + e0.w,
+                                    (z[0] - mu) * rs * g1.x + e1.x, (z[1] - mu) * rs * g1.y + e1.y, (z[2] - mu) * rs * g1.z + e1.z, (z[3] - mu) * rs * g1.w + e1.w};
+                if (ok[a]) sink.put(drow[a], BN, c, y, Sink::kLoads ? old[a][bp] : old[0][0]);
             }
             if constexpr (Sink::kLoads) {
                 if (a + PRE < FM) {
 #pragma unroll
-                    for (int b = 0; b < FN; ++b) old[a + PRE][b] = sink.load(drow[a + PRE], BN, nloc0 + b * 16 + l4);
+                    for (int bp = 0; bp < FP; ++bp) old[a + PRE][bp] = sink.load(drow[a + PRE], BN, nloc0 + bp * 32 + l8);
                 }
             }
         }

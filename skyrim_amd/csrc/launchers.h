@@ -52,6 +52,7 @@ struct Work {
     long long ao_plane, hid_plane, u_plane;
     const T* zrow;           // zeros (padding rows of the DMA GEMMs)
     int hid16;               // 1: MLP hidden stored as ONE fp16 plane (hid reinterpreted as f16*), fc2 runs 2-term fp16
+    int qkv_a1;              // 1 (fp16 planes only): QKV reads only the hi plane of the stream (2 MFMA terms)
     float2* stats;
 };
 
@@ -87,7 +88,7 @@ template <class T> hipError_t merge_planes(const T* planes, long long plane, flo
 
 // prepare-time helpers (aux.hip)
 template <class T, int NW>
-hipError_t prep_weight(const float* src, T* dst, long long plane, int N, int K, int ldd, long long sn, long long sk, int blocked, hipStream_t);
+hipError_t prep_weight(const float* src, T* dst, long long plane, int N, int K, int ldd, long long sn, long long sk, int blocked, int perm, hipStream_t);
 hipError_t prep_bias_expand(const float* table, f16* out, int types, int heads, int nH, int roll, hipStream_t);
 hipError_t prep_window_index(int* idx, int Z, int H, int W, int Hp, int top, int roll, hipStream_t);
 hipError_t prep_reciprocal(const float* src, float* dst, int n, hipStream_t);

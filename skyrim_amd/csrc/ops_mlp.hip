@@ -1,4 +1,5 @@
 // MLP half of an EarthSpecificBlock:  x += LayerNorm(norm2)( fc2( GELU( fc1(x) ) ) ), in place.
+#include <type_traits>
 #include "tiles.h"
 
 namespace skp {
@@ -38,7 +39,10 @@ hipError_t op_fc2(const Geom& g, const BlockW<typename P::T>& b, int res, typena
             DmaArgs<P2, APlanes<f16>, EP> a;
             a.as = APlanes<f16>{reinterpret_cast<const f16*>(wk.hid), 0, 4 * C, nullptr, g.ntok[res]};
             a.ep = EP{RowMapIndexed{nullptr}, SinkResidual<T>{Xs, wk.xs_plane[res]}, b.fc2_b, b.n2_g, b.n2_b, 1e-5f};
-            a.W = b.fc2h.w; a.w_plane = b.fc2h.plane; a.ldw = b.fc2h.ldw; a.zrow = reinterpret_cast<const f16*>(wk.zrow);
+            // fp16 hi/lo weights: the engine's own fc2 planes when T is fp16, the extra fc2h copy in the bf16 engine
+            if constexpr (std::is_same<T, f16>::value) { a.W = b.fc2.w; a.w_plane = b.fc2.plane; a.ldw = b.fc2.ldw; }
+            else { a.W = b.fc2h.w; a.w_plane = b.fc2h.plane; a.ldw = b.fc2h.ldw; }
+            a.zrow = reinterpret_cast<const f16*>(wk.zrow);
             a.M = g.ntok[res]; a.N = C; a.K = 4 * C;
             if (res == 0) return launch_gemm_dma<P2, typename Tiles<P2>::D192>(a, s);
             return launch_gemm_dma<P2, typename Tiles<P2>::D384>(a, s);
@@ -55,7 +59,9 @@ hipError_t op_fc2(const Geom& g, const BlockW<typename P::T>& b, int res, typena
 
 template hipError_t op_fc1<PrecBF16x3>(const Geom&, const BlockW<bf16>&, int, const bf16*, const Work<PrecBF16x3>&, hipStream_t);
 template hipError_t op_fc1<PrecF16>(const Geom&, const BlockW<f16>&, int, const f16*, const Work<PrecF16>&, hipStream_t);
+template hipError_t op_fc1<PrecF16x3>(const Geom&, const BlockW<f16>&, int, const f16*, const Work<PrecF16x3>&, hipStream_t);
 template hipError_t op_fc2<PrecBF16x3>(const Geom&, const BlockW<bf16>&, int, bf16*, const Work<PrecBF16x3>&, hipStream_t);
 template hipError_t op_fc2<PrecF16>(const Geom&, const BlockW<f16>&, int, f16*, const Work<PrecF16>&, hipStream_t);
+template hipError_t op_fc2<PrecF16x3>(const Geom&, const BlockW<f16>&, int, f16*, const Work<PrecF16x3>&, hipStream_t);
 
 }  // namespace skp

@@ -17,7 +17,14 @@ from .spec import PanguGeometry
 PREC_BF16X3 = 0
 PREC_F16 = 1
 PREC_BF16X3_H16 = 2
-PRECISIONS = {"bf16x3": PREC_BF16X3, "f16": PREC_F16, "bf16x3h": PREC_BF16X3_H16}
+PREC_F16X3 = 3
+PREC_F16X3_Q = 4
+PREC_F16X3_QH = 5
+PRECISIONS = {"bf16x3": PREC_BF16X3, "f16": PREC_F16, "bf16x3h": PREC_BF16X3_H16,
+              "f16x3": PREC_F16X3, "f16x3q": PREC_F16X3_Q, "f16x3qh": PREC_F16X3_QH}
+# default: fp16 hi/lo planes (22-bit operands), 3 MFMA terms, QKV 2 terms; ~1e-4 per-channel error per step.
+# "bf16x3" is the wide-range alternative (activations beyond fp16's 65504).
+DEFAULT_PRECISION = "f16x3q"
 
 _LIB_PATH = Path(__file__).resolve().parent.parent / "lib" / "libskyrim_pangu.so"
 
@@ -90,14 +97,14 @@ def _check(code: int, what: str):
         raise RuntimeError(f"{what} failed: {msg} (code {code})")
 
 
-def query_sizes(geom: PanguGeometry, precision: str = "bf16x3") -> SkSizes:
+def query_sizes(geom: PanguGeometry, precision: str = DEFAULT_PRECISION) -> SkSizes:
     cfg = SkConfig(geom.n_lat, geom.n_lon, PRECISIONS[precision])
     out = SkSizes()
     _check(load_library().skpangu_query_sizes(ctypes.byref(cfg), ctypes.byref(out)), "skpangu_query_sizes")
     return out
 
 
-def param_table(geom: PanguGeometry, precision: str = "bf16x3") -> list[tuple[str, int, tuple[int, ...]]]:
+def param_table(geom: PanguGeometry, precision: str = DEFAULT_PRECISION) -> list[tuple[str, int, tuple[int, ...]]]:
     """(name, element offset, shape) of every master parameter, as the library lays them out."""
     lib = load_library()
     cfg = SkConfig(geom.n_lat, geom.n_lon, PRECISIONS[precision])
@@ -115,7 +122,7 @@ def param_table(geom: PanguGeometry, precision: str = "bf16x3") -> list[tuple[st
 class PanguEngine:
     """Device-resident Pangu 6-h step.  ``step`` maps a (69, n_lat, n_lon) fp32 CUDA tensor to the next state."""
 
-    def __init__(self, geom: PanguGeometry | None = None, precision: str = "bf16x3", device: str | torch.device = "cuda:0"):
+    def __init__(self, geom: PanguGeometry | None = None, precision: str = DEFAULT_PRECISION, device: str | torch.device = "cuda:0"):
         self.lib = load_library()
         if not torch.cuda.is_available():
             raise RuntimeError("PanguEngine needs a ROCm GPU (gfx950); there is no CPU fallback")

@@ -20,7 +20,7 @@ from dataclasses import dataclass
 
 import torch
 
-from .engine import PanguEngine
+from .engine import DEFAULT_PRECISION, PanguEngine
 from .spec import CHANNELS, PanguGeometry, init_synthetic
 
 
@@ -40,7 +40,7 @@ class PanguTimeLoop:
     in_channel_names = list(CHANNELS)
     out_channel_names = list(CHANNELS)
 
-    def __init__(self, params: dict | None = None, geom: PanguGeometry | None = None, precision: str = "bf16x3",
+    def __init__(self, params: dict | None = None, geom: PanguGeometry | None = None, precision: str = DEFAULT_PRECISION,
                  device: str | torch.device = "cuda:0", seed: int = 0, params24: dict | None = None):
         """``params``: 6-h network (default: ``SKYRIM_PANGU_WEIGHTS`` state dict or seeded random init).
         ``params24`` (optional, or ``SKYRIM_PANGU_WEIGHTS_24``): the 24-h network; when present a multi-step

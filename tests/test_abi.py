@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     assert lib.skpangu_abi_version() == 1
 
 
-@pytest.mark.parametrize("prec", ["bf16x3", "f16"])
+@pytest.mark.parametrize("prec", ["bf16x3", "f16", "f16x3q", "f16x3qh"])
 @pytest.mark.parametrize("grid", [(49, 192), (721, 1440)])
 def test_param_table_matches_host_spec(grid, prec):
     g = PanguGeometry(*grid)
@@ -42,7 +42,7 @@ def test_param_table_matches_host_spec(grid, prec):
 
 
 def test_sizes_full_grid_fit_one_gpu():
-    s = E.query_sizes(PanguGeometry(721, 1440), "bf16x3")
+    s = E.query_sizes(PanguGeometry(721, 1440))
     assert s.prepared_bytes + s.workspace_bytes < 16 * 2 ** 30      # a few GB of the 288 GB
 
 

@@ -87,10 +87,9 @@ def run(prec, g, params, x):
     eng = PanguEngine(g, prec)
     eng.load_params(params)
     dev = eng.device
-    npl = 2 if prec.startswith("bf16x3") else 1
+    npl = 1 if prec == "f16" else 2
     t16 = torch.bfloat16 if prec.startswith("bf16x3") else torch.float16
-    hnpl, ht16 = (npl, t16) if prec == "bf16x3" else (1, torch.float16)
-    act = torch.float32 if prec == "bf16x3" else torch.float16
+    hnpl, ht16 = (1, torch.float16) if prec.endswith("h") else (npl, t16)
 
     xd = x.to(dev)
     # window tables
