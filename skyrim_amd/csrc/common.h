@@ -138,18 +138,37 @@ __device__ __forceinline__ int lds_off(int row, int slot) {
     else                    return row * 64 + ((slot ^ ((row >> 1) & 3)) << 4);
 }
 
-// erf-GELU.  erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, i.e. fp32 round-off class) in ~14 VALU
-// instructions instead of libm erff's branchy ~50: the fc1 epilogue evaluates 2e8 of these per launch.
-__device__ __forceinline__ float gelu_erf(float x) {
-    const float ax = fabsf(x) * 0.70710678118654752440f;
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));   // v_rcp_f32 (1 ulp), not the IEEE division sequence
-    float p = fmaf(t, 1.061405429f, -1.453152027f);
-    p = fmaf(t, p, 1.421413741f);
-    p = fmaf(t, p, -0.284496736f);
-    p = fmaf(t, p, 0.254829592f);
-    const float e = __builtin_amdgcn_exp2f(ax * ax * -1.4426950408889634f);
-    const float erf_abs = fmaf(-p * t, e, 1.0f);
-    return 0.5f * x * (1.0f + copysignf(erf_abs, x));
+// erf-GELU = 0.5 x erfc(-x/sqrt2) with erfc(u/sqrt2) = 2^Q(u) for u >= 0 (Q: degree-8 fit of log2 erfc, tools/gelu_fit.py)
+// and erfc(-z) = 2 - erfc(z).  Max abs error 3.8e-7 (fp32 round-off class; libm-erf GELU differs by the same amount),
+// ONE transcendental (v_exp_f32) and 8 FMAs: ~11 VALU issue slots per element where A&S 7.1.26 (rcp + exp) took ~20 and
+// libm erff ~50 -- the fc1 epilogue evaluates 2e8 of these per launch and is VALU-bound.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// two elements at a time so that the polynomial runs on v_pk_fma_f32 (coefficients splat in registers)
+__device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
+    f32x2 a;
+    a.x = __builtin_amdgcn_fmed3f(__builtin_fabsf(x.x), 0.f, 5.9396970f);
+    a.y = __builtin_amdgcn_fmed3f(__builtin_fabsf(x.y), 0.f, 5.9396970f);
+    f32x2 p = __builtin_elementwise_fma(a, (f32x2)(-6.177511978e-07f), (f32x2)(1.091520153e-05f));
+    p = __builtin_elementwise_fma(a, p, (f32x2)(-4.273382365e-05f));
+    p = __builtin_elementwise_fma(a, p, (f32x2)(-4.982745158e-04f));
+    p = __builtin_elementwise_fma(a, p, (f32x2)(7.545167115e-03f));
+    p = __builtin_elementwise_fma(a, p, (f32x2)(-5.282834917e-02f));
+    p = __builtin_elementwise_fma(a, p, (f32x2)(-4.591012597e-01f));
+    p = __builtin_elementwise_fma(a, p, (f32x2)(-1.151117682e+00f));
+    p = p * a;
+    f32x2 t;                                  // erf(|x|/sqrt2) = 1 - erfc
+    t.x = 1.0f - __builtin_amdgcn_exp2f(p.x);
+    t.y = 1.0f - __builtin_amdgcn_exp2f(p.y);
+    t.x = __builtin_copysignf(t.x, x.x);
+    t.y = __builtin_copysignf(t.y, x.y);
+    return ((f32x2)(0.5f) * x) * ((f32x2)(1.0f) + t);
+}
+__device__ __forceinline__ float gelu_erf(float x) { return gelu_erf2((f32x2){x, x}).x; }
+// GELU of the 8 consecutive columns held in a fragment pair
+__device__ __forceinline__ void gelu_erf8(const f32x4& lo, const f32x4& hi, float (&v)[8]) {
+    const f32x2 r0 = gelu_erf2((f32x2){lo[0], lo[1]}), r1 = gelu_erf2((f32x2){lo[2], lo[3]});
+    const f32x2 r2 = gelu_erf2((f32x2){hi[0], hi[1]}), r3 = gelu_erf2((f32x2){hi[2], hi[3]});
+    v[0] = r0.x; v[1] = r0.y; v[2] = r1.x; v[3] = r1.y; v[4] = r2.x; v[5] = r2.y; v[6] = r3.x; v[7] = r3.y;
 }
 
 constexpr int WIN_TOKENS = 144;

@@ -105,8 +105,8 @@ struct EpGelu {
 #ifdef SKP_DEBUG_NOGELU
                 float v[8] = {x[0], x[1], x[2], x[3], y[0], y[1], y[2], y[3]};
 #else
-                float v[8] = {gelu_erf(x[0]), gelu_erf(x[1]), gelu_erf(x[2]), gelu_erf(x[3]),
-                              gelu_erf(y[0]), gelu_erf(y[1]), gelu_erf(y[2]), gelu_erf(y[3])};
+                float v[8];
+                gelu_erf8(x, y, v);
 #endif
 #ifdef SKP_DEBUG_NOSTORE
                 if (v[0] == 123.456f)
