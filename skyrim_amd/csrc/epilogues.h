@@ -115,30 +115,6 @@ struct EpGelu {
             }
         }
     }
-    // ping-pong kernel (gemm_pp.h): the same epilogue cut into a straight-line pre-pass and FM x FN/2 store units
-    template <class TC, bool SWAP>
-    __device__ __forceinline__ void pp_begin(f32x4 (&acc)[TC::FM][TC::FN], int, int n0w, int lane, int, int N) const {
-        static_assert(SWAP && TC::FN % 2 == 0, "swapped order, fragment pairs");
-        const int l8 = (lane >> 4) * 8;
-#pragma unroll
-        for (int bp = 0; bp < TC::FN / 2; ++bp) {
-            const int n = n0w + bp * 32 + l8;
-            const float* bsrc = bias + (n < N ? n : 0);
-            const float4 b0 = *reinterpret_cast<const float4*>(bsrc), b1 = *reinterpret_cast<const float4*>(bsrc + 4);
-#pragma unroll
-            for (int a = 0; a < TC::FM; ++a) { add8(acc[a][2 * bp], acc[a][2 * bp + 1], b0, b1); pin(acc[a][2 * bp]); pin(acc[a][2 * bp + 1]); }
-        }
-    }
-    template <class TC, bool SWAP, int A, int BP>
-    __device__ __forceinline__ void pp_unit(f32x4 (&acc)[TC::FM][TC::FN], int m0w, int n0w, int lane, int M, int N) const {
-        const int m = m0w + A * 16 + (lane & 15), n = n0w + BP * 32 + (lane >> 4) * 8;
-        float v[8];
-        gelu_erf8(acc[A][2 * BP], acc[A][2 * BP + 1], v);
-#ifdef SKP_DEBUG_NOSTORE
-        if (v[0] == 123.456f)
-#endif
-        if (m < M && n < N) store8_planes<T, NPL>(out + blk_off(m, n, ld), plane, v);
-    }
 };
 
 // ---- QKV head split: Q (scaled), K as [win][head][144][32]; V transposed [win][head][32][144] ---- //
@@ -212,63 +188,6 @@ struct EpQKV {
 #pragma unroll
                     for (int p = 0; p < NPL; ++p) *reinterpret_cast<uint2*>(dst + p * plane) = o[p];
                 }
-            }
-        }
-    }
-    // ping-pong kernel (gemm_pp.h): pre-pass + store units, both operand orders
-    template <class TC, bool SWAP>
-    __device__ __forceinline__ void pp_begin(f32x4 (&acc)[TC::FM][TC::FN], int, int n0w, int lane, int, int N) const {
-        const int l15 = lane & 15, l8 = (lane >> 4) * 8;
-        if constexpr (SWAP) {
-#pragma unroll
-            for (int bp = 0; bp < TC::FN / 2; ++bp) {
-                const int n = n0w + bp * 32 + l8;
-                const float* bsrc = bias + (n < N ? n : 0);
-                const float4 b0 = *reinterpret_cast<const float4*>(bsrc), b1 = *reinterpret_cast<const float4*>(bsrc + 4);
-#pragma unroll
-                for (int a = 0; a < TC::FM; ++a) { add8(acc[a][2 * bp], acc[a][2 * bp + 1], b0, b1); pin(acc[a][2 * bp]); pin(acc[a][2 * bp + 1]); }
-            }
-        } else {
-#pragma unroll
-            for (int b = 0; b < TC::FN; ++b) {
-                const int n = perm8_col(n0w + b * 16 + l15);
-                const float bb = bias[n < N ? n : 0];
-#pragma unroll
-                for (int a = 0; a < TC::FM; ++a) { acc[a][b][0] += bb; acc[a][b][1] += bb; acc[a][b][2] += bb; acc[a][b][3] += bb; pin(acc[a][b]); }
-            }
-        }
-    }
-    template <class TC, bool SWAP, int A, int BP>
-    __device__ __forceinline__ void pp_unit(f32x4 (&acc)[TC::FM][TC::FN], int m0w, int n0w, int lane, int M, int N) const {
-        const int l15 = lane & 15, l4 = (lane >> 4) * 4;
-        if constexpr (SWAP) {
-            const int m = m0w + A * 16 + l15, n = n0w + BP * 32 + 2 * l4;
-            if (m >= M || n >= N) return;
-            const int win = m / WIN_TOKENS, t = m - win * WIN_TOKENS;
-            const int which = n >= C ? 1 : 0;
-            const int c = n - which * C;
-            const int head = c >> 5, d = c & 31;
-            const float s = which == 0 ? scale : 1.0f;
-            const f32x4 &x = acc[A][2 * BP], &y = acc[A][2 * BP + 1];
-            const float v[8] = {x[0] * s, x[1] * s, x[2] * s, x[3] * s, y[0] * s, y[1] * s, y[2] * s, y[3] * s};
-            T* dst = (which == 0 ? q : k) + (((long long)win * heads + head) * WIN_TOKENS + t) * HEAD_DIM + d;
-            store8_planes<T, NPL>(dst, plane, v);
-        } else {
-            const int m = m0w + A * 16 + l4;
-            if (m >= M) return;
-            const int win = m / WIN_TOKENS, t = m - win * WIN_TOKENS;
-#pragma unroll
-            for (int b = 2 * BP; b < 2 * BP + 2; ++b) {
-                const int n = perm8_col(n0w + b * 16 + l15);
-                if (n >= N) continue;
-                const int c = n - 2 * C;
-                const int head = c >> 5, d = c & 31;
-                const float v[4] = {acc[A][b][0], acc[A][b][1], acc[A][b][2], acc[A][b][3]};
-                uint2 o[NPL];
-                split4<T, NPL>(v, o);
-                T* dst = vt + (((long long)win * heads + head) * HEAD_DIM + d) * WIN_TOKENS + t;
-#pragma unroll
-                for (int p = 0; p < NPL; ++p) *reinterpret_cast<uint2*>(dst + p * plane) = o[p];
             }
         }
     }

@@ -75,7 +75,6 @@ struct DmaArgs {
     const typename P::T* zrow;   // >= max K zeros
     int M, N, K;                 // K % BK == 0
     int nM, nN;                  // tile counts
-    int pp_delay;                // gemm_pp.h: EPI-role delay after each barrier (units of 64 clocks) so the MAIN group's DMA queues first
 };
 
 template <class P, class TC>

@@ -18,7 +18,7 @@ hipError_t op_qkv(const Geom& g, const BlockW<typename P::T>& b, const int* widx
             a.ep = EpQKV<f16, 1>{wk.q, wk.k, wk.vt, wk.qkv_plane, b.qkv_b, C, heads, 0.17677669529663687f};
             a.W = b.qkv.w; a.w_plane = b.qkv.plane; a.ldw = b.qkv.ldw; a.zrow = wk.zrow;
             a.M = g.mwin[res]; a.N = 3 * C; a.K = C;
-            return launch_store_heavy<P2, typename Tiles<P2>::D192>(a, s);
+            return launch_gemm_dma<P2, typename Tiles<P2>::D192>(a, s);
         }
     }
     DmaArgs<P, APlanes<T>, EpQKV<f16, 1>> a;
@@ -26,7 +26,7 @@ hipError_t op_qkv(const Geom& g, const BlockW<typename P::T>& b, const int* widx
     a.ep = EpQKV<f16, 1>{wk.q, wk.k, wk.vt, wk.qkv_plane, b.qkv_b, C, heads, 0.17677669529663687f};
     a.W = b.qkv.w; a.w_plane = b.qkv.plane; a.ldw = b.qkv.ldw; a.zrow = wk.zrow;
     a.M = g.mwin[res]; a.N = 3 * C; a.K = C;
-    return launch_store_heavy<P, typename Tiles<P>::D192>(a, s);
+    return launch_gemm_dma<P, typename Tiles<P>::D192>(a, s);
 }
 
 template <class P>

@@ -17,7 +17,7 @@ hipError_t op_fc1(const Geom& g, const BlockW<typename P::T>& b, int res, const 
             a.ep = EPH{reinterpret_cast<f16*>(wk.hid), 0, b.fc1_b, 4 * C};
             a.W = b.fc1.w; a.w_plane = b.fc1.plane; a.ldw = b.fc1.ldw; a.zrow = wk.zrow;
             a.M = g.ntok[res]; a.N = 4 * C; a.K = C;
-            return launch_store_heavy<P, typename Tiles<P>::D192>(a, s);
+            return launch_gemm_dma<P, typename Tiles<P>::D192>(a, s);
         }
     }
     DmaArgs<P, APlanes<T>, EP> a;
@@ -25,7 +25,7 @@ hipError_t op_fc1(const Geom& g, const BlockW<typename P::T>& b, int res, const 
     a.ep = EP{wk.hid, wk.hid_plane, b.fc1_b, 4 * C};
     a.W = b.fc1.w; a.w_plane = b.fc1.plane; a.ldw = b.fc1.ldw; a.zrow = wk.zrow;
     a.M = g.ntok[res]; a.N = 4 * C; a.K = C;
-    return launch_store_heavy<P, typename Tiles<P>::D192>(a, s);
+    return launch_gemm_dma<P, typename Tiles<P>::D192>(a, s);
 }
 
 template <class P>

@@ -3,7 +3,6 @@
 #pragma once
 #include "gemm.h"
 #include "gemm_dma.h"
-#include "gemm_pp.h"
 #include "loaders.h"
 #include "epilogues.h"
 #include "launchers.h"
@@ -23,18 +22,6 @@ struct Tiles {
 };
 
 template <class P> constexpr int planes_of() { return P::NA > P::NW ? P::NA : P::NW; }
-
-// store-heavy stages (fc1, QKV): ping-pong kernel (gemm_pp.h); SKP_PP=0 in the environment selects gemm_dma.h's kernel (A/B runs)
-inline bool use_pingpong() { static const bool on = !(getenv("SKP_PP") && atoi(getenv("SKP_PP")) == 0); return on; }
-template <class P, class TCfallback, class AS, class EP>
-inline hipError_t launch_store_heavy(const DmaArgs<P, AS, EP>& a, hipStream_t s) {
-    static const bool qkv_too = getenv("SKP_PP_QKV") && atoi(getenv("SKP_PP_QKV")) != 0;
-    if (use_pingpong() && a.N % PPTile::BN == 0 && (!EP::kDualOrder || qkv_too)) {
-        if (a.K == 192) return launch_gemm_pp<P, 6>(a, s);
-        if (a.K == 384) return launch_gemm_pp<P, 12>(a, s);
-    }
-    return launch_gemm_dma<P, TCfallback>(a, s);
-}
 
 #define SKP_CHECK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return e_; } while (0)
 
