@@ -34,6 +34,20 @@ class Grid:
         return (len(self.lat), len(self.lon))
 
 
+def _load_weights(path: str, geom: PanguGeometry) -> dict:
+    """A torch state dict (``.pt``) keyed by ``spec.param_spec`` names, or the reference's own weight format: an ONNX
+    file (``pangu_weather_6.onnx`` / ``_24.onnx``) read by ``onnx_weights.convert``; ``<path>.map.json`` next to it may
+    hold an explicit {"mapping": ..., "extra": ...} when the automatic slot mapping reports unresolved slots."""
+    if str(path).endswith(".onnx"):
+        import json
+        from . import onnx_weights
+        side = str(path) + ".map.json"
+        cfg = json.load(open(side)) if os.path.exists(side) else {}
+        arrays = onnx_weights.convert(path, geom, cfg.get("mapping"), cfg.get("extra"))
+        return {k: torch.from_numpy(v) for k, v in arrays.items()}
+    return torch.load(path, map_location="cpu")
+
+
 class PanguTimeLoop:
     n_history_levels = 1
     time_step = datetime.timedelta(hours=6)
@@ -51,10 +65,10 @@ class PanguTimeLoop:
         self.engine = PanguEngine(self.geom, precision, device)
         if params is None:
             path = os.environ.get("SKYRIM_PANGU_WEIGHTS")
-            params = torch.load(path, map_location="cpu") if path else init_synthetic(self.geom, seed)
+            params = _load_weights(path, self.geom) if path else init_synthetic(self.geom, seed)
         self.engine.load_params(params)
         if params24 is None and os.environ.get("SKYRIM_PANGU_WEIGHTS_24"):
-            params24 = torch.load(os.environ["SKYRIM_PANGU_WEIGHTS_24"], map_location="cpu")
+            params24 = _load_weights(os.environ["SKYRIM_PANGU_WEIGHTS_24"], self.geom)
         self.engine24 = None
         if params24 is not None:
             self.engine24 = PanguEngine(self.geom, precision, device)
