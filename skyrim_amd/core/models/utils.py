@@ -12,6 +12,9 @@ from ...datasource import get_initial_condition_for_model
 from ...labeled import DataArray, open_dataarray
 
 
+_PINNED_LIMIT = 24 << 30     # bytes of page-locked host memory run_basic_inference may take for its result
+
+
 def run_basic_inference(model, n: int, data_source: Any, time: datetime, x=None):
     """Run a basic inference: returns DataArray(time = n + 1, channel, lat, lon); entry 0 is the state at ``time``."""
     if x is None:
@@ -22,15 +25,31 @@ def run_basic_inference(model, n: int, data_source: Any, time: datetime, x=None)
         x = torch.as_tensor(np.asarray(x.values[-model.n_history_levels:]), dtype=torch.float32).to(model.device)
         x = x.unsqueeze(0)
 
-    arrays, times = [], []
+    # The reference copies every yielded state to the host synchronously (`.cpu().numpy()`, utils.py:36): 286 MB per
+    # step through pageable memory, the sync point of its loop.  Here the n + 1 states land in ONE pinned host buffer
+    # through a copy stream, so the D2H of step k overlaps the forward of step k + 1; the result is the same array.
+    times, stacked, arrays, side = [], None, [], None
     for k, (time, output, _) in enumerate(model(time, x)):
-        # output: (B, len(out_channel_names), len(lat), len(lon)); the D2H copy is the sync point
-        arrays.append(output.cpu().numpy().squeeze())
+        out = output.squeeze(0) if output.dim() == 4 and output.shape[0] == 1 else output
+        if out.is_cuda:
+            if stacked is None:
+                pin = (n + 1) * out.numel() * 4 <= _PINNED_LIMIT
+                stacked = torch.empty((n + 1,) + tuple(out.shape), dtype=torch.float32, pin_memory=pin)
+                side = torch.cuda.Stream(out.device)
+            side.wait_stream(torch.cuda.current_stream(out.device))
+            with torch.cuda.stream(side):
+                stacked[k].copy_(out, non_blocking=True)
+            out.record_stream(side)
+        else:
+            arrays.append(out.detach().cpu().numpy())
         times.append(time)
         if k == n:
             break
-
-    stacked = np.stack(arrays)
+    if stacked is not None:
+        side.synchronize()
+        stacked = stacked[:len(times)].numpy()
+    else:
+        stacked = np.stack(arrays)
     coords = dict(time=times, channel=model.out_channel_names, lat=np.asarray(model.grid.lat), lon=np.asarray(model.grid.lon))
     return DataArray(stacked, dims=["time", "channel", "lat", "lon"], coords=coords)
 

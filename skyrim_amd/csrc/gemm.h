@@ -194,7 +194,11 @@ inline hipError_t launch_gemm(const GemmArgs<P, AL, EP>& g, hipStream_t stream) 
     dim3 grid((g.N + TC::BN - 1) / TC::BN, (g.M + TC::BM - 1) / TC::BM);
     if (grid.x == 0 || grid.y == 0) return hipSuccess;
     constexpr int smem = gemm_smem_bytes<P, TC>() + kEpiScratch;
-    static_assert(smem <= 64 * 1024, "LDS per block");
+    static_assert(smem <= 160 * 1024, "LDS per block");
+    if (smem > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<P, TC, AL, EP>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e != hipSuccess) return e;
+    }
     hipLaunchKernelGGL((gemm_kernel<P, TC, AL, EP>), grid, dim3(TC::THREADS), smem, stream, g);
     return hipGetLastError();
 }

@@ -14,7 +14,7 @@ hipError_t op_down(const Geom& g, const ModelW<typename P::T>& w, const typename
     a.ep = EP{nullptr, 384, 0, X2s, wk.xs_plane[1]};
     a.W = w.down.w; a.w_plane = w.down.plane; a.ldw = w.down.ldw;
     a.M = g.ntok[1]; a.N = 384; a.K = 768;
-    return launch_gemm<P, typename Tiles<P>::G128>(a, s);
+    return launch_gemm<P, typename Tiles<P>::L384>(a, s);      // whole N per block: the merged + normalised A rows are produced once
 }
 
 template <class P>
