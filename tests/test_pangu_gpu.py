@@ -123,6 +123,22 @@ def test_longitude_shift_equivariance_toy(eng, toy):
     assert O.per_channel_rel_err(torch.roll(y2, -96, dims=-1).cpu(), y.cpu()).max().item() < 3 * STEP_TOL[eng.precision]
 
 
+@pytest.mark.parametrize("grid", [(61, 192), (73, 288), (25, 96)])
+def test_other_geometries_step_vs_oracle(grid):
+    """Padding / window-type / down-sample parity cases the 49x192 toy and the full grid do not hit: an even coarse
+    latitude count (61 -> 16 rows: no DownSample pad row), three longitude window columns at the coarse level (288),
+    and the smallest grid the window shapes allow (25x96: one longitude window at the coarse level)."""
+    from skyrim_amd.pangu.engine import PanguEngine
+    g = PanguGeometry(*grid)
+    params = init_synthetic(g, 5)
+    x = synthetic_state(g, 5)
+    e = PanguEngine(g, device="cuda:0")
+    e.load_params(params)
+    y = e.step(x.cuda())
+    err = O.per_channel_rel_err(y.cpu(), O.forward(params, x))
+    assert torch.isfinite(y).all() and err.max().item() < 3e-4, err
+
+
 def test_step_before_prepare_is_an_error(toy):
     from skyrim_amd.pangu.engine import PanguEngine
     g, params, x = toy
