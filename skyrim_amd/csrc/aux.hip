@@ -32,9 +32,11 @@ template hipError_t prep_weight<bf16, 2>(const float*, bf16*, long long, int, in
 template hipError_t prep_weight<f16, 1>(const float*, f16*, long long, int, int, int, long long, long long, int, int, hipStream_t);
 template hipError_t prep_weight<f16, 2>(const float*, f16*, long long, int, int, int, long long, long long, int, int, hipStream_t);
 
-// Earth-specific bias gathered from the compact (3312, types, heads) table into the attention
-// kernel's accumulator order [type][head][qf][kf][lane][r]:
-//   q = 16 qf + (lane & 15), key = 16 kf + 4 (lane >> 4) + r,
+// Earth-specific bias gathered from the compact (3312, types, heads) table into the attention kernel's accumulator
+// order (attention.hip, attn_key()): per (type, head, query fragment qf) one 2304-element tile laid out as
+//   [kb = 0..3][lane][8]   keys 32 kb + 8 (lane >> 4) + [0..7]  (fragment pair 2kb, 2kb+1: one 16-byte load per lane)
+//   [lane][4]              keys 128 + 4 (lane >> 4) + [0..3]    (fragment 8)
+// with q = 16 qf + (lane & 15) and
 //   index = (z_q + 2 z_k) * 23*36 + (h_q + 6 h_k) * 23 + (w_q - w_k + 11)   (pseudocode _construct_index)
 // Odd (rolled) blocks fold the shifted-window mask in: -100 where q and key sit in different Swin
 // regions of the last Z window / last latitude window (longitude is periodic -> never masked).
@@ -42,13 +44,15 @@ __global__ void prep_bias_expand_kernel(const float* __restrict__ table, f16* __
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long total = (long long)types * heads * 81 * 256;
     if (i >= total) return;
-    const int r = (int)(i & 3), lane = (int)((i >> 2) & 63);
-    long long rest = i >> 8;
-    const int kf = (int)(rest % 9); rest /= 9;
+    const int e = (int)(i % 2304);
+    long long rest = i / 2304;
     const int qf = (int)(rest % 9); rest /= 9;
     const int head = (int)(rest % heads);
     const int type = (int)(rest / heads);
-    const int q = qf * 16 + (lane & 15), key = kf * 16 + 4 * (lane >> 4) + r;
+    int lane, key;
+    if (e < 2048) { const int kb = e >> 9; lane = (e >> 3) & 63; key = 32 * kb + 8 * (lane >> 4) + (e & 7); }
+    else          { lane = ((e - 2048) >> 2) & 63; key = 128 + 4 * (lane >> 4) + (e & 3); }
+    const int q = qf * 16 + (lane & 15);
     const int zq = q / 72, hq = (q / 12) % 6, wq = q % 12;
     const int zk = key / 72, hk = (key / 12) % 6, wk = key % 12;
     const int idx = (zq + 2 * zk) * (23 * 36) + (hq + 6 * hk) * 23 + (wq - wk + 11);

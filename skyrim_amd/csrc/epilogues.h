@@ -132,7 +132,7 @@ struct EpQKV {
     __device__ __forceinline__ bool unswapped(int n0) const { return n0 >= 2 * C; }
     template <class TC, bool SWAP>
     __device__ __forceinline__ void run(f32x4 (&acc)[TC::FM][TC::FN], int m0w, int n0w, int lane, int, int, char*, int M, int N, int) const {
-        static_assert(TC::FN % 2 == 0, "fragment pairs");
+        static_assert(TC::FN % 2 == 0 && TC::FM % 2 == 0, "fragment pairs");
         const int l15 = lane & 15, l4 = (lane >> 4) * 4, l8 = (lane >> 4) * 8;
         if constexpr (SWAP) {
 #pragma unroll
@@ -171,22 +171,20 @@ struct EpQKV {
                 for (int a = 0; a < TC::FM; ++a) { acc[a][b][0] += bb; acc[a][b][1] += bb; acc[a][b][2] += bb; acc[a][b][3] += bb; pin(acc[a][b]); }
             }
 #pragma unroll
-            for (int a = 0; a < TC::FM; ++a) {
-                const int m = m0w + a * 16 + l4;
+            for (int ap = 0; ap < TC::FM / 2; ++ap) {
+                // the tile's A rows are in perm8 order (gemm_dma.h): fragment pair (2ap, 2ap+1) = 8 consecutive tokens
+                const int m = m0w + ap * 32 + 2 * l4;
                 if (m >= M) continue;
-                const int win = m / WIN_TOKENS, t = m - win * WIN_TOKENS;
+                const int win = m / WIN_TOKENS, t = m - win * WIN_TOKENS;     // 144 % 8 == 0: the 8 tokens share a window
 #pragma unroll
                 for (int b = 0; b < TC::FN; ++b) {
                     const int n = perm8_col(n0w + b * 16 + l15);
                     if (n >= N) continue;
                     const int c = n - 2 * C;
                     const int head = c >> 5, d = c & 31;
-                    const float v[4] = {acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]};
-                    uint2 o[NPL];
-                    split4<T, NPL>(v, o);
-                    T* dst = vt + (((long long)win * heads + head) * HEAD_DIM + d) * WIN_TOKENS + t;
-#pragma unroll
-                    for (int p = 0; p < NPL; ++p) *reinterpret_cast<uint2*>(dst + p * plane) = o[p];
+                    const f32x4 &x = acc[2 * ap][b], &y = acc[2 * ap + 1][b];
+                    const float v[8] = {x[0], x[1], x[2], x[3], y[0], y[1], y[2], y[3]};
+                    store8_planes<T, NPL>(vt + (((long long)win * heads + head) * HEAD_DIM + d) * WIN_TOKENS + t, plane, v);
                 }
             }
         }

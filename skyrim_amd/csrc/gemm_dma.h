@@ -153,7 +153,9 @@ __device__ __forceinline__ void gemm_dma_body(const DmaArgs<P, AS, EP>& g, char*
             const int r = rb * RPI + lr;
             const int chunk = (BK == 64) ? (lp ^ (r & 7)) : (lp ^ ((r >> 1) & 3));
             const T *hi, *lo;
-            g.as.rows(m0 + r, chunk * 8, g.zrow, hi, lo);
+            // un-swapped tiles (V of the QKV linear): tile rows in perm8 order, so that a lane's accumulators of a fragment
+            // pair along M are 8 consecutive tokens (16-byte stores into V^T, epilogues.h EpQKV)
+            g.as.rows(m0 + ((EP::kDualOrder && !SWAP) ? perm8_col(r) : r), chunk * 8, g.zrow, hi, lo);
             src[i] = plane == 0 ? hi : lo;
             dst_off[i] = (plane * BM + rb * RPI) * BK * 2;
             is_a[i] = true;

@@ -119,11 +119,14 @@ def run(prec, g, params, x):
         be = eng.debug_buffer(f"bias_exp{blk}", torch.float16).float().cpu()
         types, heads = ref["bias"].shape[:2]
         full = ref["bias"] + (ref["mask"][:, 0][:, None] if ref["mask"] is not None else 0)
-        be = be.reshape(types, heads, 9, 9, 64, 4)
+        be = be.reshape(types, heads, 9, 2304)
         lane = torch.arange(64)
-        qi = (torch.arange(9)[:, None, None, None] * 16 + (lane & 15)[None, None, :, None]).expand(9, 9, 64, 4)
-        ki = (torch.arange(9)[None, :, None, None] * 16 + (4 * (lane >> 4))[None, None, :, None] + torch.arange(4)[None, None, None, :]).expand(9, 9, 64, 4)
-        report("bias_exp", be, full[:, :, qi, ki])
+        q_of = (torch.arange(9)[:, None] * 16 + (lane & 15)[None, :])                      # [qf][lane]
+        k_pair = 32 * torch.arange(4)[:, None, None] + 8 * (lane >> 4)[None, :, None] + torch.arange(8)[None, None, :]   # [kb][lane][8]
+        k_last = 128 + 4 * (lane >> 4)[:, None] + torch.arange(4)[None, :]                 # [lane][4]
+        exp_pair = full[:, :, q_of[:, None, :, None].expand(9, 4, 64, 8), k_pair[None].expand(9, 4, 64, 8)].reshape(types, heads, 9, 2048)
+        exp_last = full[:, :, q_of[:, :, None].expand(9, 64, 4), k_last[None].expand(9, 64, 4)].reshape(types, heads, 9, 256)
+        report("bias_exp", be, torch.cat([exp_pair, exp_last], dim=-1))
         for name in ("q", "k", "vt"):
             got = planes(eng.debug_buffer(name, torch.uint8), nq, 1, torch.float16)
             report(name, got, ref[name])
