@@ -30,11 +30,11 @@ extern "C" {
 #define SKPANGU_ABI_VERSION 1
 
 /* precision modes: how each matrix product is formed on the MFMA pipe */
-#define SKPANGU_PREC_BF16X3 0 /* bf16 hi/lo split, 3 MFMA terms, fp32-class results (default; meets the 1e-3 bar) */
+#define SKPANGU_PREC_BF16X3 0 /* bf16 hi/lo split, 3 MFMA terms, fp32 range (wide-range mode; ~8e-5 per-channel error per step) */
 #define SKPANGU_PREC_F16    1 /* single fp16 term (fast; ~1e-3 relative error per step) */
 #define SKPANGU_PREC_BF16X3_H16 2 /* bf16x3, but the MLP hidden activation is stored as one fp16 plane (~4e-4) */
 #define SKPANGU_PREC_F16X3  3 /* fp16 hi/lo split, 3 MFMA terms (22-bit operands; activations must stay < 65504) */
-#define SKPANGU_PREC_F16X3_Q 4 /* f16x3 with the QKV linear reading only the hi plane of the stream (2 terms) */
+#define SKPANGU_PREC_F16X3_Q 4 /* f16x3 with the QKV linear reading only the hi plane of the stream (2 terms): the host default, ~1e-4 */
 #define SKPANGU_PREC_F16X3_QH 5 /* f16x3_q with the MLP hidden stored as one fp16 plane (fc2: 2 terms) */
 
 #define SKPANGU_E_ARG        (-1) /* bad argument / unsupported geometry */
