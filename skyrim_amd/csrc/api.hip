@@ -1,7 +1,6 @@
 // C ABI (include/skyrim_pangu.h) over the stage launchers: geometry, master-parameter table,
 // arena planning, prepare, and the fixed launch sequence of one Pangu 6-h step.
 #include <cstdio>
-#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <type_traits>
@@ -336,27 +335,16 @@ struct Engine : IEngine {
     }
 
     // one EarthSpecificBlock on a residual stream (hi/lo planes)
-    // fp16 planes and a one-plane A operand for the QKV linear (f16x3q, f16x3qh, f16): fused kernel; SKP_FUSED_ATTN=0 keeps
-    // the two-kernel path (A/B runs, and the stage tests that look at Q/K/V)
-    bool fused_attention() const {
-        static const bool off = getenv("SKP_FUSED_ATTN") && atoi(getenv("SKP_FUSED_ATTN")) == 0;
-        return !off && std::is_same<T, f16>::value && (P::NA == 1 || wk.qkv_a1);
-    }
     hipError_t block_planes(int layer0, int i, T* xs, hipStream_t s) {
         const int res = layer_res(layer0), C = layer_dim(layer0), heads = layer_heads(layer0);
         const BlockW<T>& bw = w.blk[block_index(layer0, i)];
         const int* widx = w.widx[res][i & 1];
         const int o = res == 0 ? 0 : 5;
-        if (fused_attention()) {
-            mark(C_ATTN0 + o, s);                  // one launch: QKV linear + attention, Q/K/V never leave the CU
-            CK((op_qkv_attention<P>(g, bw, widx, res, xs, wk, s)));
-        } else {
-            mark(C_QKV0 + o, s);
-            CK((op_qkv<P>(g, bw, widx, res, xs, wk, s)));
-            mark(C_ATTN0 + o, s);
-            AttnArgs<P> a{wk.q, wk.k, wk.vt, wk.qkv_plane, bw.bias_exp, wk.ao, wk.ao_plane, C, g.nwin[res], g.nW[res], heads};
-            CK(launch_attention<P>(a, s));
-        }
+        mark(C_QKV0 + o, s);
+        CK((op_qkv<P>(g, bw, widx, res, xs, wk, s)));
+        mark(C_ATTN0 + o, s);
+        AttnArgs<P> a{wk.q, wk.k, wk.vt, wk.qkv_plane, bw.bias_exp, wk.ao, wk.ao_plane, C, g.nwin[res], g.nW[res], heads};
+        CK(launch_attention<P>(a, s));
         mark(C_PROJ0 + o, s);
         CK((op_proj<P>(g, bw, widx, res, xs, wk, s)));
         mark(C_FC1_0 + o, s);

@@ -78,8 +78,6 @@ template <class P> hipError_t launch_attention(const AttnArgs<P>&, hipStream_t);
 template <class P> hipError_t op_embed(const Geom&, const ModelW<typename P::T>&, const float* state, typename P::T* X1s, const Work<P>&, hipStream_t);
 template <class P> hipError_t op_recover(const Geom&, const ModelW<typename P::T>&, const typename P::T* skip_s, const typename P::T* x4_s, float* state, const Work<P>&, hipStream_t);
 template <class P> hipError_t op_qkv(const Geom&, const BlockW<typename P::T>&, const int* widx, int res, const typename P::T* Xs, const Work<P>&, hipStream_t);
-// QKV linear + window attention fused (qkv_attention.hip): Q/K/V stay in registers; fp16-plane modes with a one-plane QKV A operand
-template <class P> hipError_t op_qkv_attention(const Geom&, const BlockW<typename P::T>&, const int* widx, int res, const typename P::T* Xs, const Work<P>&, hipStream_t);
 template <class P> hipError_t op_proj(const Geom&, const BlockW<typename P::T>&, const int* widx, int res, typename P::T* Xs, const Work<P>&, hipStream_t);
 template <class P> hipError_t op_fc1(const Geom&, const BlockW<typename P::T>&, int res, const typename P::T* Xs, const Work<P>&, hipStream_t);
 template <class P> hipError_t op_fc2(const Geom&, const BlockW<typename P::T>&, int res, typename P::T* Xs, const Work<P>&, hipStream_t);
