@@ -107,7 +107,6 @@ struct IEngine {
 template <class P>
 struct Engine : IEngine {
     typedef typename P::T T;
-    typedef typename ActT<P>::type S;
     static constexpr int NW = P::NW;
     static constexpr int NPL = (P::NA > P::NW ? P::NA : P::NW);
 

@@ -44,10 +44,6 @@ struct PrecF16x3  { typedef f16 T;  static constexpr int NA = 2, NW = 2; };
 // fc2 of the "fp16 hidden" mode: A = single fp16 plane (the GELU output), W = fp16 hi/lo planes, 2 MFMA terms
 struct PrecF16x2W { typedef f16 T;  static constexpr int NA = 1, NW = 2; };
 
-// storage type of inter-kernel activations: fp32 when the consumer splits hi/lo, else T
-template <class P> struct ActT { typedef typename P::T type; };
-template <> struct ActT<PrecBF16x3> { typedef float type; };
-
 // ---- hi/lo split ---------------------------------------------------------- //
 // 8 fp32 -> NP planes of 8 x T packed as uint4.  lo = T(v - float(hi)).
 template <class T, int NP>

@@ -43,7 +43,6 @@ struct ModelW {
 template <class P>
 struct Work {
     typedef typename P::T T;
-    typedef typename ActT<P>::type S;
     T *X1s, *X2s, *X4s;      // residual streams: hi/lo planes, blocked layout (always two planes); lo at + xs_plane[res]
     long long xs_plane[2];
     f16 *q, *k, *vt;         // single fp16 planes in every mode (attention.hip)
