@@ -1,0 +1,215 @@
+// SFNO (FourCastNet v2) building blocks behind include/skyrim_sfno.h: every linear map of the network -- 1x1
+// convolutions, the truncated real DFT along longitude, the Legendre analysis / synthesis per order m, the per-degree
+// complex channel mixing (dhconv) and their inverses -- is ONE batched GEMM against a constant matrix:
+//
+//     out[b](m, n) = post( act( sum_k A[b](m, k) * W[b][n][k] + bias[n] + res_pre[b](m, n) ) ) + res_post[b](m, n)
+//
+// A and out are fp32 arrays addressed through strides (two-level for the row index, so that (channel, re/im) pairs and
+// NCHW / channel-last layouts need no transpose pass); W is prepared once as fp16 hi/lo planes and the product runs as
+// three fp16 MFMA terms with fp32 accumulation (fp32-class results at 1/3 of the MFMA rate).  The main
+// loop is gemm.h's register-staged pipeline (the A operand is converted on the fly).  First correct path: the strided
+// loader issues scalar loads when k is not the contiguous index; layout-specialised loaders are the next step.
+#include <hip/hip_runtime.h>
+
+#include "../../include/skyrim_sfno.h"
+#include "common.h"
+#include "epilogues.h"
+#include "gemm.h"
+#include "launchers.h"
+
+namespace skp {
+
+// ---- A operand: fp32, strided ------------------------------------------------------------------ //
+struct ALStrided {
+    static constexpr bool kDirect = false;
+    const float* a;
+    int M, K, m1;                 // row m -> (m / m1) * sm2 + (m % m1) * sm
+    long long sm, sm2, sk;
+    struct Row { long long off; int ok; };
+    struct Raw { float v[8]; };
+    __device__ __forceinline__ Row row(int m) const {
+        if (m >= M) return Row{0, 0};
+        const int hi = m / m1, lo = m - hi * m1;
+        return Row{hi * sm2 + lo * sm, 1};
+    }
+    __device__ __forceinline__ void issue(const Row& r, int k, Raw& o) const {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o.v[i] = 0.f;
+        if (!r.ok || k >= K) return;
+        const float* p = a + r.off + (long long)k * sk;
+        if (sk == 1 && k + 8 <= K && ((reinterpret_cast<size_t>(p) & 15) == 0)) {
+            const float4 x = *reinterpret_cast<const float4*>(p), y = *reinterpret_cast<const float4*>(p + 4);
+            o.v[0] = x.x; o.v[1] = x.y; o.v[2] = x.z; o.v[3] = x.w; o.v[4] = y.x; o.v[5] = y.y; o.v[6] = y.z; o.v[7] = y.w;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (k + i < K) o.v[i] = p[(long long)i * sk];
+        }
+    }
+    __device__ __forceinline__ void finish(const Raw& r, float (&v)[8]) const {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = r.v[i];
+    }
+    __device__ __forceinline__ uint4 direct(const Raw&) const { return make_uint4(0, 0, 0, 0); }
+};
+
+// ---- epilogue: bias, residual before the activation, GELU, residual after, strided fp32 store ---- //
+struct EpStrided {
+    static constexpr bool kDualOrder = false;
+    template <class TC> __device__ __forceinline__ void init(char*, int, int) const {}
+    float* out;
+    const float* bias;
+    const float* res_pre;
+    const float* res_post;
+    int m1, act;
+    long long sm, sm2, sn;
+    __device__ __forceinline__ long long addr(int m, int n) const {
+        const int hi = m / m1, lo = m - hi * m1;
+        return hi * sm2 + lo * sm + (long long)n * sn;
+    }
+    __device__ __forceinline__ float post(float v, long long o, int n) const {
+        if (bias) v += bias[n];
+        if (res_pre) v += res_pre[o];
+        if (act == 1) v = gelu_erf(v);
+        if (res_post) v += res_post[o];
+        return v;
+    }
+    template <class TC, bool SWAP>
+    __device__ __forceinline__ void run(f32x4 (&acc)[TC::FM][TC::FN], int m0w, int n0w, int lane, int, int, char*, int M, int N, int) const {
+        const int l15 = lane & 15, l4 = (lane >> 4) * 4;
+#pragma unroll
+        for (int a = 0; a < TC::FM; ++a)
+#pragma unroll
+            for (int b = 0; b < TC::FN; ++b) {
+                // SWAP: 4 consecutive n of one row; else 4 consecutive rows of one column
+                const int m = m0w + a * 16 + (SWAP ? l15 : l4), n = n0w + b * 16 + (SWAP ? l4 : l15);
+                if (m >= M || n >= N) continue;
+                const long long o0 = addr(m, n);
+                const bool vec = SWAP ? (sn == 1 && n + 3 < N) : (sm == 1 && m1 >= M && m + 3 < M);
+                if (vec && (o0 & 3) == 0 && (reinterpret_cast<size_t>(out) & 15) == 0) {
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = post(acc[a][b][r], o0 + r, SWAP ? n + r : n);
+                    *reinterpret_cast<float4*>(out + o0) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int mm = SWAP ? m : m + r, nn = SWAP ? n + r : n;
+                        if (mm < M && nn < N) {
+                            const long long o = addr(mm, nn);
+                            out[o] = post(acc[a][b][r], o, nn);
+                        }
+                    }
+                }
+            }
+    }
+};
+
+typedef PrecF16x3 PG;
+typedef TileCfg<128, 128, 32, 2, 2> TG;
+
+struct BatchStrides { long long a, w, o; };
+
+template <bool SWAP>
+__global__ void __launch_bounds__(TG::THREADS) gemm_strided_kernel(GemmArgs<PG, ALStrided, EpStrided> g, BatchStrides bs) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const long long z = blockIdx.z;
+    g.al.a += z * bs.a;
+    g.W += z * bs.w;
+    g.ep.out += z * bs.o;
+    if (g.ep.res_pre) g.ep.res_pre += z * bs.o;
+    if (g.ep.res_post) g.ep.res_post += z * bs.o;
+    gemm_body<PG, TG, ALStrided, EpStrided, SWAP>(g, smem);
+}
+
+// ---- instance norm over (H, W) per channel: two passes for the statistics, one to apply ---- //
+__device__ __forceinline__ float block_sum(float v, float* red) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    float s = 0.f;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += red[w];
+    return s;
+}
+
+__global__ void __launch_bounds__(1024) instance_norm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, float* __restrict__ out, long long HW, float eps) {
+    __shared__ float red[16];
+    const float* xc = x + (long long)blockIdx.x * HW;
+    float* oc = out + (long long)blockIdx.x * HW;
+    const bool v4 = (HW & 3) == 0;
+    float s = 0.f;
+    if (v4) {
+        for (long long i = threadIdx.x; i < HW / 4; i += blockDim.x) { const float4 v = reinterpret_cast<const float4*>(xc)[i]; s += (v.x + v.y) + (v.z + v.w); }
+    } else {
+        for (long long i = threadIdx.x; i < HW; i += blockDim.x) s += xc[i];
+    }
+    const float mean = block_sum(s, red) / (float)HW;
+    float q = 0.f;
+    if (v4) {
+        for (long long i = threadIdx.x; i < HW / 4; i += blockDim.x) {
+            const float4 v = reinterpret_cast<const float4*>(xc)[i];
+            const float a = v.x - mean, b = v.y - mean, c = v.z - mean, d = v.w - mean;
+            q += (a * a + b * b) + (c * c + d * d);
+        }
+    } else {
+        for (long long i = threadIdx.x; i < HW; i += blockDim.x) { const float d = xc[i] - mean; q += d * d; }
+    }
+    const float rstd = rsqrtf(block_sum(q, red) / (float)HW + eps);
+    const float g = gamma[blockIdx.x] * rstd, b = beta[blockIdx.x] - mean * g;
+    if (v4) {
+        for (long long i = threadIdx.x; i < HW / 4; i += blockDim.x) {
+            const float4 v = reinterpret_cast<const float4*>(xc)[i];
+            reinterpret_cast<float4*>(oc)[i] = make_float4(v.x * g + b, v.y * g + b, v.z * g + b, v.w * g + b);
+        }
+    } else {
+        for (long long i = threadIdx.x; i < HW; i += blockDim.x) oc[i] = xc[i] * g + b;
+    }
+}
+
+}  // namespace skp
+
+using namespace skp;
+
+extern "C" {
+
+int sksfno_abi_version(void) { return SKSFNO_ABI_VERSION; }
+
+int sksfno_prepare_weight(const float* src, long long sn, long long sk, int N, int K, void* dst, long long plane, int ldw, void* stream) {
+    if (!src || !dst || N <= 0 || K <= 0 || ldw < K || (ldw & 7) || plane < (long long)N * ldw) return SKSFNO_E_ARG;
+    const hipError_t e = prep_weight<f16, 2>(src, static_cast<f16*>(dst), plane, N, K, ldw, sn, sk, 0, 0, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? 0 : SKSFNO_E_HIP;
+}
+
+int sksfno_gemm_run(const sksfno_gemm* d, void* stream) {
+    if (!d || !d->a || !d->w || !d->out || d->M <= 0 || d->N <= 0 || d->K <= 0 || d->batch <= 0 || d->a_m1 <= 0 || d->o_m1 <= 0 ||
+        (d->ldw & 7) || d->ldw < d->K || (d->act != 0 && d->act != 1))
+        return SKSFNO_E_ARG;
+    GemmArgs<PG, ALStrided, EpStrided> g;
+    g.al = ALStrided{d->a, d->M, d->K, d->a_m1, d->a_sm, d->a_sm2, d->a_sk};
+    g.ep = EpStrided{d->out, d->bias, d->res_pre, d->res_post, d->o_m1, d->act, d->o_sm, d->o_sm2, d->o_sn};
+    g.W = static_cast<const f16*>(d->w);
+    g.w_plane = d->w_plane;
+    g.ldw = d->ldw;
+    g.M = d->M; g.N = d->N; g.K = d->K;
+    const BatchStrides bs{d->a_sb, d->w_sb, d->o_sb};
+    const dim3 grid((d->N + TG::BN - 1) / TG::BN, (d->M + TG::BM - 1) / TG::BM, d->batch);
+    if (grid.y > 65535 || grid.z > 65535) return SKSFNO_E_ARG;
+    constexpr int smem = gemm_smem_bytes<PG, TG>() + kEpiScratch;
+    // rows contiguous in the output (NCHW activations): un-swapped order gives 4 consecutive rows per lane
+    const bool swap = !(d->o_sm == 1 && d->o_sn != 1);
+    if (swap) hipLaunchKernelGGL(gemm_strided_kernel<true>, grid, dim3(TG::THREADS), smem, static_cast<hipStream_t>(stream), g, bs);
+    else      hipLaunchKernelGGL(gemm_strided_kernel<false>, grid, dim3(TG::THREADS), smem, static_cast<hipStream_t>(stream), g, bs);
+    return hipGetLastError() == hipSuccess ? 0 : SKSFNO_E_HIP;
+}
+
+int sksfno_instance_norm(const float* x, const float* gamma, const float* beta, float* out, int C, long long HW, float eps, void* stream) {
+    if (!x || !gamma || !beta || !out || C <= 0 || HW <= 0) return SKSFNO_E_ARG;
+    hipLaunchKernelGGL(instance_norm_kernel, dim3(C), dim3(1024), 0, static_cast<hipStream_t>(stream), x, gamma, beta, out, HW, eps);
+    return hipGetLastError() == hipSuccess ? 0 : SKSFNO_E_HIP;
+}
+
+}  // extern "C"

@@ -1,0 +1,257 @@
+"""SFNO (FourCastNet v2-small) 6-h step on one MI355X: the host owns buffers and call order, every FLOP runs in the
+HIP kernels of include/skyrim_sfno.h (libskyrim_sfno.so, loaded through ctypes; PyTorch is device memory + streams).
+
+One step = 2 + 12 * num_layers (+ 2 per resolution change) + 3 launches.  Data layouts (all fp32):
+
+    activations            [C][H][W]                      (the reference's NCHW without the batch)
+    longitude spectrum     [C][H][mmax][re, im]           truncated real DFT, m < mmax
+    SH coefficients        [l][m][C][re, im]              channel-last so that the per-degree complex channel mixing is a
+                                                          plain GEMM over k = (channel, re/im)
+
+Input normalisation, output de-normalisation and the big-skip concat are folded into the encoder / decoder weights at
+prepare time (exact algebra): the kernels read the raw state and write physical units.  There is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from pathlib import Path
+
+import numpy as np
+import torch
+
+from .sht import ShtMatrices
+from .spec import SfnoConfig, param_spec
+
+_LIB_PATH = Path(__file__).resolve().parent.parent / "lib" / "libskyrim_sfno.so"
+EXPORTS = ["sksfno_abi_version", "sksfno_prepare_weight", "sksfno_gemm_run", "sksfno_instance_norm"]
+
+
+class GemmDesc(ctypes.Structure):
+    _fields_ = [("a", ctypes.c_void_p), ("a_sb", ctypes.c_longlong), ("a_m1", ctypes.c_int),
+                ("a_sm", ctypes.c_longlong), ("a_sm2", ctypes.c_longlong), ("a_sk", ctypes.c_longlong),
+                ("w", ctypes.c_void_p), ("w_sb", ctypes.c_longlong), ("w_plane", ctypes.c_longlong), ("ldw", ctypes.c_int),
+                ("bias", ctypes.c_void_p), ("res_pre", ctypes.c_void_p), ("res_post", ctypes.c_void_p),
+                ("out", ctypes.c_void_p), ("o_sb", ctypes.c_longlong), ("o_m1", ctypes.c_int),
+                ("o_sm", ctypes.c_longlong), ("o_sm2", ctypes.c_longlong), ("o_sn", ctypes.c_longlong),
+                ("M", ctypes.c_int), ("N", ctypes.c_int), ("K", ctypes.c_int), ("batch", ctypes.c_int), ("act", ctypes.c_int)]
+
+
+_lib = None
+
+
+def load_library():
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = os.environ.get("SKYRIM_SFNO_LIB", str(_LIB_PATH))
+    if not os.path.exists(path):
+        raise RuntimeError(f"{path} not found: build the HIP library first (python -c 'import __graft_entry__ as g; g.build()')")
+    lib = ctypes.CDLL(path)
+    lib.sksfno_abi_version.restype = ctypes.c_int
+    lib.sksfno_prepare_weight.argtypes = [ctypes.c_void_p, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_int, ctypes.c_int,
+                                          ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_void_p]
+    lib.sksfno_gemm_run.argtypes = [ctypes.POINTER(GemmDesc), ctypes.c_void_p]
+    lib.sksfno_instance_norm.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                                         ctypes.c_longlong, ctypes.c_float, ctypes.c_void_p]
+    for name in EXPORTS:
+        getattr(lib, name).restype = ctypes.c_int
+    _lib = lib
+    return lib
+
+
+def _check(code: int, what: str):
+    if code != 0:
+        raise RuntimeError(f"{what} failed with code {code}")
+
+
+_BIG = 1 << 30       # "no split" value for the two-level row index
+
+
+class _Weight:
+    """A constant matrix [batch][N][K] prepared as fp16 hi/lo planes on the device."""
+
+    def __init__(self, eng, w: torch.Tensor):
+        w = w.float().contiguous()
+        if w.dim() == 2:
+            w = w[None]
+        self.batch, self.N, self.K = w.shape
+        self.ldw = (self.K + 7) // 8 * 8
+        per = self.N * self.ldw
+        self.plane = self.batch * per
+        self.w_sb = per
+        self.buf = torch.empty(2 * self.plane, dtype=torch.float16, device=eng.device)
+        chunk = max(1, (256 << 20) // (self.N * self.K * 4))          # upload at most ~256 MB of fp32 at a time
+        for b0 in range(0, self.batch, chunk):
+            src = w[b0:b0 + chunk].to(eng.device)
+            for j in range(src.shape[0]):
+                dst = self.buf.data_ptr() + 2 * (b0 + j) * per
+                _check(eng.lib.sksfno_prepare_weight(src[j].data_ptr(), self.K, 1, self.N, self.K, dst, self.plane, self.ldw, eng._stream()),
+                       "sksfno_prepare_weight")
+            torch.cuda.current_stream(eng.device).synchronize()
+
+
+class SfnoEngine:
+    def __init__(self, cfg: SfnoConfig | None = None, device: str | torch.device = "cuda:0"):
+        self.cfg = cfg or SfnoConfig()
+        if not torch.cuda.is_available():
+            raise RuntimeError("SfnoEngine needs an MI355X: the SFNO path has no CPU fallback")
+        self.lib = load_library()
+        self.device = torch.device(device)
+        self.prepared = False
+        c = self.cfg
+        if c.num_layers < 2:
+            raise ValueError("num_layers >= 2 (the first block goes to the internal grid, the last one back)")
+        self.state_shape = (c.in_chans, c.n_lat, c.n_lon)
+
+    def _stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    # ---- prepare ---------------------------------------------------------------------------------- #
+    def load_params(self, params: dict):
+        c = self.cfg
+        for name, shape in param_spec(c):
+            if name not in params or tuple(params[name].shape) != tuple(shape):
+                raise ValueError(f"parameter {name}: expected shape {shape}, got {tuple(params[name].shape) if name in params else None}")
+        p = {k: v.double() for k, v in params.items()}
+        dev = self.device
+        with torch.cuda.device(dev):
+            f32 = lambda t: t.float().contiguous().to(dev)  # noqa: E731
+            mean, std = p["norm.mean"], p["norm.std"]
+            self.enc1 = _Weight(self, p["encoder.fc1.weight"] / std[None, :])
+            self.enc1_b = f32(p["encoder.fc1.bias"] - p["encoder.fc1.weight"] @ (mean / std))
+            self.enc2 = _Weight(self, p["encoder.fc2.weight"])
+            self.pos = f32(p["pos_embed"])
+            e = c.embed_dim
+            self.blocks = []
+            for i in range(c.num_layers):
+                g = lambda n: p[f"blocks.{i}.{n}"]  # noqa: E731,B023
+                fw = g("filter.weight")                               # [in][out][l][2]
+                wr, wi = fw[..., 0].permute(2, 1, 0), fw[..., 1].permute(2, 1, 0)      # [l][out][in]
+                mix = torch.empty(c.lmax, 2 * e, 2 * e, dtype=torch.float32)
+                mix[:, 0::2, 0::2] = wr
+                mix[:, 0::2, 1::2] = -wi
+                mix[:, 1::2, 0::2] = wi
+                mix[:, 1::2, 1::2] = wr
+                self.blocks.append(dict(
+                    n0_g=f32(g("norm0.weight")), n0_b=f32(g("norm0.bias")), n1_g=f32(g("norm1.weight")), n1_b=f32(g("norm1.bias")),
+                    mix=_Weight(self, mix), skip=_Weight(self, g("inner_skip.weight")), skip_b=f32(g("inner_skip.bias")),
+                    fc1=_Weight(self, g("mlp.fc1.weight")), fc1_b=f32(g("mlp.fc1.bias")),
+                    fc2=_Weight(self, g("mlp.fc2.weight")), fc2_b=f32(g("mlp.fc2.bias"))))
+                del mix
+            wd = p["decoder.fc1.weight"]
+            self.dec1a = _Weight(self, wd[:, :e])
+            self.dec1b = _Weight(self, wd[:, e:] / std[None, :])
+            self.dec1_b = f32(p["decoder.fc1.bias"] - wd[:, e:] @ (mean / std))
+            self.dec2 = _Weight(self, p["decoder.fc2.weight"] * std[: c.out_chans, None])
+            self.dec2_b = f32(mean[: c.out_chans])
+            # transforms: outer (equiangular 721 x 1440) and inner (Legendre-Gauss h x w)
+            self.tr = {}
+            for key, (nlat, nlon, grid) in {"outer": (c.n_lat, c.n_lon, "equiangular"), "inner": (c.h, c.w, "legendre-gauss")}.items():
+                m = ShtMatrices(nlat, nlon, c.lmax, c.mmax, grid)
+                self.tr[key] = dict(n_lat=nlat, n_lon=nlon,
+                                    dft=_Weight(self, torch.from_numpy(m.dft)), idft=_Weight(self, torch.from_numpy(m.idft)),
+                                    ana=_Weight(self, torch.from_numpy(m.analysis)), syn=_Weight(self, torch.from_numpy(m.synthesis)))
+            # work buffers
+            hw_o, hw_i = c.n_lat * c.n_lon, c.h * c.w
+            hid = e * c.mlp_ratio
+            buf = lambda n: torch.empty(n, dtype=torch.float32, device=dev)  # noqa: E731
+            self.b_y, self.b_xn, self.b_sp, self.b_res = buf(e * hw_o), buf(e * hw_o), buf(e * hw_o), buf(e * hw_o)
+            self.b_hid = buf(hid * hw_i)                  # MLP hidden on the internal grid
+            self.b_hid_outer = buf(hid * hw_o)            # MLP hidden of the last block (outer grid)
+            self.b_f = buf(e * c.n_lat * 2 * c.mmax)
+            self.b_coef, self.b_mixed = buf(c.lmax * c.mmax * 2 * e), buf(c.lmax * c.mmax * 2 * e)
+            self.b_out = buf(c.out_chans * hw_o)
+            torch.cuda.current_stream(dev).synchronize()
+        self.prepared = True
+
+    # ---- launches ---------------------------------------------------------------------------------- #
+    def _gemm(self, a, W: _Weight, out, M, K, N, *, a_sm, a_sk, o_sm, o_sn, batch=1, a_sb=0, o_sb=0, a_m1=_BIG, a_sm2=0,
+              o_m1=_BIG, o_sm2=0, bias=None, res_pre=None, res_post=None, act=0, a_off=0, o_off=0, w_batched=None):
+        if N != W.N or K != W.K:
+            raise ValueError(f"GEMM {M}x{N}x{K} against a prepared [{W.N}][{W.K}] matrix")
+        ptr = lambda t, off=0: None if t is None else t.data_ptr() + 4 * off  # noqa: E731
+        d = GemmDesc(ptr(a, a_off), a_sb, a_m1, a_sm, a_sm2, a_sk,
+                     W.buf.data_ptr(), (W.w_sb if (batch > 1 if w_batched is None else w_batched) else 0), W.plane, W.ldw,
+                     ptr(bias), ptr(res_pre, o_off), ptr(res_post, o_off),
+                     ptr(out, o_off), o_sb, o_m1, o_sm, o_sm2, o_sn, M, N, K, batch, act)
+        _check(self.lib.sksfno_gemm_run(ctypes.byref(d), self._stream()), "sksfno_gemm_run")
+
+    def _norm(self, x, g, b, out, C, HW):
+        _check(self.lib.sksfno_instance_norm(x.data_ptr(), g.data_ptr(), b.data_ptr(), out.data_ptr(), C, HW, self.cfg.eps, self._stream()),
+               "sksfno_instance_norm")
+
+    def _pointwise(self, a, W, out, hw, cin, cout, **kw):
+        """1x1 convolution on [C][hw] activations: rows = pixels (contiguous), k = channel (stride hw)."""
+        self._gemm(a, W, out, hw, cin, cout, a_sm=1, a_sk=hw, o_sm=1, o_sn=hw, **kw)
+
+    def _analysis(self, x, tr, C):
+        """[C][H][W] -> SH coefficients [l][m][C][2] in self.b_coef."""
+        c = self.cfg
+        H, Wd, Mm, L = tr["n_lat"], tr["n_lon"], c.mmax, c.lmax
+        self._gemm(x, tr["dft"], self.b_f, C * H, Wd, 2 * Mm, a_sm=Wd, a_sk=1, o_sm=2 * Mm, o_sn=1)
+        # per order m: rows (channel, re/im), k = latitude
+        self._gemm(self.b_f, tr["ana"], self.b_coef, 2 * C, H, L, batch=Mm, a_sb=2, a_m1=2, a_sm=1, a_sm2=H * 2 * Mm, a_sk=2 * Mm,
+                   o_sb=2 * C, o_sm=1, o_sn=Mm * 2 * C)
+
+    def _synthesis(self, coef, tr, out, C, **kw):
+        """SH coefficients [l][m][C][2] -> [C][H][W] (+ epilogue options of the last GEMM)."""
+        c = self.cfg
+        H, Wd, Mm, L = tr["n_lat"], tr["n_lon"], c.mmax, c.lmax
+        self._gemm(coef, tr["syn"], self.b_f, 2 * C, L, H, batch=Mm, a_sb=2 * C, a_sm=1, a_sk=Mm * 2 * C,
+                   o_sb=2, o_m1=2, o_sm=1, o_sm2=H * 2 * Mm, o_sn=2 * Mm)
+        self._gemm(self.b_f, tr["idft"], out, C * H, 2 * Mm, Wd, a_sm=2 * Mm, a_sk=1, o_sm=Wd, o_sn=1, **kw)
+
+    def step(self, x: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+        """One 6-h step: fp32 (in_chans, n_lat, n_lon) on the engine device -> (out_chans, n_lat, n_lon)."""
+        if not self.prepared:
+            raise RuntimeError("SfnoEngine.step before load_params: not prepared")
+        c = self.cfg
+        if x.device != self.device or x.dtype != torch.float32 or tuple(x.shape) != self.state_shape or not x.is_contiguous():
+            raise ValueError(f"expected a contiguous float32 tensor of shape {self.state_shape} on {self.device}")
+        e, hid = c.embed_dim, c.embed_dim * c.mlp_ratio
+        hw_o = c.n_lat * c.n_lon
+        with torch.cuda.device(self.device):
+            # encoder: GELU(W1' x + b1') -> W2 . + position embedding
+            self._pointwise(x, self.enc1, self.b_sp, hw_o, c.in_chans, e, bias=self.enc1_b, act=1)
+            self._pointwise(self.b_sp, self.enc2, self.b_y, hw_o, e, e, res_post=self.pos)
+            cur = self.b_y
+            for i, blk in enumerate(self.blocks):
+                tin = self.tr["outer"] if i == 0 else self.tr["inner"]
+                tout = self.tr["outer"] if i == c.num_layers - 1 else self.tr["inner"]
+                hw_in, hw_out = tin["n_lat"] * tin["n_lon"], tout["n_lat"] * tout["n_lon"]
+                self._norm(cur, blk["n0_g"], blk["n0_b"], self.b_xn, e, hw_in)
+                self._analysis(self.b_xn, tin, e)
+                if tin is tout:
+                    res = self.b_xn
+                else:                                               # the residual is the normalised input on the OUTPUT grid
+                    self._synthesis(self.b_coef, tout, self.b_res, e)
+                    res = self.b_res
+                # dhconv: per degree l, rows = orders m, k = (in channel, re/im) -> (out channel, re/im)
+                self._gemm(self.b_coef, blk["mix"], self.b_mixed, c.mmax, 2 * e, 2 * e, batch=c.lmax, a_sb=c.mmax * 2 * e, a_sm=2 * e, a_sk=1,
+                           o_sb=c.mmax * 2 * e, o_sm=2 * e, o_sn=1)
+                self._synthesis(self.b_mixed, tout, self.b_sp, e)
+                # GELU(filter output + inner skip(residual))
+                self._pointwise(res, blk["skip"], self.b_y, hw_out, e, e, bias=blk["skip_b"], res_pre=self.b_sp, act=1)
+                self._norm(self.b_y, blk["n1_g"], blk["n1_b"], self.b_sp, e, hw_out)
+                hbuf = self.b_hid_outer if tout is self.tr["outer"] else self.b_hid
+                self._pointwise(self.b_sp, blk["fc1"], hbuf, hw_out, e, hid, bias=blk["fc1_b"], act=1)
+                self._pointwise(hbuf, blk["fc2"], self.b_y, hw_out, hid, e, bias=blk["fc2_b"], res_post=res)
+                cur = self.b_y
+            # decoder on concat(cur, normalised input): W_a cur + b' , then GELU(W_b' x + .), then W2' . + mean
+            self._pointwise(cur, self.dec1a, self.b_sp, hw_o, e, e, bias=self.dec1_b)
+            self._pointwise(x, self.dec1b, self.b_xn, hw_o, c.in_chans, e, res_pre=self.b_sp, act=1)
+            y = out if out is not None else torch.empty((c.out_chans, c.n_lat, c.n_lon), dtype=torch.float32, device=self.device)
+            if y.device != self.device or y.dtype != torch.float32 or tuple(y.shape) != (c.out_chans, c.n_lat, c.n_lon) or not y.is_contiguous():
+                raise ValueError("bad output tensor")
+            target = self.b_out if y.data_ptr() == x.data_ptr() else y
+            self._pointwise(self.b_xn, self.dec2, target, hw_o, e, c.out_chans, bias=self.dec2_b)
+            if target is self.b_out:
+                y.view(-1).copy_(self.b_out)
+        return y
+
+    def launches_per_step(self) -> int:
+        n = 2 + 3
+        for i in range(self.cfg.num_layers):
+            n += 2 + 2 + 1 + 2 + 3 + (2 if i in (0, self.cfg.num_layers - 1) else 0)
+        return n
