@@ -38,7 +38,7 @@ class GlobalModel:
 
     def build_datasource(self):
         return get_data_source(self.model.in_channel_names, initial_condition_source=self.ic_source,
-                               geom=getattr(self.model, "geom", None))
+                               geom=getattr(self.model, "geom", None), state_fn=getattr(self.model, "synthetic_state", None))
 
     def release_model(self):
         raise NotImplementedError

@@ -19,10 +19,13 @@ IC_SOURCES = ("cds", "gfs", "ifs", "synthetic", "file")
 class SyntheticDataSource:
     """ERA5-magnitude random fields, deterministic in (time, seed)."""
 
-    def __init__(self, channel_names=CHANNELS, geom: PanguGeometry | None = None, seed: int = 0):
+    def __init__(self, channel_names=CHANNELS, geom: PanguGeometry | None = None, seed: int = 0, state_fn=None):
+        """``state_fn(seed) -> (C, lat, lon) tensor`` in ``channel_names`` order: the model's own synthetic fields (models other
+        than Pangu); default: Pangu's 69-channel generator on ``geom``."""
         self.channel_names = list(channel_names)
         self.geom = geom or PanguGeometry()
         self.seed = seed
+        self.state_fn = state_fn
 
     @property
     def grid(self):
@@ -30,6 +33,8 @@ class SyntheticDataSource:
 
     def __getitem__(self, time: datetime.datetime) -> np.ndarray:
         h = int(hashlib.sha256(f"{time.isoformat()}|{self.seed}".encode()).hexdigest()[:8], 16)
+        if self.state_fn is not None:
+            return self.state_fn(h).numpy()
         full = synthetic_state(self.geom, seed=h)
         idx = [CHANNELS.index(c) for c in self.channel_names]
         return full[idx].numpy()
@@ -48,7 +53,7 @@ class FileDataSource:
         return da.sel(channel=self.channel_names).values[-1]
 
 
-def get_data_source(channel_names, initial_condition_source: str = "synthetic", geom: PanguGeometry | None = None, **kw):
+def get_data_source(channel_names, initial_condition_source: str = "synthetic", geom: PanguGeometry | None = None, state_fn=None, **kw):
     """Mirror of skyrim.libs.ic.get_data_source.  The network sources of the reference (cds / gfs / ifs)
     are out of scope (no network): they resolve to the synthetic source of the same shape, and the name is
     kept so that file names / logs keep the reference's vocabulary."""
@@ -56,7 +61,7 @@ def get_data_source(channel_names, initial_condition_source: str = "synthetic", 
         raise ValueError(f"Invalid initial condition source: {initial_condition_source}")
     if initial_condition_source == "file":
         return FileDataSource(kw["path"], channel_names)
-    return SyntheticDataSource(channel_names, geom)
+    return SyntheticDataSource(channel_names, geom, state_fn=state_fn)
 
 
 def get_initial_condition_for_model(model, data_source, time: datetime.datetime) -> torch.Tensor:
