@@ -106,7 +106,7 @@ struct EpStrided {
 };
 
 typedef PrecF16x3 PG;
-typedef TileCfg<128, 128, 32, 2, 2> TG;
+typedef TileCfg<128, 256, 32, 2, 4> TG;      // wide N: the fp32 A operand is fetched and split once per 256 output columns
 
 struct BatchStrides { long long a, w, o; };
 

@@ -99,10 +99,13 @@ class SfnoEngine:
         self.lib = load_library()
         self.device = torch.device(device)
         self.prepared = False
+        self.profiling = False            # per-launch timing with events on the launch stream (bench.py / tools)
+        self._events = []
         c = self.cfg
         if c.num_layers < 2:
             raise ValueError("num_layers >= 2 (the first block goes to the internal grid, the last one back)")
         self.state_shape = (c.in_chans, c.n_lat, c.n_lon)
+        self._label = "gemm"
 
     def _stream(self):
         return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
@@ -166,10 +169,32 @@ class SfnoEngine:
         self.prepared = True
 
     # ---- launches ---------------------------------------------------------------------------------- #
+    def _mark(self, label: str, flops: float = 0.0, nbytes: float = 0.0):
+        if self.profiling:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(torch.cuda.current_stream(self.device))
+            self._events.append((label, ev, flops, nbytes))
+
+    def profile_read(self) -> list[dict]:
+        """Per-stage totals since profiling was switched on: [{name, launches, total_ms, flops, bytes}] (stage = label of the launch)."""
+        torch.cuda.synchronize(self.device)
+        out: dict[str, dict] = {}
+        for (label, ev, fl, by), (_, nxt, _, _) in zip(self._events[:-1], self._events[1:]):
+            if label == "end":
+                continue
+            d = out.setdefault(label, dict(name=label, launches=0, total_ms=0.0, flops=0.0, bytes=0.0))
+            d["launches"] += 1
+            d["total_ms"] += ev.elapsed_time(nxt)
+            d["flops"] += fl
+            d["bytes"] += by
+        self._events = []
+        return list(out.values())
+
     def _gemm(self, a, W: _Weight, out, M, K, N, *, a_sm, a_sk, o_sm, o_sn, batch=1, a_sb=0, o_sb=0, a_m1=_BIG, a_sm2=0,
               o_m1=_BIG, o_sm2=0, bias=None, res_pre=None, res_post=None, act=0, a_off=0, o_off=0, w_batched=None):
         if N != W.N or K != W.K:
             raise ValueError(f"GEMM {M}x{N}x{K} against a prepared [{W.N}][{W.K}] matrix")
+        self._mark(self._label, 2.0 * M * N * K * batch, 4.0 * batch * (M * K + M * N * (1 + (res_pre is not None) + (res_post is not None))))
         ptr = lambda t, off=0: None if t is None else t.data_ptr() + 4 * off  # noqa: E731
         d = GemmDesc(ptr(a, a_off), a_sb, a_m1, a_sm, a_sm2, a_sk,
                      W.buf.data_ptr(), (W.w_sb if (batch > 1 if w_batched is None else w_batched) else 0), W.plane, W.ldw,
@@ -178,19 +203,23 @@ class SfnoEngine:
         _check(self.lib.sksfno_gemm_run(ctypes.byref(d), self._stream()), "sksfno_gemm_run")
 
     def _norm(self, x, g, b, out, C, HW):
+        self._mark("norm", 8.0 * C * HW, 16.0 * C * HW)
         _check(self.lib.sksfno_instance_norm(x.data_ptr(), g.data_ptr(), b.data_ptr(), out.data_ptr(), C, HW, self.cfg.eps, self._stream()),
                "sksfno_instance_norm")
 
-    def _pointwise(self, a, W, out, hw, cin, cout, **kw):
+    def _pointwise(self, a, W, out, hw, cin, cout, label="conv1x1", **kw):
         """1x1 convolution on [C][hw] activations: rows = pixels (contiguous), k = channel (stride hw)."""
+        self._label = label
         self._gemm(a, W, out, hw, cin, cout, a_sm=1, a_sk=hw, o_sm=1, o_sn=hw, **kw)
 
     def _analysis(self, x, tr, C):
         """[C][H][W] -> SH coefficients [l][m][C][2] in self.b_coef."""
         c = self.cfg
         H, Wd, Mm, L = tr["n_lat"], tr["n_lon"], c.mmax, c.lmax
+        self._label = "dft"
         self._gemm(x, tr["dft"], self.b_f, C * H, Wd, 2 * Mm, a_sm=Wd, a_sk=1, o_sm=2 * Mm, o_sn=1)
         # per order m: rows (channel, re/im), k = latitude
+        self._label = "legendre_analysis"
         self._gemm(self.b_f, tr["ana"], self.b_coef, 2 * C, H, L, batch=Mm, a_sb=2, a_m1=2, a_sm=1, a_sm2=H * 2 * Mm, a_sk=2 * Mm,
                    o_sb=2 * C, o_sm=1, o_sn=Mm * 2 * C)
 
@@ -198,8 +227,10 @@ class SfnoEngine:
         """SH coefficients [l][m][C][2] -> [C][H][W] (+ epilogue options of the last GEMM)."""
         c = self.cfg
         H, Wd, Mm, L = tr["n_lat"], tr["n_lon"], c.mmax, c.lmax
+        self._label = "legendre_synthesis"
         self._gemm(coef, tr["syn"], self.b_f, 2 * C, L, H, batch=Mm, a_sb=2 * C, a_sm=1, a_sk=Mm * 2 * C,
                    o_sb=2, o_m1=2, o_sm=1, o_sm2=H * 2 * Mm, o_sn=2 * Mm)
+        self._label = "idft"
         self._gemm(self.b_f, tr["idft"], out, C * H, 2 * Mm, Wd, a_sm=2 * Mm, a_sk=1, o_sm=Wd, o_sn=1, **kw)
 
     def step(self, x: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
@@ -213,8 +244,8 @@ class SfnoEngine:
         hw_o = c.n_lat * c.n_lon
         with torch.cuda.device(self.device):
             # encoder: GELU(W1' x + b1') -> W2 . + position embedding
-            self._pointwise(x, self.enc1, self.b_sp, hw_o, c.in_chans, e, bias=self.enc1_b, act=1)
-            self._pointwise(self.b_sp, self.enc2, self.b_y, hw_o, e, e, res_post=self.pos)
+            self._pointwise(x, self.enc1, self.b_sp, hw_o, c.in_chans, e, label="encoder", bias=self.enc1_b, act=1)
+            self._pointwise(self.b_sp, self.enc2, self.b_y, hw_o, e, e, label="encoder", res_post=self.pos)
             cur = self.b_y
             for i, blk in enumerate(self.blocks):
                 tin = self.tr["outer"] if i == 0 else self.tr["inner"]
@@ -228,26 +259,29 @@ class SfnoEngine:
                     self._synthesis(self.b_coef, tout, self.b_res, e)
                     res = self.b_res
                 # dhconv: per degree l, rows = orders m, k = (in channel, re/im) -> (out channel, re/im)
+                self._label = "dhconv"
                 self._gemm(self.b_coef, blk["mix"], self.b_mixed, c.mmax, 2 * e, 2 * e, batch=c.lmax, a_sb=c.mmax * 2 * e, a_sm=2 * e, a_sk=1,
                            o_sb=c.mmax * 2 * e, o_sm=2 * e, o_sn=1)
                 self._synthesis(self.b_mixed, tout, self.b_sp, e)
                 # GELU(filter output + inner skip(residual))
-                self._pointwise(res, blk["skip"], self.b_y, hw_out, e, e, bias=blk["skip_b"], res_pre=self.b_sp, act=1)
+                outer = "_outer" if tout is self.tr["outer"] else ""
+                self._pointwise(res, blk["skip"], self.b_y, hw_out, e, e, label="inner_skip" + outer, bias=blk["skip_b"], res_pre=self.b_sp, act=1)
                 self._norm(self.b_y, blk["n1_g"], blk["n1_b"], self.b_sp, e, hw_out)
                 hbuf = self.b_hid_outer if tout is self.tr["outer"] else self.b_hid
-                self._pointwise(self.b_sp, blk["fc1"], hbuf, hw_out, e, hid, bias=blk["fc1_b"], act=1)
-                self._pointwise(hbuf, blk["fc2"], self.b_y, hw_out, hid, e, bias=blk["fc2_b"], res_post=res)
+                self._pointwise(self.b_sp, blk["fc1"], hbuf, hw_out, e, hid, label="mlp" + outer, bias=blk["fc1_b"], act=1)
+                self._pointwise(hbuf, blk["fc2"], self.b_y, hw_out, hid, e, label="mlp" + outer, bias=blk["fc2_b"], res_post=res)
                 cur = self.b_y
             # decoder on concat(cur, normalised input): W_a cur + b' , then GELU(W_b' x + .), then W2' . + mean
-            self._pointwise(cur, self.dec1a, self.b_sp, hw_o, e, e, bias=self.dec1_b)
-            self._pointwise(x, self.dec1b, self.b_xn, hw_o, c.in_chans, e, res_pre=self.b_sp, act=1)
+            self._pointwise(cur, self.dec1a, self.b_sp, hw_o, e, e, label="decoder", bias=self.dec1_b)
+            self._pointwise(x, self.dec1b, self.b_xn, hw_o, c.in_chans, e, label="decoder", res_pre=self.b_sp, act=1)
             y = out if out is not None else torch.empty((c.out_chans, c.n_lat, c.n_lon), dtype=torch.float32, device=self.device)
             if y.device != self.device or y.dtype != torch.float32 or tuple(y.shape) != (c.out_chans, c.n_lat, c.n_lon) or not y.is_contiguous():
                 raise ValueError("bad output tensor")
             target = self.b_out if y.data_ptr() == x.data_ptr() else y
-            self._pointwise(self.b_xn, self.dec2, target, hw_o, e, c.out_chans, bias=self.dec2_b)
+            self._pointwise(self.b_xn, self.dec2, target, hw_o, e, c.out_chans, label="decoder", bias=self.dec2_b)
             if target is self.b_out:
                 y.view(-1).copy_(self.b_out)
+            self._mark("end")
         return y
 
     def launches_per_step(self) -> int:

@@ -30,3 +30,11 @@ torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / n
 print(f"{1e3 * dt:.1f} ms/step  {1 / dt:.2f} steps/s  {flops_per_step(cfg) / dt / 1e12:.1f} TFLOP/s algorithmic ({flops_per_step(cfg) / 1e12:.2f} TF/step), "
       f"{eng.launches_per_step()} launches, finite {bool(torch.isfinite(xd).all())}", flush=True)
+eng.profiling = True
+for _ in range(3):
+    eng.step(xd, xd)
+st = eng.profile_read()
+tot = sum(d["total_ms"] for d in st)
+for d in sorted(st, key=lambda d: -d["total_ms"]):
+    ms = d["total_ms"] / 3
+    print(f"  {d['name']:22s} {d['launches'] // 3:3d} launches  {ms:7.3f} ms/step ({100 * d['total_ms'] / tot:4.1f} %)  {d['flops'] / 3 / ms / 1e9:8.1f} TFLOP/s dense  {d['bytes'] / 3 / ms / 1e6:7.1f} GB/s", flush=True)
