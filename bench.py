@@ -138,6 +138,93 @@ def api_rollout_rate(precision, geom, params, x_host, dev, n=6):
                     + str(bool(torch.isfinite(torch.from_numpy(out.values[-1])).all()))}
 
 
+def run_sfno(args, rank, local_rank, world, dist):
+    """The same contract for the SFNO row (BASELINE.json configs[2]): one step = one 6-h forward of FourCastNet v2-small on a
+    synthetic 73-channel 721x1440 state resident in HBM; N > 1 = one member per rank + the closing ensemble reduction."""
+    from skyrim_amd.pangu.ensemble import ensemble_mean_spread
+    from skyrim_amd.sfno.engine import SfnoEngine
+    from skyrim_amd.sfno.spec import SfnoConfig, flops_per_step, init_synthetic, synthetic_state
+    cfg = SfnoConfig(n_lat=args.n_lat, n_lon=args.n_lon)
+    params = init_synthetic(cfg, 0)
+    dev = torch.device("cuda", local_rank)
+    eng = SfnoEngine(cfg, dev)
+    eng.load_params(params)
+    x_host = synthetic_state(cfg, rank if world > 1 else 0)
+    x = x_host.to(dev)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        eng.step(x, x)
+    if world > 1:
+        ensemble_mean_spread([x], world)
+    eng.profiling = True
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.step(x, x)
+    if world > 1:
+        ensemble_mean_spread([x], world)
+    sync()
+    elapsed = time.perf_counter() - t0
+    stats = eng.profile_read()
+    eng.profiling = False
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    finite = bool(torch.isfinite(x).all().item())
+    if rank != 0:
+        return
+    f_step = flops_per_step(cfg)
+    dom = max(stats, key=lambda s: s["total_ms"])
+    dom_ms = dom["total_ms"] / dom["launches"]
+    achieved = dom["flops"] / dom["launches"] / (dom_ms * 1e-3)
+    gpu_ms = sum(s["total_ms"] for s in stats) / args.steps
+    out = {
+        "metric": "6-h forecast steps/sec on 721x1440 state, 1/2/4/8 MI355X; per-channel max rel-err vs ref",
+        "value": world * args.steps / elapsed, "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f16", "data": "synthetic",
+        "config": {"workload": f"FourCastNet v2-small (SFNO: embed {cfg.embed_dim}, {cfg.num_layers} layers, scale factor {cfg.scale_factor}) 6-h "
+                               f"autoregressive rollout, {cfg.n_lat}x{cfg.n_lon}x{cfg.in_chans} state, random-init weights, state resident in "
+                               "HBM, 1 ensemble member per GPU",
+                   "precision": "every linear map (1x1 convs, DFT, Legendre, dhconv) as a GEMM with fp16 hi/lo operands, 3 MFMA terms, fp32 "
+                                "accumulate; fp32 activations",
+                   "parallelism": f"member-parallel x{world}" if world > 1 else "single GPU", "finite": finite},
+        "roofline": {"bound": "mfma", "kernel": dom["name"] + " (gemm_strided_kernel)", "achieved": achieved / 1e12, "peak": PEAK_MFMA_BF16 / 1e12,
+                     "unit": "TFLOP/s", "frac": achieved / PEAK_MFMA_BF16, "traffic": None, "avg_launch_ms": dom_ms,
+                     "alg_flops_per_launch": dom["flops"] / dom["launches"],
+                     "note": "dense GEMM FLOPs of the launch (the Legendre / dhconv GEMMs also multiply the l < m zeros)",
+                     "step": {"alg_tflop": f_step / 1e12, "gpu_ms": gpu_ms, "mfma_frac": f_step / (gpu_ms * 1e-3) / PEAK_MFMA_BF16},
+                     "stages": {s["name"]: {"ms_per_step": round(s["total_ms"] / args.steps, 4), "launches_per_step": s["launches"] // args.steps,
+                                            "dense_tflops": round(s["flops"] / (s["total_ms"] * 1e-3) / 1e12, 1)} for s in stats}},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        from oracle import sfno_oracle as O
+        t0 = time.time()
+        with torch.no_grad():
+            mean, std = params["norm.mean"][:, None, None], params["norm.std"][:, None, None]
+            y = torch.nn.functional.gelu(O._conv1x1((x_host - mean) / std, params["encoder.fc1.weight"], params["encoder.fc1.bias"]))
+            y = O._conv1x1(y, params["encoder.fc2.weight"]) + params["pos_embed"]
+        dt = time.time() - t0
+        f_sample = 2.0 * cfg.n_lat * cfg.n_lon * (cfg.in_chans * cfg.embed_dim + cfg.embed_dim ** 2)
+        out["cpu_baseline"] = {"value": 1.0 / (dt * f_step / f_sample), "unit": "steps/s", "cores": torch.get_num_threads(), "kind": "port",
+                               "sample": f"encoder (two 1x1 convolutions + GELU + position embedding) of one {cfg.n_lat}x{cfg.n_lon} step "
+                                         f"({100 * f_sample / f_step:.1f}% of its FLOPs) in {dt:.1f} s, scaled by FLOPs; PyTorch-CPU fp32 restatement"}
+    if world == 1 and not args.no_parity:
+        from oracle import sfno_oracle as O
+        tiny = SfnoConfig(n_lat=97, n_lon=192, in_chans=11, out_chans=11, embed_dim=40, num_layers=4, scale_factor=3)
+        tp, tx = init_synthetic(tiny, 0), synthetic_state(tiny, 0)
+        te = SfnoEngine(tiny, dev)
+        te.load_params(tp)
+        out["parity"] = {"grid": "97x192", "max_rel_err": O.per_channel_rel_err(te.step(tx.to(dev)).cpu(), O.forward(tp, tx, tiny)).max().item(), "bar": 1e-3}
+    print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -149,6 +236,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-alt-modes", action="store_true", help="skip the short runs of the other precision modes")
+    ap.add_argument("--model", default="pangu", choices=["pangu", "sfno"],
+                    help="pangu (default; BASELINE.json's headline configuration) or sfno (FourCastNet v2-small, configs[2])")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo only to "
                     "exercise the multi-rank control flow on a box with fewer GPUs than ranks)")
     args = ap.parse_args()
@@ -172,6 +261,12 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(args.backend)
+
+    if args.model == "sfno":
+        run_sfno(args, rank, local_rank, world, dist)
+        if world > 1:
+            dist.destroy_process_group()
+        return
 
     from skyrim_amd.pangu.engine import DEFAULT_PRECISION, PRECISIONS, PanguEngine
     from skyrim_amd.pangu.ensemble import ensemble_mean_spread
