@@ -21,6 +21,7 @@ extern "C" {
 /* out[b](m, n) = act( sum_k A[b](m, k) W[b][n][k] + bias[n] + res_pre[b](m, n) ) + res_post[b](m, n),  b < batch.
  * A[b](m, k)  = a[b * a_sb + (m / a_m1) * a_sm2 + (m % a_m1) * a_sm + k * a_sk]      (fp32)
  * out[b](m,n) at out[b * o_sb + (m / o_m1) * o_sm2 + (m % o_m1) * o_sm + n * o_sn]   (fp32; res_pre / res_post likewise)
+ * (batch b of a ragged launch: see k_lo_step / m_cap_step below)
  * W[b]        = fp16 hi plane [N][ldw] at w + b * w_sb (elements), lo plane at + w_plane (sksfno_prepare_weight). */
 typedef struct sksfno_gemm {
     const float* a;
@@ -39,6 +40,9 @@ typedef struct sksfno_gemm {
     long long o_sm, o_sm2, o_sn;
     int M, N, K, batch;
     int act;               /* 0 = none, 1 = erf-GELU */
+    /* ragged batches (spherical harmonics are zero for l < m): batch b contracts only k >= (b * k_lo_step) rounded down to a
+     * multiple of 32, and computes only rows m < m_cap0 + b * m_cap_step when m_cap_step > 0 (other rows are left untouched). */
+    int k_lo_step, m_cap0, m_cap_step;
 } sksfno_gemm;
 
 int sksfno_abi_version(void);

@@ -108,7 +108,7 @@ struct EpStrided {
 typedef PrecF16x3 PG;
 typedef TileCfg<128, 256, 32, 2, 4> TG;      // wide N: the fp32 A operand is fetched and split once per 256 output columns
 
-struct BatchStrides { long long a, w, o; };
+struct BatchStrides { long long a, w, o; int k_lo_step, m_cap0, m_cap_step; };
 
 template <bool SWAP>
 __global__ void __launch_bounds__(TG::THREADS) gemm_strided_kernel(GemmArgs<PG, ALStrided, EpStrided> g, BatchStrides bs) {
@@ -119,6 +119,19 @@ __global__ void __launch_bounds__(TG::THREADS) gemm_strided_kernel(GemmArgs<PG, 
     g.ep.out += z * bs.o;
     if (g.ep.res_pre) g.ep.res_pre += z * bs.o;
     if (g.ep.res_post) g.ep.res_post += z * bs.o;
+    if (bs.k_lo_step > 0) {                       // contraction starts at the first 32-aligned k that can be non-zero
+        const int kb = ((int)z * bs.k_lo_step) & ~31;
+        if (kb >= g.K) return;
+        g.al.a += (long long)kb * g.al.sk;
+        g.W += kb;
+        g.K -= kb;
+        g.al.K -= kb;
+    }
+    if (bs.m_cap_step > 0) {
+        const int cap = bs.m_cap0 + (int)z * bs.m_cap_step;
+        if (cap < g.M) { g.M = cap; g.al.M = cap; }
+        if ((int)blockIdx.y * TG::BM >= g.M) return;
+    }
     gemm_body<PG, TG, ALStrided, EpStrided, SWAP>(g, smem);
 }
 
@@ -186,7 +199,7 @@ int sksfno_prepare_weight(const float* src, long long sn, long long sk, int N, i
 
 int sksfno_gemm_run(const sksfno_gemm* d, void* stream) {
     if (!d || !d->a || !d->w || !d->out || d->M <= 0 || d->N <= 0 || d->K <= 0 || d->batch <= 0 || d->a_m1 <= 0 || d->o_m1 <= 0 ||
-        (d->ldw & 7) || d->ldw < d->K || (d->act != 0 && d->act != 1))
+        (d->ldw & 7) || d->ldw < d->K || (d->act != 0 && d->act != 1) || d->k_lo_step < 0 || d->m_cap_step < 0)
         return SKSFNO_E_ARG;
     GemmArgs<PG, ALStrided, EpStrided> g;
     g.al = ALStrided{d->a, d->M, d->K, d->a_m1, d->a_sm, d->a_sm2, d->a_sk};
@@ -195,7 +208,7 @@ int sksfno_gemm_run(const sksfno_gemm* d, void* stream) {
     g.w_plane = d->w_plane;
     g.ldw = d->ldw;
     g.M = d->M; g.N = d->N; g.K = d->K;
-    const BatchStrides bs{d->a_sb, d->w_sb, d->o_sb};
+    const BatchStrides bs{d->a_sb, d->w_sb, d->o_sb, d->k_lo_step, d->m_cap0, d->m_cap_step};
     const dim3 grid((d->N + TG::BN - 1) / TG::BN, (d->M + TG::BM - 1) / TG::BM, d->batch);
     if (grid.y > 65535 || grid.z > 65535) return SKSFNO_E_ARG;
     constexpr int smem = gemm_smem_bytes<PG, TG>() + kEpiScratch;

@@ -34,7 +34,8 @@ class GemmDesc(ctypes.Structure):
                 ("bias", ctypes.c_void_p), ("res_pre", ctypes.c_void_p), ("res_post", ctypes.c_void_p),
                 ("out", ctypes.c_void_p), ("o_sb", ctypes.c_longlong), ("o_m1", ctypes.c_int),
                 ("o_sm", ctypes.c_longlong), ("o_sm2", ctypes.c_longlong), ("o_sn", ctypes.c_longlong),
-                ("M", ctypes.c_int), ("N", ctypes.c_int), ("K", ctypes.c_int), ("batch", ctypes.c_int), ("act", ctypes.c_int)]
+                ("M", ctypes.c_int), ("N", ctypes.c_int), ("K", ctypes.c_int), ("batch", ctypes.c_int), ("act", ctypes.c_int),
+                ("k_lo_step", ctypes.c_int), ("m_cap0", ctypes.c_int), ("m_cap_step", ctypes.c_int)]
 
 
 _lib = None
@@ -163,7 +164,8 @@ class SfnoEngine:
             self.b_hid = buf(hid * hw_i)                  # MLP hidden on the internal grid
             self.b_hid_outer = buf(hid * hw_o)            # MLP hidden of the last block (outer grid)
             self.b_f = buf(e * c.n_lat * 2 * c.mmax)
-            self.b_coef, self.b_mixed = buf(c.lmax * c.mmax * 2 * e), buf(c.lmax * c.mmax * 2 * e)
+            self.b_coef = buf(c.lmax * c.mmax * 2 * e)
+            self.b_mixed = torch.zeros(c.lmax * c.mmax * 2 * e, dtype=torch.float32, device=dev)     # rows m > l are never written
             self.b_out = buf(c.out_chans * hw_o)
             torch.cuda.current_stream(dev).synchronize()
         self.prepared = True
@@ -191,7 +193,7 @@ class SfnoEngine:
         return list(out.values())
 
     def _gemm(self, a, W: _Weight, out, M, K, N, *, a_sm, a_sk, o_sm, o_sn, batch=1, a_sb=0, o_sb=0, a_m1=_BIG, a_sm2=0,
-              o_m1=_BIG, o_sm2=0, bias=None, res_pre=None, res_post=None, act=0, a_off=0, o_off=0, w_batched=None):
+              o_m1=_BIG, o_sm2=0, bias=None, res_pre=None, res_post=None, act=0, a_off=0, o_off=0, w_batched=None, k_lo_step=0, m_cap0=0, m_cap_step=0):
         if N != W.N or K != W.K:
             raise ValueError(f"GEMM {M}x{N}x{K} against a prepared [{W.N}][{W.K}] matrix")
         self._mark(self._label, 2.0 * M * N * K * batch, 4.0 * batch * (M * K + M * N * (1 + (res_pre is not None) + (res_post is not None))))
@@ -199,7 +201,7 @@ class SfnoEngine:
         d = GemmDesc(ptr(a, a_off), a_sb, a_m1, a_sm, a_sm2, a_sk,
                      W.buf.data_ptr(), (W.w_sb if (batch > 1 if w_batched is None else w_batched) else 0), W.plane, W.ldw,
                      ptr(bias), ptr(res_pre, o_off), ptr(res_post, o_off),
-                     ptr(out, o_off), o_sb, o_m1, o_sm, o_sm2, o_sn, M, N, K, batch, act)
+                     ptr(out, o_off), o_sb, o_m1, o_sm, o_sm2, o_sn, M, N, K, batch, act, k_lo_step, m_cap0, m_cap_step)
         _check(self.lib.sksfno_gemm_run(ctypes.byref(d), self._stream()), "sksfno_gemm_run")
 
     def _norm(self, x, g, b, out, C, HW):
@@ -228,8 +230,9 @@ class SfnoEngine:
         c = self.cfg
         H, Wd, Mm, L = tr["n_lat"], tr["n_lon"], c.mmax, c.lmax
         self._label = "legendre_synthesis"
+        # order m only has degrees l >= m: the contraction over l starts at (the 32-aligned floor of) m
         self._gemm(coef, tr["syn"], self.b_f, 2 * C, L, H, batch=Mm, a_sb=2 * C, a_sm=1, a_sk=Mm * 2 * C,
-                   o_sb=2, o_m1=2, o_sm=1, o_sm2=H * 2 * Mm, o_sn=2 * Mm)
+                   o_sb=2, o_m1=2, o_sm=1, o_sm2=H * 2 * Mm, o_sn=2 * Mm, k_lo_step=1)
         self._label = "idft"
         self._gemm(self.b_f, tr["idft"], out, C * H, 2 * Mm, Wd, a_sm=2 * Mm, a_sk=1, o_sm=Wd, o_sn=1, **kw)
 
@@ -261,7 +264,7 @@ class SfnoEngine:
                 # dhconv: per degree l, rows = orders m, k = (in channel, re/im) -> (out channel, re/im)
                 self._label = "dhconv"
                 self._gemm(self.b_coef, blk["mix"], self.b_mixed, c.mmax, 2 * e, 2 * e, batch=c.lmax, a_sb=c.mmax * 2 * e, a_sm=2 * e, a_sk=1,
-                           o_sb=c.mmax * 2 * e, o_sm=2 * e, o_sn=1)
+                           o_sb=c.mmax * 2 * e, o_sm=2 * e, o_sn=1, m_cap0=1, m_cap_step=1)      # degree l has orders m <= l only
                 self._synthesis(self.b_mixed, tout, self.b_sp, e)
                 # GELU(filter output + inner skip(residual))
                 outer = "_outer" if tout is self.tr["outer"] else ""
