@@ -43,6 +43,10 @@ typedef struct sksfno_gemm {
     /* ragged batches (spherical harmonics are zero for l < m): batch b contracts only k >= (b * k_lo_step) rounded down to a
      * multiple of 32, and computes only rows m < m_cap0 + b * m_cap_step when m_cap_step > 0 (other rows are left untouched). */
     int k_lo_step, m_cap0, m_cap_step;
+    /* optional per-k affine applied to A before it is split into fp16 hi/lo: A'(m, k) = A(m, k) * a_kscale[k] + a_kshift[k]
+     * (input normalisation -- raw fields such as geopotential or pressure exceed the fp16 range); both or neither */
+    const float* a_kscale;
+    const float* a_kshift;
 } sksfno_gemm;
 
 int sksfno_abi_version(void);

@@ -25,8 +25,10 @@ struct ALStrided {
     const float* a;
     int M, K, m1;                 // row m -> (m / m1) * sm2 + (m % m1) * sm
     long long sm, sm2, sk;
+    const float* kscale;          // optional per-k affine applied BEFORE the fp16 split: A'(m, k) = A(m, k) * kscale[k] + kshift[k]
+    const float* kshift;          // (input normalisation: raw fields such as geopotential ~2e5 would overflow fp16)
     struct Row { long long off; int ok; };
-    struct Raw { float v[8]; };
+    struct Raw { float v[8]; int k; };
     __device__ __forceinline__ Row row(int m) const {
         if (m >= M) return Row{0, 0};
         const int hi = m / m1, lo = m - hi * m1;
@@ -35,7 +37,9 @@ struct ALStrided {
     __device__ __forceinline__ void issue(const Row& r, int k, Raw& o) const {
 #pragma unroll
         for (int i = 0; i < 8; ++i) o.v[i] = 0.f;
+        o.k = -1;
         if (!r.ok || k >= K) return;
+        o.k = k;
         const float* p = a + r.off + (long long)k * sk;
         if (sk == 1 && k + 8 <= K && ((reinterpret_cast<size_t>(p) & 15) == 0)) {
             const float4 x = *reinterpret_cast<const float4*>(p), y = *reinterpret_cast<const float4*>(p + 4);
@@ -49,6 +53,11 @@ struct ALStrided {
     __device__ __forceinline__ void finish(const Raw& r, float (&v)[8]) const {
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] = r.v[i];
+        if (kscale != nullptr && r.k >= 0) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (r.k + i < K) v[i] = v[i] * kscale[r.k + i] + kshift[r.k + i];
+        }
     }
     __device__ __forceinline__ uint4 direct(const Raw&) const { return make_uint4(0, 0, 0, 0); }
 };
@@ -199,10 +208,11 @@ int sksfno_prepare_weight(const float* src, long long sn, long long sk, int N, i
 
 int sksfno_gemm_run(const sksfno_gemm* d, void* stream) {
     if (!d || !d->a || !d->w || !d->out || d->M <= 0 || d->N <= 0 || d->K <= 0 || d->batch <= 0 || d->a_m1 <= 0 || d->o_m1 <= 0 ||
-        (d->ldw & 7) || d->ldw < d->K || (d->act != 0 && d->act != 1) || d->k_lo_step < 0 || d->m_cap_step < 0)
+        (d->ldw & 7) || d->ldw < d->K || (d->act != 0 && d->act != 1) || d->k_lo_step < 0 || d->m_cap_step < 0 ||
+        (d->a_kscale == nullptr) != (d->a_kshift == nullptr) || (d->a_kscale != nullptr && d->k_lo_step > 0))
         return SKSFNO_E_ARG;
     GemmArgs<PG, ALStrided, EpStrided> g;
-    g.al = ALStrided{d->a, d->M, d->K, d->a_m1, d->a_sm, d->a_sm2, d->a_sk};
+    g.al = ALStrided{d->a, d->M, d->K, d->a_m1, d->a_sm, d->a_sm2, d->a_sk, d->a_kscale, d->a_kshift};
     g.ep = EpStrided{d->out, d->bias, d->res_pre, d->res_post, d->o_m1, d->act, d->o_sm, d->o_sm2, d->o_sn};
     g.W = static_cast<const f16*>(d->w);
     g.w_plane = d->w_plane;

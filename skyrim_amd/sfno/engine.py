@@ -8,8 +8,9 @@ One step = 2 + 12 * num_layers (+ 2 per resolution change) + 3 launches.  Data l
     SH coefficients        [l][m][C][re, im]              channel-last so that the per-degree complex channel mixing is a
                                                           plain GEMM over k = (channel, re/im)
 
-Input normalisation, output de-normalisation and the big-skip concat are folded into the encoder / decoder weights at
-prepare time (exact algebra): the kernels read the raw state and write physical units.  There is no CPU fallback.
+The kernels read the raw state and write physical units: the input normalisation is a per-channel affine in the loader of
+the two GEMMs that read the state (before the fp16 split: raw geopotential / pressure exceed the fp16 range), the output
+de-normalisation is folded into the decoder's last matrix, the big-skip concat is two GEMMs into one accumulator chain.  There is no CPU fallback.
 """
 from __future__ import annotations
 
@@ -35,7 +36,8 @@ class GemmDesc(ctypes.Structure):
                 ("out", ctypes.c_void_p), ("o_sb", ctypes.c_longlong), ("o_m1", ctypes.c_int),
                 ("o_sm", ctypes.c_longlong), ("o_sm2", ctypes.c_longlong), ("o_sn", ctypes.c_longlong),
                 ("M", ctypes.c_int), ("N", ctypes.c_int), ("K", ctypes.c_int), ("batch", ctypes.c_int), ("act", ctypes.c_int),
-                ("k_lo_step", ctypes.c_int), ("m_cap0", ctypes.c_int), ("m_cap_step", ctypes.c_int)]
+                ("k_lo_step", ctypes.c_int), ("m_cap0", ctypes.c_int), ("m_cap_step", ctypes.c_int),
+                ("a_kscale", ctypes.c_void_p), ("a_kshift", ctypes.c_void_p)]
 
 
 _lib = None
@@ -122,8 +124,11 @@ class SfnoEngine:
         with torch.cuda.device(dev):
             f32 = lambda t: t.float().contiguous().to(dev)  # noqa: E731
             mean, std = p["norm.mean"], p["norm.std"]
-            self.enc1 = _Weight(self, p["encoder.fc1.weight"] / std[None, :])
-            self.enc1_b = f32(p["encoder.fc1.bias"] - p["encoder.fc1.weight"] @ (mean / std))
+            # the input normalisation is applied by the GEMM's loader BEFORE the fp16 split (raw geopotential / pressure exceed
+            # the fp16 range), the output de-normalisation is folded into the decoder's last matrix
+            self.in_scale, self.in_shift = f32(1.0 / std), f32(-mean / std)
+            self.enc1 = _Weight(self, p["encoder.fc1.weight"])
+            self.enc1_b = f32(p["encoder.fc1.bias"])
             self.enc2 = _Weight(self, p["encoder.fc2.weight"])
             self.pos = f32(p["pos_embed"])
             e = c.embed_dim
@@ -145,8 +150,8 @@ class SfnoEngine:
                 del mix
             wd = p["decoder.fc1.weight"]
             self.dec1a = _Weight(self, wd[:, :e])
-            self.dec1b = _Weight(self, wd[:, e:] / std[None, :])
-            self.dec1_b = f32(p["decoder.fc1.bias"] - wd[:, e:] @ (mean / std))
+            self.dec1b = _Weight(self, wd[:, e:])
+            self.dec1_b = f32(p["decoder.fc1.bias"])
             self.dec2 = _Weight(self, p["decoder.fc2.weight"] * std[: c.out_chans, None])
             self.dec2_b = f32(mean[: c.out_chans])
             # transforms: outer (equiangular 721 x 1440) and inner (Legendre-Gauss h x w)
@@ -193,7 +198,7 @@ class SfnoEngine:
         return list(out.values())
 
     def _gemm(self, a, W: _Weight, out, M, K, N, *, a_sm, a_sk, o_sm, o_sn, batch=1, a_sb=0, o_sb=0, a_m1=_BIG, a_sm2=0,
-              o_m1=_BIG, o_sm2=0, bias=None, res_pre=None, res_post=None, act=0, a_off=0, o_off=0, w_batched=None, k_lo_step=0, m_cap0=0, m_cap_step=0):
+              o_m1=_BIG, o_sm2=0, bias=None, res_pre=None, res_post=None, act=0, a_off=0, o_off=0, w_batched=None, k_lo_step=0, m_cap0=0, m_cap_step=0, a_kscale=None, a_kshift=None):
         if N != W.N or K != W.K:
             raise ValueError(f"GEMM {M}x{N}x{K} against a prepared [{W.N}][{W.K}] matrix")
         self._mark(self._label, 2.0 * M * N * K * batch, 4.0 * batch * (M * K + M * N * (1 + (res_pre is not None) + (res_post is not None))))
@@ -201,7 +206,7 @@ class SfnoEngine:
         d = GemmDesc(ptr(a, a_off), a_sb, a_m1, a_sm, a_sm2, a_sk,
                      W.buf.data_ptr(), (W.w_sb if (batch > 1 if w_batched is None else w_batched) else 0), W.plane, W.ldw,
                      ptr(bias), ptr(res_pre, o_off), ptr(res_post, o_off),
-                     ptr(out, o_off), o_sb, o_m1, o_sm, o_sm2, o_sn, M, N, K, batch, act, k_lo_step, m_cap0, m_cap_step)
+                     ptr(out, o_off), o_sb, o_m1, o_sm, o_sm2, o_sn, M, N, K, batch, act, k_lo_step, m_cap0, m_cap_step, ptr(a_kscale), ptr(a_kshift))
         _check(self.lib.sksfno_gemm_run(ctypes.byref(d), self._stream()), "sksfno_gemm_run")
 
     def _norm(self, x, g, b, out, C, HW):
@@ -247,7 +252,8 @@ class SfnoEngine:
         hw_o = c.n_lat * c.n_lon
         with torch.cuda.device(self.device):
             # encoder: GELU(W1' x + b1') -> W2 . + position embedding
-            self._pointwise(x, self.enc1, self.b_sp, hw_o, c.in_chans, e, label="encoder", bias=self.enc1_b, act=1)
+            self._pointwise(x, self.enc1, self.b_sp, hw_o, c.in_chans, e, label="encoder", bias=self.enc1_b, act=1,
+                            a_kscale=self.in_scale, a_kshift=self.in_shift)
             self._pointwise(self.b_sp, self.enc2, self.b_y, hw_o, e, e, label="encoder", res_post=self.pos)
             cur = self.b_y
             for i, blk in enumerate(self.blocks):
@@ -276,7 +282,8 @@ class SfnoEngine:
                 cur = self.b_y
             # decoder on concat(cur, normalised input): W_a cur + b' , then GELU(W_b' x + .), then W2' . + mean
             self._pointwise(cur, self.dec1a, self.b_sp, hw_o, e, e, label="decoder", bias=self.dec1_b)
-            self._pointwise(x, self.dec1b, self.b_xn, hw_o, c.in_chans, e, label="decoder", res_pre=self.b_sp, act=1)
+            self._pointwise(x, self.dec1b, self.b_xn, hw_o, c.in_chans, e, label="decoder", res_pre=self.b_sp, act=1,
+                            a_kscale=self.in_scale, a_kshift=self.in_shift)
             y = out if out is not None else torch.empty((c.out_chans, c.n_lat, c.n_lon), dtype=torch.float32, device=self.device)
             if y.device != self.device or y.dtype != torch.float32 or tuple(y.shape) != (c.out_chans, c.n_lat, c.n_lon) or not y.is_contiguous():
                 raise ValueError("bad output tensor")

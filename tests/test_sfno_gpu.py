@@ -75,6 +75,25 @@ def test_longitude_rotation_equivariance(case):
     assert O.per_channel_rel_err(torch.roll(y2, -s, dims=-1).cpu(), y.cpu()).max().item() < 1e-4
 
 
+def test_physical_magnitudes_do_not_overflow_fp16():
+    """Geopotential (~2e5 m2/s2) and pressure (~1e5 Pa) exceed the fp16 range: the state must be normalised BEFORE the
+    hi/lo fp16 split of the GEMM operands (loader-side affine), not through folded weights."""
+    from skyrim_amd.sfno.engine import SfnoEngine
+    cfg = CONFIGS["tiny"]
+    params = dict(init_synthetic(cfg, 1))
+    params["norm.mean"] = torch.tensor([2.0e5, 1.013e5, 5.5e4, 280.0, -3.0])
+    params["norm.std"] = torch.tensor([3.0e3, 1.2e3, 9.0e2, 15.0, 8.0])
+    z = (synthetic_state(cfg, 1) - init_synthetic(cfg, 1)["norm.mean"][:, None, None]) / init_synthetic(cfg, 1)["norm.std"][:, None, None]
+    x = (params["norm.mean"][:, None, None] + params["norm.std"][:, None, None] * z).contiguous()
+    eng = SfnoEngine(cfg, "cuda:0")
+    eng.load_params(params)
+    y = eng.step(x.cuda())
+    assert torch.isfinite(y).all()
+    ref = O.forward(params, x, cfg)
+    err = ((y.cpu().double() - ref.double()).abs().amax(dim=(-2, -1)) / params["norm.std"].double()).max().item()    # in units of each channel's std
+    assert err < 1e-3, err
+
+
 def test_gemm_building_block_against_float64():
     """One sksfno_gemm_run with every feature on: two-level row index on both sides, batch, bias, both residuals, GELU, K / N tails."""
     from skyrim_amd.sfno import engine as E
