@@ -83,23 +83,68 @@ struct EpStrided {
         if (res_post) v += res_post[o];
         return v;
     }
+    // Loads before stores (epilogues.h): on gfx950 a load issued after a store waits for that store's acknowledgement, so the
+    // bias is read once up front and the residual operands of row group a + 1 are in flight while group a is computed and
+    // stored; only the rare element-wise path (two-level rows, tails, unaligned) loads inside the store loop.
     template <class TC, bool SWAP>
     __device__ __forceinline__ void run(f32x4 (&acc)[TC::FM][TC::FN], int m0w, int n0w, int lane, int, int, char*, int M, int N, int) const {
+        constexpr int FM = TC::FM, FN = TC::FN;
         const int l15 = lane & 15, l4 = (lane >> 4) * 4;
+        const bool aligned = (reinterpret_cast<size_t>(out) & 15) == 0 && (res_pre == nullptr || (reinterpret_cast<size_t>(res_pre) & 15) == 0) &&
+                             (res_post == nullptr || (reinterpret_cast<size_t>(res_post) & 15) == 0);
+        float4 bv[FN];                                   // SWAP: bias of 4 consecutive columns; else .x = the lane's column
 #pragma unroll
-        for (int a = 0; a < TC::FM; ++a)
+        for (int b = 0; b < FN; ++b) {
+            const int n = n0w + b * 16 + (SWAP ? l4 : l15);
+            bv[b] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (bias != nullptr && n < N) {
+                if (SWAP) {
+                    bv[b].x = bias[n];
+                    if (n + 1 < N) bv[b].y = bias[n + 1];
+                    if (n + 2 < N) bv[b].z = bias[n + 2];
+                    if (n + 3 < N) bv[b].w = bias[n + 3];
+                } else {
+                    bv[b].x = bv[b].y = bv[b].z = bv[b].w = bias[n];
+                }
+            }
+        }
+        long long off[2][FN];
+        bool vec[2][FN];
+        float4 rp[2][FN], rq[2][FN];
+        auto prefetch = [&](int a, int s) {
 #pragma unroll
-            for (int b = 0; b < TC::FN; ++b) {
-                // SWAP: 4 consecutive n of one row; else 4 consecutive rows of one column
+            for (int b = 0; b < FN; ++b) {
+                const int m = m0w + a * 16 + (SWAP ? l15 : l4), n = n0w + b * 16 + (SWAP ? l4 : l15);
+                vec[s][b] = false;
+                rp[s][b] = make_float4(0.f, 0.f, 0.f, 0.f);
+                rq[s][b] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (m >= M || n >= N) continue;
+                off[s][b] = addr(m, n);
+                const bool v = (SWAP ? (sn == 1 && n + 3 < N) : (sm == 1 && m1 >= M && m + 3 < M)) && (off[s][b] & 3) == 0 && aligned;
+                vec[s][b] = v;
+                if (v) {
+                    if (res_pre) rp[s][b] = *reinterpret_cast<const float4*>(res_pre + off[s][b]);
+                    if (res_post) rq[s][b] = *reinterpret_cast<const float4*>(res_post + off[s][b]);
+                }
+            }
+        };
+        prefetch(0, 0);
+#pragma unroll
+        for (int a = 0; a < FM; ++a) {
+            const int s = a & 1;
+            if (a + 1 < FM) prefetch(a + 1, s ^ 1);
+#pragma unroll
+            for (int b = 0; b < FN; ++b) {
                 const int m = m0w + a * 16 + (SWAP ? l15 : l4), n = n0w + b * 16 + (SWAP ? l4 : l15);
                 if (m >= M || n >= N) continue;
-                const long long o0 = addr(m, n);
-                const bool vec = SWAP ? (sn == 1 && n + 3 < N) : (sm == 1 && m1 >= M && m + 3 < M);
-                if (vec && (o0 & 3) == 0 && (reinterpret_cast<size_t>(out) & 15) == 0) {
-                    float v[4];
+                if (vec[s][b]) {
+                    float v[4] = {acc[a][b][0] + bv[b].x + rp[s][b].x, acc[a][b][1] + bv[b].y + rp[s][b].y,
+                                  acc[a][b][2] + bv[b].z + rp[s][b].z, acc[a][b][3] + bv[b].w + rp[s][b].w};
+                    if (act == 1) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = post(acc[a][b][r], o0 + r, SWAP ? n + r : n);
-                    *reinterpret_cast<float4*>(out + o0) = make_float4(v[0], v[1], v[2], v[3]);
+                        for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+                    }
+                    *reinterpret_cast<float4*>(out + off[s][b]) = make_float4(v[0] + rq[s][b].x, v[1] + rq[s][b].y, v[2] + rq[s][b].z, v[3] + rq[s][b].w);
                 } else {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
@@ -111,6 +156,7 @@ struct EpStrided {
                     }
                 }
             }
+        }
     }
 };
 
