@@ -4,9 +4,10 @@ HIP kernels of include/skyrim_sfno.h (libskyrim_sfno.so, loaded through ctypes; 
 One step = 2 + 12 * num_layers (+ 2 per resolution change) + 3 launches.  Data layouts (all fp32):
 
     activations            [C][H][W]                      (the reference's NCHW without the batch)
-    longitude spectrum     [C][H][mmax][re, im]           truncated real DFT, m < mmax
-    SH coefficients        [l][m][C][re, im]              channel-last so that the per-degree complex channel mixing is a
-                                                          plain GEMM over k = (channel, re/im)
+    longitude spectrum     [mmax][re, im][C][H padded]    truncated real DFT, m < mmax; order-major so that the Legendre
+                                                          GEMM of one order reads / writes contiguous latitudes
+    SH coefficients        [l][m][re, im][C]              (re/im, channel) last so that the per-degree complex channel mixing
+                                                          is a plain GEMM over k = (re/im, channel)
 
 The kernels read the raw state and write physical units: the input normalisation is a per-channel affine in the loader of
 the two GEMMs that read the state (before the fp16 split: raw geopotential / pressure exceed the fp16 range), the output
@@ -138,10 +139,10 @@ class SfnoEngine:
                 fw = g("filter.weight")                               # [in][out][l][2]
                 wr, wi = fw[..., 0].permute(2, 1, 0), fw[..., 1].permute(2, 1, 0)      # [l][out][in]
                 mix = torch.empty(c.lmax, 2 * e, 2 * e, dtype=torch.float32)
-                mix[:, 0::2, 0::2] = wr
-                mix[:, 0::2, 1::2] = -wi
-                mix[:, 1::2, 0::2] = wi
-                mix[:, 1::2, 1::2] = wr
+                mix[:, :e, :e] = wr                                   # rows (re/im out, channel out), cols (re/im in, channel in)
+                mix[:, :e, e:] = -wi
+                mix[:, e:, :e] = wi
+                mix[:, e:, e:] = wr
                 self.blocks.append(dict(
                     n0_g=f32(g("norm0.weight")), n0_b=f32(g("norm0.bias")), n1_g=f32(g("norm1.weight")), n1_b=f32(g("norm1.bias")),
                     mix=_Weight(self, mix), skip=_Weight(self, g("inner_skip.weight")), skip_b=f32(g("inner_skip.bias")),
@@ -168,7 +169,8 @@ class SfnoEngine:
             self.b_y, self.b_xn, self.b_sp, self.b_res = buf(e * hw_o), buf(e * hw_o), buf(e * hw_o), buf(e * hw_o)
             self.b_hid = buf(hid * hw_i)                  # MLP hidden on the internal grid
             self.b_hid_outer = buf(hid * hw_o)            # MLP hidden of the last block (outer grid)
-            self.b_f = buf(e * c.n_lat * 2 * c.mmax)
+            self.ldl = (c.n_lat + 3) // 4 * 4                 # padded latitude count of the longitude-spectrum buffer
+            self.b_f = buf(2 * c.mmax * e * self.ldl)
             self.b_coef = buf(c.lmax * c.mmax * 2 * e)
             self.b_mixed = torch.zeros(c.lmax * c.mmax * 2 * e, dtype=torch.float32, device=dev)     # rows m > l are never written
             self.b_out = buf(c.out_chans * hw_o)
@@ -220,26 +222,28 @@ class SfnoEngine:
         self._gemm(a, W, out, hw, cin, cout, a_sm=1, a_sk=hw, o_sm=1, o_sn=hw, **kw)
 
     def _analysis(self, x, tr, C):
-        """[C][H][W] -> SH coefficients [l][m][C][2] in self.b_coef."""
+        """[C][H][W] -> SH coefficients [l][m][re/im][C] in self.b_coef."""
         c = self.cfg
-        H, Wd, Mm, L = tr["n_lat"], tr["n_lon"], c.mmax, c.lmax
+        H, Wd, Mm, L, ldl = tr["n_lat"], tr["n_lon"], c.mmax, c.lmax, self.ldl
+        # truncated DFT, one batch per channel: rows = latitudes, k = longitude -> spectrum [order, re/im][C][ldl] (order-major, so
+        # that the Legendre GEMM of one order reads k = latitude contiguously)
         self._label = "dft"
-        self._gemm(x, tr["dft"], self.b_f, C * H, Wd, 2 * Mm, a_sm=Wd, a_sk=1, o_sm=2 * Mm, o_sn=1)
-        # per order m: rows (channel, re/im), k = latitude
+        self._gemm(x, tr["dft"], self.b_f, H, Wd, 2 * Mm, batch=C, a_sb=H * Wd, a_sm=Wd, a_sk=1, o_sb=ldl, o_sm=1, o_sn=C * ldl, w_batched=False)
+        # per order m: rows (re/im, channel), k = latitude
         self._label = "legendre_analysis"
-        self._gemm(self.b_f, tr["ana"], self.b_coef, 2 * C, H, L, batch=Mm, a_sb=2, a_m1=2, a_sm=1, a_sm2=H * 2 * Mm, a_sk=2 * Mm,
+        self._gemm(self.b_f, tr["ana"], self.b_coef, 2 * C, H, L, batch=Mm, a_sb=2 * C * ldl, a_sm=ldl, a_sk=1,
                    o_sb=2 * C, o_sm=1, o_sn=Mm * 2 * C)
 
     def _synthesis(self, coef, tr, out, C, **kw):
-        """SH coefficients [l][m][C][2] -> [C][H][W] (+ epilogue options of the last GEMM)."""
+        """SH coefficients [l][m][re/im][C] -> [C][H][W] (+ epilogue options of the last GEMM)."""
         c = self.cfg
-        H, Wd, Mm, L = tr["n_lat"], tr["n_lon"], c.mmax, c.lmax
+        H, Wd, Mm, L, ldl = tr["n_lat"], tr["n_lon"], c.mmax, c.lmax, self.ldl
         self._label = "legendre_synthesis"
         # order m only has degrees l >= m: the contraction over l starts at (the 32-aligned floor of) m
         self._gemm(coef, tr["syn"], self.b_f, 2 * C, L, H, batch=Mm, a_sb=2 * C, a_sm=1, a_sk=Mm * 2 * C,
-                   o_sb=2, o_m1=2, o_sm=1, o_sm2=H * 2 * Mm, o_sn=2 * Mm, k_lo_step=1)
+                   o_sb=2 * C * ldl, o_sm=ldl, o_sn=1, k_lo_step=1)
         self._label = "idft"
-        self._gemm(self.b_f, tr["idft"], out, C * H, 2 * Mm, Wd, a_sm=2 * Mm, a_sk=1, o_sm=Wd, o_sn=1, **kw)
+        self._gemm(self.b_f, tr["idft"], out, H, 2 * Mm, Wd, batch=C, a_sb=ldl, a_sm=1, a_sk=C * ldl, o_sb=H * Wd, o_sm=Wd, o_sn=1, w_batched=False, **kw)
 
     def step(self, x: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
         """One 6-h step: fp32 (in_chans, n_lat, n_lon) on the engine device -> (out_chans, n_lat, n_lon)."""
