@@ -47,6 +47,11 @@ typedef struct sksfno_gemm {
      * (input normalisation -- raw fields such as geopotential or pressure exceed the fp16 range); both or neither */
     const float* a_kscale;
     const float* a_kshift;
+    /* optional second A source for k >= a2_k_split (concatenation along K, e.g. the big-skip concat of the decoder): same row
+     * addressing as `a`, k stride a2_sk; a2_k_split a multiple of 8; batch == 1 */
+    const float* a2;
+    long long a2_sk;
+    int a2_k_split;
 } sksfno_gemm;
 
 int sksfno_abi_version(void);

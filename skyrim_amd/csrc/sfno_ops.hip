@@ -27,6 +27,9 @@ struct ALStrided {
     long long sm, sm2, sk;
     const float* kscale;          // optional per-k affine applied BEFORE the fp16 split: A'(m, k) = A(m, k) * kscale[k] + kshift[k]
     const float* kshift;          // (input normalisation: raw fields such as geopotential ~2e5 would overflow fp16)
+    const float* a2;              // optional second source for k >= k_split (concat along K; same row addressing, k stride sk2)
+    long long sk2;
+    int k_split;                  // multiple of 8
     struct Row { long long off; int ok; };
     struct Raw { float v[8]; int k; };
     __device__ __forceinline__ Row row(int m) const {
@@ -40,14 +43,16 @@ struct ALStrided {
         o.k = -1;
         if (!r.ok || k >= K) return;
         o.k = k;
-        const float* p = a + r.off + (long long)k * sk;
-        if (sk == 1 && k + 8 <= K && ((reinterpret_cast<size_t>(p) & 15) == 0)) {
+        const bool second = a2 != nullptr && k >= k_split;
+        const long long skk = second ? sk2 : sk;
+        const float* p = second ? a2 + r.off + (long long)(k - k_split) * sk2 : a + r.off + (long long)k * sk;
+        if (skk == 1 && k + 8 <= K && ((reinterpret_cast<size_t>(p) & 15) == 0)) {
             const float4 x = *reinterpret_cast<const float4*>(p), y = *reinterpret_cast<const float4*>(p + 4);
             o.v[0] = x.x; o.v[1] = x.y; o.v[2] = x.z; o.v[3] = x.w; o.v[4] = y.x; o.v[5] = y.y; o.v[6] = y.z; o.v[7] = y.w;
         } else {
 #pragma unroll
             for (int i = 0; i < 8; ++i)
-                if (k + i < K) o.v[i] = p[(long long)i * sk];
+                if (k + i < K) o.v[i] = p[(long long)i * skk];
         }
     }
     __device__ __forceinline__ void finish(const Raw& r, float (&v)[8]) const {
@@ -209,24 +214,24 @@ __global__ void __launch_bounds__(1024) instance_norm_kernel(const float* __rest
     const float* xc = x + (long long)blockIdx.x * HW;
     float* oc = out + (long long)blockIdx.x * HW;
     const bool v4 = (HW & 3) == 0;
-    float s = 0.f;
-    if (v4) {
-        for (long long i = threadIdx.x; i < HW / 4; i += blockDim.x) { const float4 v = reinterpret_cast<const float4*>(xc)[i]; s += (v.x + v.y) + (v.z + v.w); }
-    } else {
-        for (long long i = threadIdx.x; i < HW; i += blockDim.x) s += xc[i];
-    }
-    const float mean = block_sum(s, red) / (float)HW;
-    float q = 0.f;
+    // one pass for both moments, shifted by the channel's first value (var = E[(x-p)^2] - E[x-p]^2 keeps its digits as long as
+    // |mean - p| is a few standard deviations): 2 reads + 1 write of the tensor instead of 3 + 1
+    const float pv = xc[0];
+    float s = 0.f, q = 0.f;
     if (v4) {
         for (long long i = threadIdx.x; i < HW / 4; i += blockDim.x) {
             const float4 v = reinterpret_cast<const float4*>(xc)[i];
-            const float a = v.x - mean, b = v.y - mean, c = v.z - mean, d = v.w - mean;
+            const float a = v.x - pv, b = v.y - pv, c = v.z - pv, d = v.w - pv;
+            s += (a + b) + (c + d);
             q += (a * a + b * b) + (c * c + d * d);
         }
     } else {
-        for (long long i = threadIdx.x; i < HW; i += blockDim.x) { const float d = xc[i] - mean; q += d * d; }
+        for (long long i = threadIdx.x; i < HW; i += blockDim.x) { const float d = xc[i] - pv; s += d; q += d * d; }
     }
-    const float rstd = rsqrtf(block_sum(q, red) / (float)HW + eps);
+    const float m1 = block_sum(s, red) / (float)HW;
+    const float m2 = block_sum(q, red) / (float)HW;
+    const float mean = pv + m1;
+    const float rstd = rsqrtf(fmaxf(m2 - m1 * m1, 0.f) + eps);
     const float g = gamma[blockIdx.x] * rstd, b = beta[blockIdx.x] - mean * g;
     if (v4) {
         for (long long i = threadIdx.x; i < HW / 4; i += blockDim.x) {
@@ -255,10 +260,11 @@ int sksfno_prepare_weight(const float* src, long long sn, long long sk, int N, i
 int sksfno_gemm_run(const sksfno_gemm* d, void* stream) {
     if (!d || !d->a || !d->w || !d->out || d->M <= 0 || d->N <= 0 || d->K <= 0 || d->batch <= 0 || d->a_m1 <= 0 || d->o_m1 <= 0 ||
         (d->ldw & 7) || d->ldw < d->K || (d->act != 0 && d->act != 1) || d->k_lo_step < 0 || d->m_cap_step < 0 ||
-        (d->a_kscale == nullptr) != (d->a_kshift == nullptr) || (d->a_kscale != nullptr && d->k_lo_step > 0))
+        (d->a_kscale == nullptr) != (d->a_kshift == nullptr) || (d->a_kscale != nullptr && d->k_lo_step > 0) ||
+        (d->a2 != nullptr && (d->a2_k_split <= 0 || (d->a2_k_split & 7) || d->a2_k_split >= d->K || d->k_lo_step > 0 || d->batch != 1)))
         return SKSFNO_E_ARG;
     GemmArgs<PG, ALStrided, EpStrided> g;
-    g.al = ALStrided{d->a, d->M, d->K, d->a_m1, d->a_sm, d->a_sm2, d->a_sk, d->a_kscale, d->a_kshift};
+    g.al = ALStrided{d->a, d->M, d->K, d->a_m1, d->a_sm, d->a_sm2, d->a_sk, d->a_kscale, d->a_kshift, d->a2, d->a2_sk, d->a2_k_split};
     g.ep = EpStrided{d->out, d->bias, d->res_pre, d->res_post, d->o_m1, d->act, d->o_sm, d->o_sm2, d->o_sn};
     g.W = static_cast<const f16*>(d->w);
     g.w_plane = d->w_plane;

@@ -1,7 +1,7 @@
 """SFNO (FourCastNet v2-small) 6-h step on one MI355X: the host owns buffers and call order, every FLOP runs in the
 HIP kernels of include/skyrim_sfno.h (libskyrim_sfno.so, loaded through ctypes; PyTorch is device memory + streams).
 
-One step = 2 + 12 * num_layers (+ 2 per resolution change) + 3 launches.  Data layouts (all fp32):
+One step = 88 launches at the default depth (8 blocks).  Data layouts (all fp32):
 
     activations            [C][H][W]                      (the reference's NCHW without the batch)
     longitude spectrum     [mmax][re, im][C][H padded]    truncated real DFT, m < mmax; order-major so that the Legendre
@@ -38,7 +38,8 @@ class GemmDesc(ctypes.Structure):
                 ("o_sm", ctypes.c_longlong), ("o_sm2", ctypes.c_longlong), ("o_sn", ctypes.c_longlong),
                 ("M", ctypes.c_int), ("N", ctypes.c_int), ("K", ctypes.c_int), ("batch", ctypes.c_int), ("act", ctypes.c_int),
                 ("k_lo_step", ctypes.c_int), ("m_cap0", ctypes.c_int), ("m_cap_step", ctypes.c_int),
-                ("a_kscale", ctypes.c_void_p), ("a_kshift", ctypes.c_void_p)]
+                ("a_kscale", ctypes.c_void_p), ("a_kshift", ctypes.c_void_p),
+                ("a2", ctypes.c_void_p), ("a2_sk", ctypes.c_longlong), ("a2_k_split", ctypes.c_int)]
 
 
 _lib = None
@@ -149,9 +150,17 @@ class SfnoEngine:
                     fc1=_Weight(self, g("mlp.fc1.weight")), fc1_b=f32(g("mlp.fc1.bias")),
                     fc2=_Weight(self, g("mlp.fc2.weight")), fc2_b=f32(g("mlp.fc2.bias"))))
                 del mix
+            # decoder.fc1 acts on concat(features, normalised input): one GEMM with two A sources along K (k < e: features,
+            # k >= e: the raw state, normalised by the loader's per-k affine) when e is a multiple of 8, else two GEMMs
             wd = p["decoder.fc1.weight"]
-            self.dec1a = _Weight(self, wd[:, :e])
-            self.dec1b = _Weight(self, wd[:, e:])
+            self.dec_fused = e % 8 == 0
+            if self.dec_fused:
+                self.dec1 = _Weight(self, wd)
+                self.dec_scale = f32(torch.cat([torch.ones(e, dtype=torch.float64), 1.0 / std]))
+                self.dec_shift = f32(torch.cat([torch.zeros(e, dtype=torch.float64), -mean / std]))
+            else:
+                self.dec1a = _Weight(self, wd[:, :e])
+                self.dec1b = _Weight(self, wd[:, e:])
             self.dec1_b = f32(p["decoder.fc1.bias"])
             self.dec2 = _Weight(self, p["decoder.fc2.weight"] * std[: c.out_chans, None])
             self.dec2_b = f32(mean[: c.out_chans])
@@ -200,7 +209,7 @@ class SfnoEngine:
         return list(out.values())
 
     def _gemm(self, a, W: _Weight, out, M, K, N, *, a_sm, a_sk, o_sm, o_sn, batch=1, a_sb=0, o_sb=0, a_m1=_BIG, a_sm2=0,
-              o_m1=_BIG, o_sm2=0, bias=None, res_pre=None, res_post=None, act=0, a_off=0, o_off=0, w_batched=None, k_lo_step=0, m_cap0=0, m_cap_step=0, a_kscale=None, a_kshift=None):
+              o_m1=_BIG, o_sm2=0, bias=None, res_pre=None, res_post=None, act=0, a_off=0, o_off=0, w_batched=None, k_lo_step=0, m_cap0=0, m_cap_step=0, a_kscale=None, a_kshift=None, a2=None, a2_sk=0, a2_k_split=0):
         if N != W.N or K != W.K:
             raise ValueError(f"GEMM {M}x{N}x{K} against a prepared [{W.N}][{W.K}] matrix")
         self._mark(self._label, 2.0 * M * N * K * batch, 4.0 * batch * (M * K + M * N * (1 + (res_pre is not None) + (res_post is not None))))
@@ -208,7 +217,7 @@ class SfnoEngine:
         d = GemmDesc(ptr(a, a_off), a_sb, a_m1, a_sm, a_sm2, a_sk,
                      W.buf.data_ptr(), (W.w_sb if (batch > 1 if w_batched is None else w_batched) else 0), W.plane, W.ldw,
                      ptr(bias), ptr(res_pre, o_off), ptr(res_post, o_off),
-                     ptr(out, o_off), o_sb, o_m1, o_sm, o_sm2, o_sn, M, N, K, batch, act, k_lo_step, m_cap0, m_cap_step, ptr(a_kscale), ptr(a_kshift))
+                     ptr(out, o_off), o_sb, o_m1, o_sm, o_sm2, o_sn, M, N, K, batch, act, k_lo_step, m_cap0, m_cap_step, ptr(a_kscale), ptr(a_kshift), ptr(a2), a2_sk, a2_k_split)
         _check(self.lib.sksfno_gemm_run(ctypes.byref(d), self._stream()), "sksfno_gemm_run")
 
     def _norm(self, x, g, b, out, C, HW):
@@ -285,9 +294,13 @@ class SfnoEngine:
                 self._pointwise(hbuf, blk["fc2"], self.b_y, hw_out, hid, e, label="mlp" + outer, bias=blk["fc2_b"], res_post=res)
                 cur = self.b_y
             # decoder on concat(cur, normalised input): W_a cur + b' , then GELU(W_b' x + .), then W2' . + mean
-            self._pointwise(cur, self.dec1a, self.b_sp, hw_o, e, e, label="decoder", bias=self.dec1_b)
-            self._pointwise(x, self.dec1b, self.b_xn, hw_o, c.in_chans, e, label="decoder", res_pre=self.b_sp, act=1,
-                            a_kscale=self.in_scale, a_kshift=self.in_shift)
+            if self.dec_fused:
+                self._pointwise(cur, self.dec1, self.b_xn, hw_o, e + c.in_chans, e, label="decoder", bias=self.dec1_b, act=1,
+                                a_kscale=self.dec_scale, a_kshift=self.dec_shift, a2=x, a2_sk=hw_o, a2_k_split=e)
+            else:
+                self._pointwise(cur, self.dec1a, self.b_sp, hw_o, e, e, label="decoder", bias=self.dec1_b)
+                self._pointwise(x, self.dec1b, self.b_xn, hw_o, c.in_chans, e, label="decoder", res_pre=self.b_sp, act=1,
+                                a_kscale=self.in_scale, a_kshift=self.in_shift)
             y = out if out is not None else torch.empty((c.out_chans, c.n_lat, c.n_lon), dtype=torch.float32, device=self.device)
             if y.device != self.device or y.dtype != torch.float32 or tuple(y.shape) != (c.out_chans, c.n_lat, c.n_lon) or not y.is_contiguous():
                 raise ValueError("bad output tensor")
@@ -299,7 +312,7 @@ class SfnoEngine:
         return y
 
     def launches_per_step(self) -> int:
-        n = 2 + 3
+        n = 2 + (2 if self.dec_fused else 3)
         for i in range(self.cfg.num_layers):
-            n += 2 + 2 + 1 + 2 + 3 + (2 if i in (0, self.cfg.num_layers - 1) else 0)
+            n += 2 + 2 + 1 + 2 + 3 + (2 if i in (0, self.cfg.num_layers - 1) else 0)     # norms, analysis, dhconv, synthesis, skip + MLP
         return n
