@@ -52,6 +52,8 @@ typedef struct sksfno_gemm {
     const float* a2;
     long long a2_sk;
     int a2_k_split;
+    /* MFMA terms: 3 (or 0) = A and W as fp16 hi/lo pairs (fp32-class product); 2 = A rounded to one fp16 plane, W hi/lo */
+    int terms;
 } sksfno_gemm;
 
 int sksfno_abi_version(void);

@@ -170,8 +170,8 @@ typedef TileCfg<128, 256, 32, 2, 4> TG;      // wide N: the fp32 A operand is fe
 
 struct BatchStrides { long long a, w, o; int k_lo_step, m_cap0, m_cap_step; };
 
-template <bool SWAP>
-__global__ void __launch_bounds__(TG::THREADS) gemm_strided_kernel(GemmArgs<PG, ALStrided, EpStrided> g, BatchStrides bs) {
+template <class PX, bool SWAP>
+__global__ void __launch_bounds__(TG::THREADS) gemm_strided_kernel(GemmArgs<PX, ALStrided, EpStrided> g, BatchStrides bs) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const long long z = blockIdx.z;
     g.al.a += z * bs.a;
@@ -192,7 +192,7 @@ __global__ void __launch_bounds__(TG::THREADS) gemm_strided_kernel(GemmArgs<PG, 
         if (cap < g.M) { g.M = cap; g.al.M = cap; }
         if ((int)blockIdx.y * TG::BM >= g.M) return;
     }
-    gemm_body<PG, TG, ALStrided, EpStrided, SWAP>(g, smem);
+    gemm_body<PX, TG, ALStrided, EpStrided, SWAP>(g, smem);
 }
 
 // ---- instance norm over (H, W) per channel: two passes for the statistics, one to apply ---- //
@@ -259,25 +259,32 @@ int sksfno_prepare_weight(const float* src, long long sn, long long sk, int N, i
 
 int sksfno_gemm_run(const sksfno_gemm* d, void* stream) {
     if (!d || !d->a || !d->w || !d->out || d->M <= 0 || d->N <= 0 || d->K <= 0 || d->batch <= 0 || d->a_m1 <= 0 || d->o_m1 <= 0 ||
-        (d->ldw & 7) || d->ldw < d->K || (d->act != 0 && d->act != 1) || d->k_lo_step < 0 || d->m_cap_step < 0 ||
+        (d->ldw & 7) || d->ldw < d->K || (d->act != 0 && d->act != 1) || d->k_lo_step < 0 || d->m_cap_step < 0 || (d->terms != 0 && d->terms != 2 && d->terms != 3) ||
         (d->a_kscale == nullptr) != (d->a_kshift == nullptr) || (d->a_kscale != nullptr && d->k_lo_step > 0) ||
         (d->a2 != nullptr && (d->a2_k_split <= 0 || (d->a2_k_split & 7) || d->a2_k_split >= d->K || d->k_lo_step > 0 || d->batch != 1)))
         return SKSFNO_E_ARG;
-    GemmArgs<PG, ALStrided, EpStrided> g;
-    g.al = ALStrided{d->a, d->M, d->K, d->a_m1, d->a_sm, d->a_sm2, d->a_sk, d->a_kscale, d->a_kshift, d->a2, d->a2_sk, d->a2_k_split};
-    g.ep = EpStrided{d->out, d->bias, d->res_pre, d->res_post, d->o_m1, d->act, d->o_sm, d->o_sm2, d->o_sn};
-    g.W = static_cast<const f16*>(d->w);
-    g.w_plane = d->w_plane;
-    g.ldw = d->ldw;
-    g.M = d->M; g.N = d->N; g.K = d->K;
+    const ALStrided al{d->a, d->M, d->K, d->a_m1, d->a_sm, d->a_sm2, d->a_sk, d->a_kscale, d->a_kshift, d->a2, d->a2_sk, d->a2_k_split};
+    const EpStrided ep{d->out, d->bias, d->res_pre, d->res_post, d->o_m1, d->act, d->o_sm, d->o_sm2, d->o_sn};
     const BatchStrides bs{d->a_sb, d->w_sb, d->o_sb, d->k_lo_step, d->m_cap0, d->m_cap_step};
     const dim3 grid((d->N + TG::BN - 1) / TG::BN, (d->M + TG::BM - 1) / TG::BM, d->batch);
     if (grid.y > 65535 || grid.z > 65535) return SKSFNO_E_ARG;
-    constexpr int smem = gemm_smem_bytes<PG, TG>() + kEpiScratch;
     // rows contiguous in the output (NCHW activations): un-swapped order gives 4 consecutive rows per lane
     const bool swap = !(d->o_sm == 1 && d->o_sn != 1);
-    if (swap) hipLaunchKernelGGL(gemm_strided_kernel<true>, grid, dim3(TG::THREADS), smem, static_cast<hipStream_t>(stream), g, bs);
-    else      hipLaunchKernelGGL(gemm_strided_kernel<false>, grid, dim3(TG::THREADS), smem, static_cast<hipStream_t>(stream), g, bs);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    auto launch = [&](auto px) {
+        typedef decltype(px) PX;
+        GemmArgs<PX, ALStrided, EpStrided> g;
+        g.al = al; g.ep = ep;
+        g.W = static_cast<const f16*>(d->w);
+        g.w_plane = d->w_plane;
+        g.ldw = d->ldw;
+        g.M = d->M; g.N = d->N; g.K = d->K;
+        constexpr int smem = gemm_smem_bytes<PX, TG>() + kEpiScratch;
+        if (swap) hipLaunchKernelGGL((gemm_strided_kernel<PX, true>), grid, dim3(TG::THREADS), smem, st, g, bs);
+        else      hipLaunchKernelGGL((gemm_strided_kernel<PX, false>), grid, dim3(TG::THREADS), smem, st, g, bs);
+    };
+    if (d->terms == 2) launch(PrecF16x2W{});      // A as one fp16 plane, W hi/lo
+    else               launch(PrecF16x3{});
     return hipGetLastError() == hipSuccess ? 0 : SKSFNO_E_HIP;
 }
 

@@ -39,7 +39,7 @@ class GemmDesc(ctypes.Structure):
                 ("M", ctypes.c_int), ("N", ctypes.c_int), ("K", ctypes.c_int), ("batch", ctypes.c_int), ("act", ctypes.c_int),
                 ("k_lo_step", ctypes.c_int), ("m_cap0", ctypes.c_int), ("m_cap_step", ctypes.c_int),
                 ("a_kscale", ctypes.c_void_p), ("a_kshift", ctypes.c_void_p),
-                ("a2", ctypes.c_void_p), ("a2_sk", ctypes.c_longlong), ("a2_k_split", ctypes.c_int)]
+                ("a2", ctypes.c_void_p), ("a2_sk", ctypes.c_longlong), ("a2_k_split", ctypes.c_int), ("terms", ctypes.c_int)]
 
 
 _lib = None
@@ -97,8 +97,13 @@ class _Weight:
 
 
 class SfnoEngine:
-    def __init__(self, cfg: SfnoConfig | None = None, device: str | torch.device = "cuda:0"):
+    def __init__(self, cfg: SfnoConfig | None = None, device: str | torch.device = "cuda:0", terms: int = 3):
+        """``terms``: MFMA terms per GEMM -- 3: activations and constants as fp16 hi/lo pairs (fp32-class, ~1e-6 vs the oracle);
+        2: activations rounded to one fp16 plane (faster; error measured in tests/test_sfno_gpu.py)."""
         self.cfg = cfg or SfnoConfig()
+        if terms not in (2, 3):
+            raise ValueError("terms must be 2 or 3")
+        self.terms = terms
         if not torch.cuda.is_available():
             raise RuntimeError("SfnoEngine needs an MI355X: the SFNO path has no CPU fallback")
         self.lib = load_library()
@@ -217,7 +222,7 @@ class SfnoEngine:
         d = GemmDesc(ptr(a, a_off), a_sb, a_m1, a_sm, a_sm2, a_sk,
                      W.buf.data_ptr(), (W.w_sb if (batch > 1 if w_batched is None else w_batched) else 0), W.plane, W.ldw,
                      ptr(bias), ptr(res_pre, o_off), ptr(res_post, o_off),
-                     ptr(out, o_off), o_sb, o_m1, o_sm, o_sm2, o_sn, M, N, K, batch, act, k_lo_step, m_cap0, m_cap_step, ptr(a_kscale), ptr(a_kshift), ptr(a2), a2_sk, a2_k_split)
+                     ptr(out, o_off), o_sb, o_m1, o_sm, o_sm2, o_sn, M, N, K, batch, act, k_lo_step, m_cap0, m_cap_step, ptr(a_kscale), ptr(a_kshift), ptr(a2), a2_sk, a2_k_split, self.terms)
         _check(self.lib.sksfno_gemm_run(ctypes.byref(d), self._stream()), "sksfno_gemm_run")
 
     def _norm(self, x, g, b, out, C, HW):

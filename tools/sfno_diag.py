@@ -20,6 +20,9 @@ for name in sys.argv[1:] or ["tiny", "small"]:
     p, x = init_synthetic(cfg, 0), synthetic_state(cfg, 0)
     t0 = time.time()
     ref = O.forward(p, x, cfg)
+    e2 = SfnoEngine(cfg, terms=2)
+    e2.load_params(p)
+    print(f"{name}: terms=2 per-channel rel err max {O.per_channel_rel_err(e2.step(x.to(e2.device)).cpu(), ref).max().item():.3e}", flush=True)
     eng = SfnoEngine(cfg)
     eng.load_params(p)
     y = eng.step(x.to(eng.device))

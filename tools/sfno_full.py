@@ -13,7 +13,7 @@ cfg = SfnoConfig()
 t0 = time.time()
 p, x = init_synthetic(cfg, 0), synthetic_state(cfg, 0)
 print(f"init {time.time() - t0:.1f}s", flush=True)
-eng = SfnoEngine(cfg)
+eng = SfnoEngine(cfg, terms=int(sys.argv[1]) if len(sys.argv) > 1 else 3)
 t0 = time.time()
 eng.load_params(p)
 print(f"prepare {time.time() - t0:.1f}s  mem {torch.cuda.memory_allocated() / 2**30:.1f} GiB", flush=True)
