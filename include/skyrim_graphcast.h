@@ -1,0 +1,62 @@
+/* C ABI of the gfx950 GraphCast building blocks.
+ *
+ * Replaces, for the GraphCast row of the north star, what the reference reaches through
+ * earth2mip.networks.graphcast.load_time_loop_operational(...) and stepper.step()
+ * (/root/reference/skyrim/core/models/graphcast.py:51-54, 102-118): DeepMind's JAX typed graph network.  A step is a
+ * sequence of interaction-network MLPs; each is  gather + concat -> Linear -> swish -> Linear -> LayerNorm (+ residual),
+ * with a sum over incoming edges between the edge and the node update:
+ *     skgc_gather_gemm   first Linear of an MLP on rows assembled from up to three row-major sources through index arrays
+ *                        (edge latent | sender node | receiver node), bias + swish fused
+ *     sksfno_gemm_run    (include/skyrim_sfno.h) second Linear, and the output layer that writes the next state
+ *     skgc_layer_norm    LayerNorm over the latent (+ residual)
+ *     skgc_segment_sum   sum of edge rows per receiver (edges sorted by receiver, CSR offsets)
+ * All pointers are device pointers; calls are asynchronous on `stream` (a hipStream_t); nothing is allocated inside. */
+#ifndef SKYRIM_GRAPHCAST_H
+#define SKYRIM_GRAPHCAST_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SKGC_ABI_VERSION 1
+#define SKGC_E_ARG (-1)
+#define SKGC_E_HIP (-2)
+
+/* out[m][n] = act( sum_k A(m, k) W[n][k] + bias[n] ),  m < M, n < N, out row-major with leading dimension ldo.
+ * A(m, :) = concat_s src[s][ idx[s] ? idx[s][m] : m ][0 .. width[s])   (fp32 rows with leading dimension ld[s]; widths are
+ * multiples of 8 except the last; K = sum of widths); optional per-k affine A * kscale[k] + kshift[k] before the fp16 split.
+ * W: fp16 hi/lo planes [N][ldw] prepared by sksfno_prepare_weight. */
+typedef struct skgc_gather_gemm_desc {
+    const float* src[3];
+    const int* idx[3];
+    long long ld[3];
+    int width[3];
+    int n_src;
+    const float* kscale;
+    const float* kshift;
+    const void* w;
+    long long w_plane;
+    int ldw;
+    const float* bias;
+    float* out;
+    long long ldo;
+    int M, N;
+    int act;   /* 0 = none, 2 = swish */
+} skgc_gather_gemm_desc;
+
+int skgc_abi_version(void);
+int skgc_gather_gemm(const skgc_gather_gemm_desc* desc, void* stream);
+
+/* out[r][:] = (res ? res[r][:] : 0) + LayerNorm(x[r][:]) * gamma + beta  over N columns (eps 1e-5); out may alias res or x */
+int skgc_layer_norm(const float* x, const float* gamma, const float* beta, const float* res, float* out, long long rows, int N, void* stream);
+
+/* out[v][:] = sum of e[j][:] for offsets[v] <= j < offsets[v + 1]   (edges sorted by receiver; nodes without edges get zeros) */
+int skgc_segment_sum(const float* e, const int* offsets, float* out, int n_nodes, int N, void* stream);
+
+/* dst[i] += src[i], i < n (n % 4 == 0): the residual update of the edge latents */
+int skgc_add_inplace(float* dst, const float* src, long long n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -39,7 +39,7 @@ typedef struct sksfno_gemm {
     int o_m1;
     long long o_sm, o_sm2, o_sn;
     int M, N, K, batch;
-    int act;               /* 0 = none, 1 = erf-GELU */
+    int act;               /* 0 = none, 1 = erf-GELU, 2 = swish */
     /* ragged batches (spherical harmonics are zero for l < m): batch b contracts only k >= (b * k_lo_step) rounded down to a
      * multiple of 32, and computes only rows m < m_cap0 + b * m_cap_step when m_cap_step > 0 (other rows are left untouched). */
     int k_lo_step, m_cap0, m_cap_step;

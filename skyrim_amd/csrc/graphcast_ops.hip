@@ -1,0 +1,186 @@
+// GraphCast building blocks behind include/skyrim_graphcast.h (interaction-network MLPs on the icosahedral multi-mesh).
+//
+// skgc_gather_gemm: the first Linear of every MLP.  Its input row is never materialised: the loader assembles
+// concat(edge latent, sender latent, receiver latent) from the three row-major sources through the edge's index arrays
+// (k-contiguous 32-byte reads), so a 3.1 M-edge x 1536-wide matrix (19 GB) stays virtual.  Same 3-term fp16 MFMA pipeline as
+// the SFNO GEMMs (strided_gemm.h / gemm.h); LayerNorm and the receiver sum are small HBM-bound kernels.
+#include "../../include/skyrim_graphcast.h"
+#include "strided_gemm.h"
+
+namespace skp {
+
+struct ALGather {
+    static constexpr bool kDirect = false;
+    const float* src[3];
+    const int* idx[3];
+    long long ld[3];
+    int k0[4];                    // segment s covers k0[s] <= k < k0[s + 1]
+    int n_src, M, K;
+    const float* kscale;
+    const float* kshift;
+    struct Row { long long r[3]; int ok; };
+    struct Raw { float v[8]; int k; };
+    __device__ __forceinline__ Row row(int m) const {
+        Row o;
+        o.ok = m < M;
+#pragma unroll
+        for (int s = 0; s < 3; ++s) o.r[s] = (o.ok && s < n_src) ? (long long)(idx[s] ? idx[s][m] : m) * ld[s] : 0;
+        return o;
+    }
+    __device__ __forceinline__ void issue(const Row& r, int k, Raw& o) const {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o.v[i] = 0.f;
+        o.k = -1;
+        if (!r.ok || k >= K) return;
+        o.k = k;
+        const int s = k >= k0[2] ? 2 : (k >= k0[1] ? 1 : 0);            // chunks never straddle segments (widths % 8 == 0)
+        const float* p = src[s] + r.r[s] + (k - k0[s]);
+        if (k + 8 <= k0[s + 1] && (reinterpret_cast<size_t>(p) & 15) == 0) {
+            const float4 x = *reinterpret_cast<const float4*>(p), y = *reinterpret_cast<const float4*>(p + 4);
+            o.v[0] = x.x; o.v[1] = x.y; o.v[2] = x.z; o.v[3] = x.w; o.v[4] = y.x; o.v[5] = y.y; o.v[6] = y.z; o.v[7] = y.w;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (k + i < k0[s + 1]) o.v[i] = p[i];
+        }
+    }
+    __device__ __forceinline__ void finish(const Raw& r, float (&v)[8]) const {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = r.v[i];
+        if (kscale != nullptr && r.k >= 0) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (r.k + i < K) v[i] = v[i] * kscale[r.k + i] + kshift[r.k + i];
+        }
+    }
+    __device__ __forceinline__ uint4 direct(const Raw&) const { return make_uint4(0, 0, 0, 0); }
+};
+
+__global__ void __launch_bounds__(TG::THREADS) gather_gemm_kernel(const GemmArgs<PrecF16x3, ALGather, EpStrided> g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    gemm_body<PrecF16x3, TG, ALGather, EpStrided, true>(g, smem);
+}
+
+// one wave per row; N <= 1024
+__global__ void __launch_bounds__(256) layer_norm_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         const float* res, float* out, long long rows, int N) {
+    const int lane = threadIdx.x & 63;
+    const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const float* xr = x + r * N;
+    float v[16];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int c = lane + i * 64;
+        v[i] = c < N ? xr[c] : 0.f;
+        s += v[i];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s / (float)N;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const float d = (lane + i * 64 < N) ? v[i] - mean : 0.f;
+        q += d * d;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    const float rstd = rsqrtf(q / (float)N + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int c = lane + i * 64;
+        if (c < N) {
+            float y = (v[i] - mean) * rstd * gamma[c] + beta[c];
+            if (res) y += res[r * N + c];
+            out[r * N + c] = y;
+        }
+    }
+}
+
+// one wave per node, float4 per lane per pass (N % 4 == 0)
+__global__ void __launch_bounds__(256) segment_sum_kernel(const float* __restrict__ e, const int* __restrict__ offsets, float* __restrict__ out, int n_nodes, int N) {
+    const int lane = threadIdx.x & 63;
+    const int v = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (v >= n_nodes) return;
+    const int j0 = offsets[v], j1 = offsets[v + 1];
+    for (int c = lane * 4; c < N; c += 256) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int j = j0; j < j1; ++j) {
+            const float4 t = *reinterpret_cast<const float4*>(e + (long long)j * N + c);
+            acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+        }
+        *reinterpret_cast<float4*>(out + (long long)v * N + c) = acc;
+    }
+}
+
+__global__ void __launch_bounds__(256) add_inplace_kernel(float* __restrict__ dst, const float* __restrict__ src, long long n4) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    float4 a = reinterpret_cast<float4*>(dst)[i];
+    const float4 b = reinterpret_cast<const float4*>(src)[i];
+    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    reinterpret_cast<float4*>(dst)[i] = a;
+}
+
+}  // namespace skp
+
+using namespace skp;
+
+extern "C" {
+
+int skgc_abi_version(void) { return SKGC_ABI_VERSION; }
+
+int skgc_gather_gemm(const skgc_gather_gemm_desc* d, void* stream) {
+    if (!d || !d->w || !d->out || d->M <= 0 || d->N <= 0 || d->n_src < 1 || d->n_src > 3 || (d->ldw & 7) || d->ldo < d->N ||
+        (d->act != 0 && d->act != 2) || (d->kscale == nullptr) != (d->kshift == nullptr))
+        return SKGC_E_ARG;
+    GemmArgs<PrecF16x3, ALGather, EpStrided> g;
+    int k = 0;
+    for (int s = 0; s < 3; ++s) {
+        g.al.k0[s] = k;
+        g.al.src[s] = nullptr; g.al.idx[s] = nullptr; g.al.ld[s] = 0;
+        if (s < d->n_src) {
+            if (!d->src[s] || d->width[s] <= 0 || d->ld[s] < d->width[s] || (s + 1 < d->n_src && (d->width[s] & 7))) return SKGC_E_ARG;
+            g.al.src[s] = d->src[s]; g.al.idx[s] = d->idx[s]; g.al.ld[s] = d->ld[s];
+            k += d->width[s];
+        }
+    }
+    g.al.k0[3] = k;
+    if (d->ldw < k) return SKGC_E_ARG;
+    g.al.n_src = d->n_src; g.al.M = d->M; g.al.K = k; g.al.kscale = d->kscale; g.al.kshift = d->kshift;
+    g.ep = EpStrided{d->out, d->bias, nullptr, nullptr, 1 << 30, d->act, d->ldo, 0, 1};
+    g.W = static_cast<const f16*>(d->w);
+    g.w_plane = d->w_plane;
+    g.ldw = d->ldw;
+    g.M = d->M; g.N = d->N; g.K = k;
+    const dim3 grid((d->N + TG::BN - 1) / TG::BN, (d->M + TG::BM - 1) / TG::BM);
+    if (grid.y > 65535) {
+        // more than 8.3 M rows: not needed (3.1 M edges), refuse rather than wrap
+        return SKGC_E_ARG;
+    }
+    constexpr int smem = gemm_smem_bytes<PrecF16x3, TG>() + kEpiScratch;
+    hipLaunchKernelGGL(gather_gemm_kernel, grid, dim3(TG::THREADS), smem, static_cast<hipStream_t>(stream), g);
+    return hipGetLastError() == hipSuccess ? 0 : SKGC_E_HIP;
+}
+
+int skgc_layer_norm(const float* x, const float* gamma, const float* beta, const float* res, float* out, long long rows, int N, void* stream) {
+    if (!x || !gamma || !beta || !out || rows <= 0 || N <= 0 || N > 1024) return SKGC_E_ARG;
+    hipLaunchKernelGGL(layer_norm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream), x, gamma, beta, res, out, rows, N);
+    return hipGetLastError() == hipSuccess ? 0 : SKGC_E_HIP;
+}
+
+int skgc_segment_sum(const float* e, const int* offsets, float* out, int n_nodes, int N, void* stream) {
+    if (!e || !offsets || !out || n_nodes <= 0 || N <= 0 || (N & 3)) return SKGC_E_ARG;
+    hipLaunchKernelGGL(segment_sum_kernel, dim3((unsigned)((n_nodes + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream), e, offsets, out, n_nodes, N);
+    return hipGetLastError() == hipSuccess ? 0 : SKGC_E_HIP;
+}
+
+int skgc_add_inplace(float* dst, const float* src, long long n, void* stream) {
+    if (!dst || !src || n <= 0 || (n & 3)) return SKGC_E_ARG;
+    hipLaunchKernelGGL(add_inplace_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), dst, src, n / 4);
+    return hipGetLastError() == hipSuccess ? 0 : SKGC_E_HIP;
+}
+
+}  // extern "C"

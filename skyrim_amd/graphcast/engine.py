@@ -1,0 +1,245 @@
+"""GraphCast 6-h step on one MI355X: the host owns the graph, the buffers and the call order; every FLOP runs in the HIP
+kernels of include/skyrim_graphcast.h and include/skyrim_sfno.h (ctypes; PyTorch is device memory + streams).
+
+Latents are fp32 row-major ``[rows][latent]`` (grid nodes, mesh nodes, and the three edge sets).  An MLP is
+
+    skgc_gather_gemm (gather + concat + Linear + swish)  ->  sksfno_gemm_run (Linear)  ->  skgc_layer_norm (+ residual)
+
+and the receiver sum between an edge update and its node update is skgc_segment_sum over edges sorted by receiver.  The
+embeddings of the structural features (mesh nodes, all three edge sets) do not depend on the input and are computed once in
+``load_params``.  The grid-node features are read in place from a ``[186][n_grid]`` stack (two states, forcings, static
+fields, structural features) with the state normalisation as a per-k affine in the loader; the output layer writes
+``x(t) + diff_std * residual`` straight into the ``(83, n_lat, n_lon)`` result.  There is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from pathlib import Path
+
+import numpy as np
+import torch
+
+from ..sfno import engine as _sf
+from .mesh import GraphStructure, build_graph
+from .spec import N_FORCING, N_STATIC, GraphcastConfig, mlp_names, param_spec
+
+_LIB_PATH = Path(__file__).resolve().parent.parent / "lib" / "libskyrim_graphcast.so"
+EXPORTS = ["skgc_abi_version", "skgc_gather_gemm", "skgc_layer_norm", "skgc_segment_sum", "skgc_add_inplace"]
+
+
+class GatherDesc(ctypes.Structure):
+    _fields_ = [("src", ctypes.c_void_p * 3), ("idx", ctypes.c_void_p * 3), ("ld", ctypes.c_longlong * 3), ("width", ctypes.c_int * 3),
+                ("n_src", ctypes.c_int), ("kscale", ctypes.c_void_p), ("kshift", ctypes.c_void_p),
+                ("w", ctypes.c_void_p), ("w_plane", ctypes.c_longlong), ("ldw", ctypes.c_int), ("bias", ctypes.c_void_p),
+                ("out", ctypes.c_void_p), ("ldo", ctypes.c_longlong), ("M", ctypes.c_int), ("N", ctypes.c_int), ("act", ctypes.c_int)]
+
+
+_lib = None
+
+
+def load_library():
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = os.environ.get("SKYRIM_GRAPHCAST_LIB", str(_LIB_PATH))
+    if not os.path.exists(path):
+        raise RuntimeError(f"{path} not found: build the HIP library first (python -c 'import __graft_entry__ as g; g.build()')")
+    lib = ctypes.CDLL(path)
+    lib.skgc_gather_gemm.argtypes = [ctypes.POINTER(GatherDesc), ctypes.c_void_p]
+    lib.skgc_layer_norm.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_longlong, ctypes.c_int, ctypes.c_void_p]
+    lib.skgc_segment_sum.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    lib.skgc_add_inplace.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_void_p]
+    for name in EXPORTS:
+        getattr(lib, name).restype = ctypes.c_int
+    _lib = lib
+    return lib
+
+
+def _check(code: int, what: str):
+    if code != 0:
+        raise RuntimeError(f"{what} failed with code {code}")
+
+
+class GraphcastEngine:
+    def __init__(self, cfg: GraphcastConfig | None = None, device: str | torch.device = "cuda:0", graph: GraphStructure | None = None):
+        self.cfg = cfg or GraphcastConfig()
+        if not torch.cuda.is_available():
+            raise RuntimeError("GraphcastEngine needs an MI355X: the GraphCast path has no CPU fallback")
+        if self.cfg.latent % 8 != 0:
+            raise ValueError("latent must be a multiple of 8")
+        self.lib = load_library()
+        self.sf = _sf.load_library()
+        self.device = torch.device(device)
+        self.graph = graph or build_graph(self.cfg.n_lat, self.cfg.n_lon, self.cfg.splits)
+        self.prepared = False
+        self.profiling = False
+        self._events = []
+        self.state_shape = (self.cfg.n_vars, self.cfg.n_lat, self.cfg.n_lon)
+
+    def _stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    # ---- profiling (same contract as SfnoEngine) ---------------------------------------------------- #
+    def _mark(self, label: str, flops: float = 0.0):
+        if self.profiling:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(torch.cuda.current_stream(self.device))
+            self._events.append((label, ev, flops))
+
+    def profile_read(self) -> list[dict]:
+        torch.cuda.synchronize(self.device)
+        out: dict[str, dict] = {}
+        for (label, ev, fl), (_, nxt, _) in zip(self._events[:-1], self._events[1:]):
+            if label == "end":
+                continue
+            d = out.setdefault(label, dict(name=label, launches=0, total_ms=0.0, flops=0.0))
+            d["launches"] += 1
+            d["total_ms"] += ev.elapsed_time(nxt)
+            d["flops"] += fl
+        self._events = []
+        return list(out.values())
+
+    # ---- kernels ------------------------------------------------------------------------------------- #
+    def _fc1(self, W, bias, sources, rows, out, kscale=None, kshift=None, label="mlp"):
+        """sources: [(tensor [n][ld], index tensor or None, width)] -> out[rows][latent] = swish(concat(...) W^T + b)."""
+        d = GatherDesc()
+        for s, (t, idx, width) in enumerate(sources):
+            d.src[s] = t.data_ptr()
+            d.idx[s] = idx.data_ptr() if idx is not None else None
+            d.ld[s] = t.shape[-1] if t.dim() == 2 else width
+            d.width[s] = width
+        d.n_src = len(sources)
+        d.kscale = kscale.data_ptr() if kscale is not None else None
+        d.kshift = kshift.data_ptr() if kshift is not None else None
+        d.w, d.w_plane, d.ldw = W.buf.data_ptr(), W.plane, W.ldw
+        d.bias = bias.data_ptr()
+        d.out, d.ldo, d.M, d.N, d.act = out.data_ptr(), W.N, rows, W.N, 2
+        self._mark(label, 2.0 * rows * W.N * W.K)
+        _check(self.lib.skgc_gather_gemm(ctypes.byref(d), self._stream()), "skgc_gather_gemm")
+
+    def _gemm(self, a, W, out, M, *, a_sm, a_sk, o_sm, o_sn, bias=None, res_post=None, act=0, kscale=None, kshift=None, label="mlp"):
+        ptr = lambda t: None if t is None else t.data_ptr()  # noqa: E731
+        d = _sf.GemmDesc(a.data_ptr(), 0, 1 << 30, a_sm, 0, a_sk, W.buf.data_ptr(), 0, W.plane, W.ldw, ptr(bias), None, ptr(res_post),
+                         out.data_ptr(), 0, 1 << 30, o_sm, 0, o_sn, M, W.N, W.K, 1, act, 0, 0, 0, ptr(kscale), ptr(kshift), None, 0, 0, 3)
+        self._mark(label, 2.0 * M * W.N * W.K)
+        _check(self.sf.sksfno_gemm_run(ctypes.byref(d), self._stream()), "sksfno_gemm_run")
+
+    def _ln(self, x, g, b, res, out, rows, label="layer_norm"):
+        self._mark(label)
+        _check(self.lib.skgc_layer_norm(x.data_ptr(), g.data_ptr(), b.data_ptr(), res.data_ptr() if res is not None else None, out.data_ptr(),
+                                        rows, self.cfg.latent, self._stream()), "skgc_layer_norm")
+
+    def _segsum(self, e, offsets, out, n_nodes):
+        self._mark("segment_sum")
+        _check(self.lib.skgc_segment_sum(e.data_ptr(), offsets.data_ptr(), out.data_ptr(), n_nodes, self.cfg.latent, self._stream()), "skgc_segment_sum")
+
+    def _mlp(self, name, sources, rows, out, res=None, label=None):
+        """out = (res +) LayerNorm(fc2(swish(fc1(concat(sources)))));  out may alias res."""
+        m = self.m[name]
+        L = self.cfg.latent
+        self._fc1(m["fc1"], m["b1"], sources, rows, self.b_h, label=label or name.split(".")[0])
+        self._gemm(self.b_h, m["fc2"], self.b_t, rows, a_sm=L, a_sk=1, o_sm=L, o_sn=1, bias=m["b2"], label=label or name.split(".")[0])
+        self._ln(self.b_t, m["g"], m["b"], res, out, rows)
+
+    # ---- prepare ------------------------------------------------------------------------------------- #
+    def load_params(self, params: dict):
+        c, g, dev = self.cfg, self.graph, self.device
+        for name, shape in param_spec(c):
+            if name not in params or tuple(params[name].shape) != tuple(shape):
+                raise ValueError(f"parameter {name}: expected shape {shape}, got {tuple(params[name].shape) if name in params else None}")
+        L = c.latent
+        with torch.cuda.device(dev):
+            f32 = lambda t: t.float().contiguous().to(dev)  # noqa: E731
+            p = {k: v.double() for k, v in params.items() if k != "static"}
+            mean, std, dstd = p["norm.mean"], p["norm.std"], p["norm.diff_std"]
+            weng = type("W", (), {"device": dev, "lib": self.sf, "_stream": self._stream})()       # what sfno's _Weight needs
+            self.m = {}
+            for name, d_in, d_out, ln in mlp_names(c):
+                w2, b2 = p[name + ".fc2.weight"], p[name + ".fc2.bias"]
+                if name == "out":                                       # fold the residual's de-normalisation into the last layer
+                    w2, b2 = w2 * dstd[:, None], b2 * dstd
+                self.m[name] = dict(fc1=_sf._Weight(weng, p[name + ".fc1.weight"]), b1=f32(p[name + ".fc1.bias"]),
+                                    fc2=_sf._Weight(weng, w2), b2=f32(b2),
+                                    g=f32(p[name + ".ln.weight"]) if ln else None, b=f32(p[name + ".ln.bias"]) if ln else None)
+            n_state = 2 * c.n_vars
+            one, zero = torch.ones(N_FORCING + N_STATIC + 3, dtype=torch.float64), torch.zeros(N_FORCING + N_STATIC + 3, dtype=torch.float64)
+            self.in_scale = f32(torch.cat([1.0 / std, 1.0 / std, one]))
+            self.in_shift = f32(torch.cat([-mean / std, -mean / std, zero]))
+            i32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(dev)  # noqa: E731
+
+            def csr(edges, n):
+                off = np.zeros(n + 1, dtype=np.int64)
+                np.add.at(off, edges[:, 1] + 1, 1)
+                return i32(np.cumsum(off))
+
+            self.g2m_s, self.g2m_r, self.g2m_off = i32(g.g2m_edges[:, 0]), i32(g.g2m_edges[:, 1]), csr(g.g2m_edges, g.n_mesh)
+            self.me_s, self.me_r, self.me_off = i32(g.mesh_edges[:, 0]), i32(g.mesh_edges[:, 1]), csr(g.mesh_edges, g.n_mesh)
+            self.m2g_s, self.m2g_r, self.m2g_off = i32(g.m2g_edges[:, 0]), i32(g.m2g_edges[:, 1]), csr(g.m2g_edges, g.n_grid)
+            P, E1, EM, E2 = g.n_grid, len(g.g2m_edges), len(g.mesh_edges), len(g.m2g_edges)
+            self.P, self.E1, self.EM, self.E2 = P, E1, EM, E2
+            buf = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)  # noqa: E731
+            rows_max = max(P, E1, E2, EM, g.n_mesh)
+            self.b_h, self.b_t = buf(rows_max, L), buf(rows_max, L)
+            self.feat = torch.zeros(c.grid_in, P, dtype=torch.float32, device=dev)          # [186][n_grid]: states, forcings, static, structural
+            self.feat[n_state + N_FORCING:n_state + N_FORCING + N_STATIC] = f32(params["static"]).reshape(N_STATIC, P)
+            self.feat[n_state + N_FORCING + N_STATIC:] = torch.from_numpy(g.grid_node_feat.T.copy()).to(dev)
+            self.vg, self.vm = buf(P, L), buf(g.n_mesh, L)
+            self.agg_m, self.agg_g = buf(g.n_mesh, L), buf(P, L)
+            self.e1, self.em, self.e2, self.de = buf(E1, L), buf(EM, L), buf(E2, L), buf(EM, L)
+            # input-independent embeddings of the structural features
+            self.vm0, self.e1_0, self.em_0, self.e2_0 = buf(g.n_mesh, L), buf(E1, L), buf(EM, L), buf(E2, L)
+            for name, feat, out in (("embed.mesh", g.mesh_node_feat, self.vm0), ("embed.g2m_edge", g.g2m_edge_feat, self.e1_0),
+                                    ("embed.mesh_edge", g.mesh_edge_feat, self.em_0), ("embed.m2g_edge", g.m2g_edge_feat, self.e2_0)):
+                ft = torch.from_numpy(np.ascontiguousarray(feat)).to(dev)
+                self._mlp(name, [(ft, None, ft.shape[1])], ft.shape[0], out)
+            torch.cuda.current_stream(dev).synchronize()
+        self.prepared = True
+
+    # ---- step ----------------------------------------------------------------------------------------- #
+    def step(self, x_prev: torch.Tensor, x_cur: torch.Tensor, forcing: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+        """(83, n_lat, n_lon) states at t-6h and t, (15, n_lat, n_lon) forcings -> state at t+6h (fp32, engine device)."""
+        if not self.prepared:
+            raise RuntimeError("GraphcastEngine.step before load_params: not prepared")
+        c, L = self.cfg, self.cfg.latent
+        for t, shape in ((x_prev, self.state_shape), (x_cur, self.state_shape), (forcing, (N_FORCING, c.n_lat, c.n_lon))):
+            if t.device != self.device or t.dtype != torch.float32 or tuple(t.shape) != shape or not t.is_contiguous():
+                raise ValueError(f"expected contiguous float32 tensors of shape {self.state_shape} (states) / {(N_FORCING, c.n_lat, c.n_lon)} on {self.device}")
+        P, V = self.P, c.n_vars
+        with torch.cuda.device(self.device):
+            y = out if out is not None else torch.empty(self.state_shape, dtype=torch.float32, device=self.device)
+            if y.device != self.device or y.dtype != torch.float32 or tuple(y.shape) != self.state_shape or not y.is_contiguous():
+                raise ValueError("bad output tensor")
+            self.feat[:V].copy_(x_prev.reshape(V, P))
+            self.feat[V:2 * V].copy_(x_cur.reshape(V, P))
+            self.feat[2 * V:2 * V + N_FORCING].copy_(forcing.reshape(N_FORCING, P))
+            m = self.m["embed.grid"]
+            # grid-node embedder: rows = grid nodes (contiguous), k = feature (stride n_grid), normalisation in the loader
+            self._gemm(self.feat, m["fc1"], self.b_h, P, a_sm=1, a_sk=P, o_sm=L, o_sn=1, bias=m["b1"], act=2,
+                       kscale=self.in_scale, kshift=self.in_shift, label="embed")
+            self._gemm(self.b_h, m["fc2"], self.b_t, P, a_sm=L, a_sk=1, o_sm=L, o_sn=1, bias=m["b2"], label="embed")
+            self._ln(self.b_t, m["g"], m["b"], None, self.vg, P)
+            # encoder: grid -> mesh
+            self._mlp("g2m.edge", [(self.e1_0, None, L), (self.vg, self.g2m_s, L), (self.vm0, self.g2m_r, L)], self.E1, self.e1, label="encoder")
+            self._segsum(self.e1, self.g2m_off, self.agg_m, self.graph.n_mesh)
+            self._mlp("g2m.mesh_node", [(self.vm0, None, L), (self.agg_m, None, L)], self.graph.n_mesh, self.vm, res=self.vm0, label="encoder")
+            self._mlp("g2m.grid_node", [(self.vg, None, L)], P, self.vg, res=self.vg, label="encoder")
+            # processor on the multi-mesh
+            self.em.copy_(self.em_0)
+            for i in range(c.steps):
+                de = self.de
+                self._mlp(f"proc.{i}.edge", [(self.em, None, L), (self.vm, self.me_s, L), (self.vm, self.me_r, L)], self.EM, de, label="processor")
+                self._segsum(de, self.me_off, self.agg_m, self.graph.n_mesh)
+                self._mlp(f"proc.{i}.node", [(self.vm, None, L), (self.agg_m, None, L)], self.graph.n_mesh, self.vm, res=self.vm, label="processor")
+                self._mark("edge_residual")
+                _check(self.lib.skgc_add_inplace(self.em.data_ptr(), de.data_ptr(), self.EM * L, self._stream()), "skgc_add_inplace")
+            # decoder: mesh -> grid
+            self._mlp("m2g.edge", [(self.e2_0, None, L), (self.vm, self.m2g_s, L), (self.vg, self.m2g_r, L)], self.E2, self.e2, label="decoder")
+            self._segsum(self.e2, self.m2g_off, self.agg_g, P)
+            self._mlp("m2g.grid_node", [(self.vg, None, L), (self.agg_g, None, L)], P, self.vg, res=self.vg, label="decoder")
+            # output layer: x(t+6h) = x(t) + diff_std * MLP(vg), written channel-major
+            mo = self.m["out"]
+            self._fc1(mo["fc1"], mo["b1"], [(self.vg, None, L)], P, self.b_h, label="output")
+            self._gemm(self.b_h, mo["fc2"], y, P, a_sm=L, a_sk=1, o_sm=1, o_sn=P, bias=mo["b2"], res_post=self.feat[V:2 * V], label="output")
+            self._mark("end")
+        return y

@@ -1,0 +1,183 @@
+"""Graph structure of GraphCast (Lam et al. 2023, and deepmind/graphcast's icosahedral_mesh.py / grid_mesh_connectivity.py):
+
+* the icosahedral multi-mesh: a regular icosahedron refined ``splits`` times by edge bisection (M0 ... M_splits; the nodes of a
+  coarser mesh are a subset of the finer one's), its edge set the UNION of the edges of all levels, both directions
+  (splits = 6: 40 962 nodes, 81 920 finest faces, 327 660 directed edges);
+* grid -> mesh edges: every lat/lon grid point sends to the finest-mesh nodes within 0.6 x (longest finest-mesh edge);
+* mesh -> grid edges: every grid point receives from the 3 vertices of the finest-mesh triangle that contains it;
+* structural features: nodes (cos lat, sin lon, cos lon); edges (length, and the sender's position relative to the receiver in
+  the receiver's local frame -- rotated so that the receiver sits at lat = lon = 0), scaled by the longest edge of the set.
+
+Everything here is host-side preparation (numpy / scipy.spatial), done once per geometry.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import numpy as np
+from scipy.spatial import cKDTree
+
+
+def icosahedron():
+    phi = (1.0 + np.sqrt(5.0)) / 2.0
+    v = []
+    for a in (1.0, -1.0):
+        for b in (phi, -phi):
+            v += [(a, b, 0.0), (0.0, a, b), (b, 0.0, a)]
+    v = np.array(v, dtype=np.float64)
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    # faces = all vertex triples at mutual distance = edge length
+    d = np.linalg.norm(v[:, None] - v[None], axis=-1)
+    edge = d[d > 1e-9].min()
+    adj = np.abs(d - edge) < 1e-6
+    faces = []
+    for i in range(12):
+        for j in range(i + 1, 12):
+            if not adj[i, j]:
+                continue
+            for k in range(j + 1, 12):
+                if adj[i, k] and adj[j, k]:
+                    f = [i, j, k]
+                    if np.dot(np.cross(v[j] - v[i], v[k] - v[i]), v[i] + v[j] + v[k]) < 0:      # outward orientation
+                        f = [i, k, j]
+                    faces.append(f)
+    # rotate so that two opposite vertices sit on the poles (deepmind's mesh does the same; any fixed orientation works)
+    z = v[0]
+    x = np.cross([0.0, 0.0, 1.0], z)
+    if np.linalg.norm(x) > 1e-12:
+        x /= np.linalg.norm(x)
+        c, s = z[2], np.sqrt(1.0 - z[2] ** 2)
+        k = np.array([[0, -x[2], x[1]], [x[2], 0, -x[0]], [-x[1], x[0], 0]])
+        r = np.eye(3) + (-s) * k + (1 - c) * (k @ k)        # Rodrigues rotation taking z to the north pole
+        v = v @ r.T
+    return v, np.array(faces, dtype=np.int64)
+
+
+def refine(vertices: np.ndarray, faces: np.ndarray):
+    """Split every triangle in 4 by bisecting its edges (midpoints projected to the sphere); existing vertices keep their index."""
+    verts = list(vertices)
+    cache: dict = {}
+
+    def mid(a, b):
+        key = (a, b) if a < b else (b, a)
+        if key not in cache:
+            p = verts[a] + verts[b]
+            verts.append(p / np.linalg.norm(p))
+            cache[key] = len(verts) - 1
+        return cache[key]
+
+    out = []
+    for a, b, c in faces:
+        ab, bc, ca = mid(a, b), mid(b, c), mid(c, a)
+        out += [[a, ab, ca], [ab, b, bc], [ca, bc, c], [ab, bc, ca]]
+    return np.array(verts), np.array(out, dtype=np.int64)
+
+
+def faces_to_edges(faces: np.ndarray) -> np.ndarray:
+    """Directed edges (sender, receiver) of a triangle mesh, both directions, unique."""
+    e = np.concatenate([faces[:, [0, 1]], faces[:, [1, 2]], faces[:, [2, 0]]])
+    e = np.concatenate([e, e[:, ::-1]])
+    return np.unique(e, axis=0)
+
+
+def lat_lon_to_xyz(lat_deg, lon_deg):
+    lat, lon = np.deg2rad(lat_deg), np.deg2rad(lon_deg)
+    return np.stack([np.cos(lat) * np.cos(lon), np.cos(lat) * np.sin(lon), np.sin(lat)], axis=-1)
+
+
+def xyz_to_lat_lon(p):
+    return np.arcsin(np.clip(p[..., 2], -1.0, 1.0)), np.arctan2(p[..., 1], p[..., 0])
+
+
+def edge_features(pos_send: np.ndarray, pos_recv: np.ndarray) -> np.ndarray:
+    """(length, dx, dy, dz of the sender relative to the receiver in the receiver's local frame) / longest length."""
+    lat, lon = xyz_to_lat_lon(pos_recv)
+    # rotate about z by -lon, then about y so that the receiver goes to (1, 0, 0)
+    cl, sl, cp, sp = np.cos(lon), np.sin(lon), np.cos(lat), np.sin(lat)
+
+    def rot(p):
+        x1 = cl * p[:, 0] + sl * p[:, 1]
+        y1 = -sl * p[:, 0] + cl * p[:, 1]
+        z1 = p[:, 2]
+        return np.stack([cp * x1 + sp * z1, y1, -sp * x1 + cp * z1], axis=-1)
+
+    rel = rot(pos_send) - rot(pos_recv)
+    length = np.linalg.norm(rel, axis=-1, keepdims=True)
+    f = np.concatenate([length, rel], axis=-1)
+    return (f / length.max()).astype(np.float32)
+
+
+def node_features(pos: np.ndarray) -> np.ndarray:
+    lat, lon = xyz_to_lat_lon(pos)
+    return np.stack([np.cos(lat), np.sin(lon), np.cos(lon)], axis=-1).astype(np.float32)
+
+
+@dataclass
+class GraphStructure:
+    n_grid: int
+    n_mesh: int
+    mesh_pos: np.ndarray         # [n_mesh][3]
+    grid_pos: np.ndarray         # [n_grid][3]
+    mesh_edges: np.ndarray       # [E_mesh][2] (sender, receiver), multi-mesh, sorted by receiver
+    g2m_edges: np.ndarray        # [E_g2m][2]  (grid sender, mesh receiver), sorted by receiver
+    m2g_edges: np.ndarray        # [3 n_grid][2] (mesh sender, grid receiver), sorted by receiver
+    mesh_edge_feat: np.ndarray   # [E][4]
+    g2m_edge_feat: np.ndarray
+    m2g_edge_feat: np.ndarray
+    mesh_node_feat: np.ndarray   # [n_mesh][3]
+    grid_node_feat: np.ndarray   # [n_grid][3]
+    faces: np.ndarray            # finest faces
+
+
+def _sort_by_receiver(edges: np.ndarray) -> np.ndarray:
+    order = np.lexsort((edges[:, 0], edges[:, 1]))
+    return edges[order]
+
+
+def containing_triangles(points: np.ndarray, verts: np.ndarray, faces: np.ndarray) -> np.ndarray:
+    """Index of the spherical triangle containing each unit vector (ties on edges / vertices go to the best candidate)."""
+    cent = verts[faces].mean(axis=1)
+    cent /= np.linalg.norm(cent, axis=1, keepdims=True)
+    tree = cKDTree(cent)
+    k = min(12, len(faces))
+    _, cand = tree.query(points, k=k)
+    a, b, c = verts[faces[:, 0]], verts[faces[:, 1]], verts[faces[:, 2]]
+    nab, nbc, nca = np.cross(a, b), np.cross(b, c), np.cross(c, a)          # inward-pointing for outward-oriented faces
+    best = np.full(len(points), -1, dtype=np.int64)
+    best_margin = np.full(len(points), -np.inf)
+    for j in range(k):
+        f = cand[:, j]
+        m = np.minimum(np.minimum(np.einsum("ij,ij->i", nab[f], points), np.einsum("ij,ij->i", nbc[f], points)), np.einsum("ij,ij->i", nca[f], points))
+        upd = m > best_margin
+        best[upd], best_margin[upd] = f[upd], m[upd]
+    if (best_margin < -1e-9).any():
+        raise RuntimeError("a grid point lies in none of its candidate triangles")
+    return best
+
+
+def build_graph(n_lat: int, n_lon: int, splits: int) -> GraphStructure:
+    v, f = icosahedron()
+    levels = [(v, f)]
+    for _ in range(splits):
+        v, f = refine(v, f)
+        levels.append((v, f))
+    mesh_edges = np.unique(np.concatenate([faces_to_edges(ff) for _, ff in levels]), axis=0)
+    mesh_edges = _sort_by_receiver(mesh_edges)
+    lat = np.linspace(90.0, -90.0, n_lat)
+    lon = np.arange(n_lon) * (360.0 / n_lon)
+    grid_pos = lat_lon_to_xyz(np.repeat(lat, n_lon), np.tile(lon, n_lat))
+    fine_edges = faces_to_edges(f)
+    longest = np.linalg.norm(v[fine_edges[:, 0]] - v[fine_edges[:, 1]], axis=1).max()
+    tree = cKDTree(v)
+    near = tree.query_ball_point(grid_pos, r=0.6 * longest)
+    send = np.repeat(np.arange(len(grid_pos)), [len(x) for x in near])
+    recv = np.concatenate([np.asarray(x, dtype=np.int64) for x in near])
+    g2m = _sort_by_receiver(np.stack([send, recv], axis=1))
+    tri = containing_triangles(grid_pos, v, f)
+    m2g = np.stack([f[tri].reshape(-1), np.repeat(np.arange(len(grid_pos)), 3)], axis=1)       # already sorted by receiver
+    return GraphStructure(
+        n_grid=len(grid_pos), n_mesh=len(v), mesh_pos=v, grid_pos=grid_pos, mesh_edges=mesh_edges, g2m_edges=g2m, m2g_edges=m2g,
+        mesh_edge_feat=edge_features(v[mesh_edges[:, 0]], v[mesh_edges[:, 1]]),
+        g2m_edge_feat=edge_features(grid_pos[g2m[:, 0]], v[g2m[:, 1]]),
+        m2g_edge_feat=edge_features(v[m2g[:, 0]], grid_pos[m2g[:, 1]]),
+        mesh_node_feat=node_features(v), grid_node_feat=node_features(grid_pos), faces=f)
