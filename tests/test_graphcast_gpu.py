@@ -1,0 +1,129 @@
+"""GPU parity tests of the GraphCast path: HIP kernels called through the C ABIs of include/skyrim_graphcast.h and
+include/skyrim_sfno.h against the CPU oracle.  GraphCast predicts an INCREMENT of the latest state, so two errors are asserted:
+per channel against max|x(t+6h)| (the north star's 1e-3 bar; observed ~1e-7) and against the size of the predicted increment
+(observed ~3e-5, asserted <= 1e-3)."""
+import datetime
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import graphcast_oracle as O
+from skyrim_amd.graphcast.spec import GraphcastConfig, forcings, init_synthetic, synthetic_states
+
+pytestmark = pytest.mark.gpu
+
+CONFIGS = {
+    "tiny": GraphcastConfig(n_lat=33, n_lon=64, splits=2, latent=32, steps=3),
+    "small": GraphcastConfig(n_lat=61, n_lon=120, splits=3, latent=72, steps=4, n_vars=11),      # odd sizes: K / N tails in the GEMMs
+}
+
+
+@pytest.fixture(scope="module", params=["tiny", "small"])
+def case(request):
+    from skyrim_amd.graphcast.engine import GraphcastEngine
+    cfg = CONFIGS[request.param]
+    eng = GraphcastEngine(cfg, "cuda:0")
+    p = init_synthetic(cfg, 0)
+    eng.load_params(p)
+    x0, x1 = synthetic_states(cfg, 0)
+    return cfg, p, x0, x1, forcings(cfg, 1000.0), eng
+
+
+def test_step_vs_oracle(case):
+    cfg, p, x0, x1, f, eng = case
+    y = eng.step(x0.cuda(), x1.cuda(), f.cuda())
+    ref = O.forward(p, eng.graph, x0, x1, f, cfg)
+    assert torch.isfinite(y).all() and tuple(y.shape) == (cfg.n_vars, cfg.n_lat, cfg.n_lon)
+    assert O.per_channel_rel_err(y.cpu(), ref).max().item() < 1e-5
+    assert O.increment_rel_err(y.cpu(), ref, x1).max().item() < 1e-3
+
+
+def test_rollout_and_determinism(case):
+    cfg, p, x0, x1, f, eng = case
+    a, b, ra, rb = x0.cuda(), x1.cuda(), x0, x1
+    for k in range(3):
+        fk = forcings(cfg, 1000.0 + 6.0 * k)
+        a, b = b, eng.step(a, b, fk.cuda())
+        ra, rb = rb, O.forward(p, eng.graph, ra, rb, fk, cfg)
+    assert O.per_channel_rel_err(b.cpu(), rb).max().item() < 1e-5
+    y1, y2 = eng.step(x0.cuda(), x1.cuda(), f.cuda()), eng.step(x0.cuda(), x1.cuda(), f.cuda())
+    assert torch.equal(y1, y2)
+    out = x1.cuda().clone()
+    eng.step(x0.cuda(), out, f.cuda(), out=out)                           # writing the result over x(t) is allowed
+    assert torch.equal(out, y1)
+
+
+def test_matches_golden_fixture():
+    from skyrim_amd.graphcast.engine import GraphcastEngine
+    cfg = CONFIGS["tiny"]
+    gold = np.load(__file__.rsplit("/", 1)[0] + "/golden/graphcast_tiny_33x64.npz")
+    eng = GraphcastEngine(cfg, "cuda:0")
+    eng.load_params(init_synthetic(cfg, 0))
+    x0, x1 = synthetic_states(cfg, 0)
+    y = eng.step(x0.cuda(), x1.cuda(), forcings(cfg, 1000.0).cuda()).cpu().numpy()
+    assert (np.abs(y[:, ::2, ::4] - gold["step1_sub"]) / gold["increment_absmax"][:, None, None]).max() < 1e-3
+
+
+def test_building_blocks_against_torch():
+    from skyrim_amd.graphcast import engine as E
+    eng = E.GraphcastEngine(CONFIGS["tiny"], "cuda:0")
+    gen = torch.Generator().manual_seed(5)
+    L = 32
+    # layer norm (+ residual), in place
+    x, g, b, r = torch.randn(1000, L, generator=gen), torch.randn(L, generator=gen), torch.randn(L, generator=gen), torch.randn(1000, L, generator=gen)
+    xd, rd = x.cuda(), r.cuda()
+    eng._ln(xd, g.cuda(), b.cuda(), rd, rd, 1000)
+    assert torch.allclose(rd.cpu(), r + torch.nn.functional.layer_norm(x, (L,), g, b, 1e-5), atol=2e-6)
+    # segment sum with an empty segment
+    counts = torch.randint(0, 7, (50,), generator=gen)
+    counts[7] = 0
+    off = torch.cat([torch.zeros(1, dtype=torch.int64), counts.cumsum(0)]).int()
+    e = torch.randn(int(off[-1]), L, generator=gen)
+    out = torch.full((50, L), 7.0, device="cuda")
+    eng._segsum(e.cuda(), off.cuda(), out, 50)
+    ref = torch.zeros(50, L).index_add_(0, torch.repeat_interleave(torch.arange(50), counts), e)
+    assert torch.allclose(out.cpu(), ref, atol=1e-5) and float(out[7].abs().max()) == 0.0
+    # gather + concat + Linear + swish
+    n0, n1, rows = 300, 40, 777
+    s0, s1, s2 = torch.randn(rows, L, generator=gen), torch.randn(n0, L, generator=gen), torch.randn(n1, L, generator=gen)
+    i1, i2 = torch.randint(0, n0, (rows,), generator=gen).int(), torch.randint(0, n1, (rows,), generator=gen).int()
+    w, bias = torch.randn(L, 3 * L, generator=gen) / 10, torch.randn(L, generator=gen)
+    weng = type("W", (), {"device": eng.device, "lib": eng.sf, "_stream": eng._stream})()
+    W = E._sf._Weight(weng, w)
+    outd = torch.zeros(rows, L, device="cuda")
+    eng._fc1(W, bias.cuda(), [(s0.cuda(), None, L), (s1.cuda(), i1.cuda(), L), (s2.cuda(), i2.cuda(), L)], rows, outd)
+    ref = torch.nn.functional.silu(torch.cat([s0, s1[i1.long()], s2[i2.long()]], 1).double() @ w.double().T + bias.double())
+    assert ((outd.cpu().double() - ref).abs().max() / ref.abs().max()).item() < 2e-6
+
+
+def test_errors_are_loud():
+    from skyrim_amd.graphcast.engine import GraphcastEngine
+    cfg = CONFIGS["tiny"]
+    eng = GraphcastEngine(cfg, "cuda:0")
+    x0, x1 = synthetic_states(cfg, 0)
+    f = forcings(cfg, 0.0)
+    with pytest.raises(RuntimeError, match="not prepared"):
+        eng.step(x0.cuda(), x1.cuda(), f.cuda())
+    p = init_synthetic(cfg, 0)
+    with pytest.raises(ValueError):
+        eng.load_params({k: v for k, v in p.items() if k != "out.fc2.weight"})
+    eng.load_params(p)
+    with pytest.raises(ValueError):
+        eng.step(x0.cuda(), x1.cuda(), f.cuda()[:10].contiguous())
+    with pytest.raises(ValueError):
+        GraphcastEngine(GraphcastConfig(n_lat=33, n_lon=64, splits=2, latent=30, steps=2), "cuda:0")
+
+
+def test_reference_api_forecast_on_the_graphcast_engine():
+    """GraphcastModel.forecast through run_basic_inference with two history levels (reference graphcast.py:112-115: time = 2)."""
+    from skyrim_amd.core.models.graphcast import GraphcastModel
+    cfg = CONFIGS["tiny"]
+    params = init_synthetic(cfg, 0)
+    model = GraphcastModel(ic_source="synthetic", cfg=cfg, params=params)
+    assert model.model.n_history_levels == 2 and len(model.in_channel_names) == 83
+    t0 = datetime.datetime(2024, 5, 13, 18)
+    da = model.forecast(t0, n_steps=2)
+    assert da.dims == ("time", "channel", "lat", "lon") and da.values.shape == (3, 83, cfg.n_lat, cfg.n_lon)
+    assert list(da.time.values) == [np.datetime64(t0 + k * datetime.timedelta(hours=6), "ns") for k in range(3)]
+    assert np.isfinite(da.values).all()

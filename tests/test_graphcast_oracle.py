@@ -1,0 +1,104 @@
+"""CPU tests of the GraphCast row: the graph construction against the published node / edge counts and geometric invariants, the
+oracle against its golden fixture, and the C ABI of libskyrim_graphcast.so (symbols + argument errors; no compute without a GPU)."""
+import ctypes
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import graphcast_oracle as O
+from skyrim_amd.graphcast import engine as E
+from skyrim_amd.graphcast.mesh import build_graph, edge_features, faces_to_edges, icosahedron, lat_lon_to_xyz, refine
+from skyrim_amd.graphcast.spec import CHANNELS, GraphcastConfig, flops_per_step, forcings, init_synthetic, mlp_names, param_spec, synthetic_states
+
+TINY = GraphcastConfig(n_lat=33, n_lon=64, splits=2, latent=32, steps=3)
+GOLD = Path(__file__).resolve().parent / "golden" / "graphcast_tiny_33x64.npz"
+
+
+def test_icosahedron_and_refinement_invariants():
+    v, f = icosahedron()
+    assert v.shape == (12, 3) and f.shape == (20, 3) and np.allclose(np.linalg.norm(v, axis=1), 1.0)
+    e = faces_to_edges(f)
+    assert len(e) == 60 and np.allclose(np.linalg.norm(v[e[:, 0]] - v[e[:, 1]], axis=1), np.linalg.norm(v[e[0, 0]] - v[e[0, 1]]))
+    assert abs(abs(v[:, 2]).max() - 1.0) < 1e-12                       # two vertices on the poles
+    for _ in range(3):
+        v0 = v
+        v, f = refine(v, f)
+        assert np.array_equal(v[: len(v0)], v0)                          # coarser nodes keep their index (multi-mesh)
+        assert len(v) - len(faces_to_edges(f)) // 2 + len(f) == 2         # Euler characteristic of the sphere
+        assert np.allclose(np.linalg.norm(v, axis=1), 1.0)
+        assert (np.einsum("ij,ij->i", np.cross(v[f[:, 1]] - v[f[:, 0]], v[f[:, 2]] - v[f[:, 0]]), v[f].sum(1)) > 0).all()   # outward faces
+
+
+@pytest.mark.timeout(600)
+def test_full_size_graph_has_the_published_counts():
+    """Lam et al. 2023: M6 has 40 962 nodes / 81 920 faces, the multi-mesh 327 660 directed edges, and each of the 1 038 240 grid
+    points receives from the 3 vertices of its triangle; ~1.6 M grid->mesh edges at 0.6 x the longest M6 edge."""
+    g = build_graph(721, 1440, 6)
+    assert (g.n_grid, g.n_mesh, len(g.faces), len(g.mesh_edges), len(g.m2g_edges)) == (1038240, 40962, 81920, 327660, 3114720)
+    assert 1.55e6 < len(g.g2m_edges) < 1.70e6
+    assert len(np.unique(g.g2m_edges[:, 1])) == g.n_mesh                  # every mesh node hears from the grid
+    assert (np.diff(g.mesh_edges[:, 1]) >= 0).all() and (np.diff(g.g2m_edges[:, 1]) >= 0).all() and (np.diff(g.m2g_edges[:, 1]) >= 0).all()
+    assert np.array_equal(g.m2g_edges[:, 1], np.repeat(np.arange(g.n_grid), 3))
+    # barycentric check on a sample: the grid point lies inside (or on) its triangle
+    idx = np.arange(0, g.n_grid, 997)
+    tri = g.mesh_pos[g.m2g_edges[:, 0].reshape(-1, 3)[idx]]
+    p = g.grid_pos[idx]
+    for i, j in ((0, 1), (1, 2), (2, 0)):
+        assert (np.einsum("ij,ij->i", np.cross(tri[:, i], tri[:, j]), p) > -1e-9).all()
+    assert g.mesh_edge_feat.shape == (327660, 4) and abs(g.mesh_edge_feat[:, 0].max() - 1.0) < 1e-6 and g.grid_node_feat.shape == (1038240, 3)
+
+
+def test_edge_features_are_receiver_local():
+    recv = lat_lon_to_xyz(np.array([0.0, 40.0, -70.0]), np.array([0.0, 100.0, 250.0]))
+    east = lat_lon_to_xyz(np.array([0.0, 40.0, -70.0]), np.array([1.0, 101.0, 251.0]))
+    north = lat_lon_to_xyz(np.array([1.0, 41.0, -69.0]), np.array([0.0, 100.0, 250.0]))
+    fe, fn = edge_features(east, recv), edge_features(north, recv)
+    # in the receiver's frame (receiver at (1, 0, 0)): a sender to the east has +y, one to the north +z, the same at every location
+    assert (fe[:, 2] > 0).all() and (np.abs(fe[:, 3]) < 0.02 * fe[:, 0]).all()
+    assert (fn[:, 3] > 0).all() and (np.abs(fn[:, 2]) < 1e-6).all()
+    assert np.allclose(fn[:, 0], fn[0, 0], rtol=1e-5)
+
+
+def test_oracle_matches_golden_fixture():
+    gold = np.load(GOLD)
+    g = build_graph(TINY.n_lat, TINY.n_lon, TINY.splits)
+    assert np.array_equal(g.mesh_edges, gold["mesh_edges"]) and np.array_equal(g.g2m_edges[::13], gold["g2m_edges_sub"])
+    assert np.array_equal(g.m2g_edges[::11, 0], gold["m2g_senders_sub"]) and np.allclose(g.mesh_edge_feat[::9], gold["mesh_edge_feat_sub"], atol=1e-6)
+    p = init_synthetic(TINY, 0)
+    x0, x1 = synthetic_states(TINY, 0)
+    f = forcings(TINY, 1000.0)
+    assert np.array_equal(x1[:, ::2, ::4].numpy(), gold["x_cur_sub"]) and np.allclose(f[:, ::4, ::8].numpy(), gold["forcing_sub"], atol=1e-6)
+    taps = {}
+    y = O.forward(p, g, x0, x1, f, TINY, taps=taps)
+    assert (np.abs(y[:, ::2, ::4].numpy() - gold["step1_sub"]) / gold["increment_absmax"][:, None, None]).max() < 1e-4
+    assert np.allclose(taps["encoder.vm"][::7].numpy(), gold["encoder_vm_sub"], atol=1e-4)
+    assert np.allclose(taps["processor.vm"][::7].numpy(), gold["processor_vm_sub"], atol=1e-3)
+    assert torch.equal(y, O.forward(p, g, x0, x1, f, TINY))
+
+
+def test_spec():
+    full = GraphcastConfig()
+    assert len(CHANNELS) == 83 and CHANNELS[0] == "z50" and CHANNELS[13] == "q50" and CHANNELS[-5:] == ["u10m", "v10m", "t2m", "msl", "tp06"]
+    assert full.grid_in == 186 and len(mlp_names(full)) == 8 + 32 + 3
+    n_param = sum(int(np.prod(s)) for n, s in param_spec(full) if n != "static")
+    assert 35e6 < n_param < 37e6                                          # the paper's 36.7 M
+    assert 25e12 < flops_per_step(full, 1038240, 40962, 327660, 1645760, 3114720) < 27e12
+    f = forcings(TINY, 12.0)
+    assert f.shape == (15, 33, 64) and float(f[0].min()) >= 0.0 and float(f[0].max()) <= 1.0 and abs(float(f[1, 0, 0]) ** 2 + float(f[2, 0, 0]) ** 2 - 1.0) < 1e-6
+
+
+def test_graphcast_library_exports_declared_symbols_and_rejects_bad_arguments():
+    header = (Path(__file__).resolve().parent.parent / "include" / "skyrim_graphcast.h").read_text()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    syms = sorted(set(re.findall(r"\b(skgc_[a-z_]+)\s*\(", header)))
+    lib = E.load_library()
+    assert set(syms) == set(E.EXPORTS) and all(hasattr(lib, s) for s in syms)
+    assert lib.skgc_abi_version() == 1
+    assert lib.skgc_gather_gemm(None, None) == -1
+    assert lib.skgc_gather_gemm(ctypes.byref(E.GatherDesc()), None) == -1
+    assert lib.skgc_layer_norm(None, None, None, None, None, 4, 32, None) == -1
+    assert lib.skgc_segment_sum(None, None, None, 4, 32, None) == -1
+    assert lib.skgc_add_inplace(None, None, 16, None) == -1
