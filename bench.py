@@ -225,6 +225,103 @@ def run_sfno(args, rank, local_rank, world, dist):
     print(json.dumps(out), flush=True)
 
 
+def run_graphcast(args, rank, local_rank, world, dist):
+    """The same contract for the GraphCast row (BASELINE.json configs[3]): one step = one 6-h forward of the 0.25-degree, 13-level
+    GraphCast (M6 multi-mesh, 16 processor layers) on synthetic 83-channel states resident in HBM; N > 1 = one member per rank (the
+    2-GPU mesh split of configs[3] is not built: a step fits one GPU) + the closing ensemble reduction."""
+    from skyrim_amd.graphcast.engine import GraphcastEngine
+    from skyrim_amd.graphcast.spec import GraphcastConfig, flops_per_step, forcings, init_synthetic, synthetic_states
+    from skyrim_amd.pangu.ensemble import ensemble_mean_spread
+    cfg = GraphcastConfig(n_lat=args.n_lat, n_lon=args.n_lon)
+    dev = torch.device("cuda", local_rank)
+    eng = GraphcastEngine(cfg, dev)
+    g = eng.graph
+    params = init_synthetic(cfg, 0)
+    eng.load_params(params)
+    x0h, x1h = synthetic_states(cfg, rank if world > 1 else 0)
+    a, b = x0h.to(dev), x1h.to(dev)
+    fcs = [forcings(cfg, 1000.0 + 6.0 * k).to(dev) for k in range(args.warmup + args.steps)]      # host-side preparation, outside the timed region
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step(k):
+        nonlocal a, b
+        nxt = eng.step(a, b, fcs[k], out=a)          # x(t-6h) is dead after the step: its buffer takes x(t+6h)
+        a, b = b, nxt
+
+    for k in range(args.warmup):
+        step(k)
+    if world > 1:
+        ensemble_mean_spread([b], world)
+    eng.profiling = True
+    sync()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(args.warmup + k)
+    if world > 1:
+        ensemble_mean_spread([b], world)
+    sync()
+    elapsed = time.perf_counter() - t0
+    stats = eng.profile_read()
+    eng.profiling = False
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    finite = bool(torch.isfinite(b).all().item())
+    if rank != 0:
+        return
+    f_step = flops_per_step(cfg, g.n_grid, g.n_mesh, len(g.mesh_edges), len(g.g2m_edges), len(g.m2g_edges))
+    dom = max(stats, key=lambda s: s["total_ms"])
+    achieved = dom["flops"] / (dom["total_ms"] * 1e-3)
+    gpu_ms = sum(s["total_ms"] for s in stats) / args.steps
+    out = {
+        "metric": "6-h forecast steps/sec on 721x1440 state, 1/2/4/8 MI355X; per-channel max rel-err vs ref",
+        "value": world * args.steps / elapsed, "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f16", "data": "synthetic",
+        "config": {"workload": f"GraphCast (M{cfg.splits} multi-mesh: {g.n_mesh} nodes, {len(g.mesh_edges)} edges; {len(g.g2m_edges)} grid->mesh and "
+                               f"{len(g.m2g_edges)} mesh->grid edges; latent {cfg.latent}, {cfg.steps} processor layers) 6-h autoregressive rollout, "
+                               f"{cfg.n_lat}x{cfg.n_lon}x{cfg.n_vars} state, random-init weights (35.4 M), states resident in HBM, 1 member per GPU",
+                   "precision": "every Linear as a GEMM with fp16 hi/lo operands, 3 MFMA terms, fp32 accumulate; fp32 latents",
+                   "parallelism": f"member-parallel x{world}" if world > 1 else "single GPU", "finite": finite},
+        "roofline": {"bound": "mfma", "kernel": dom["name"] + " (gather_gemm_kernel + gemm_strided_kernel)", "achieved": achieved / 1e12,
+                     "peak": PEAK_MFMA_BF16 / 1e12, "unit": "TFLOP/s", "frac": achieved / PEAK_MFMA_BF16, "traffic": None,
+                     "avg_launch_ms": dom["total_ms"] / dom["launches"],
+                     "step": {"alg_tflop": f_step / 1e12, "gpu_ms": gpu_ms, "mfma_frac": f_step / (gpu_ms * 1e-3) / PEAK_MFMA_BF16},
+                     "stages": {s["name"]: {"ms_per_step": round(s["total_ms"] / args.steps, 3), "launches_per_step": s["launches"] // args.steps,
+                                            "dense_tflops": round(s["flops"] / (s["total_ms"] * 1e-3) / 1e12, 1)} for s in stats}},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        from oracle import graphcast_oracle as O
+        t0 = time.time()
+        with torch.no_grad():                        # bounded sample: the grid-node embedder of one full-size step
+            mean, std = params["norm.mean"][:, None, None], params["norm.std"][:, None, None]
+            feats = torch.cat([(x0h - mean) / std, (x1h - mean) / std, fcs[0].cpu(), params["static"]], dim=0).flatten(1).T
+            O.mlp(params, "embed.grid", torch.cat([feats, torch.from_numpy(g.grid_node_feat)], dim=1))
+        dt = time.time() - t0
+        f_sample = 2.0 * g.n_grid * (cfg.grid_in * cfg.latent + cfg.latent * cfg.latent)
+        out["cpu_baseline"] = {"value": 1.0 / (dt * f_step / f_sample), "unit": "steps/s", "cores": torch.get_num_threads(), "kind": "port",
+                               "sample": f"grid-node embedder (186 -> 512 -> 512 + LayerNorm on {g.n_grid} nodes) of one step "
+                                         f"({100 * f_sample / f_step:.1f}% of its FLOPs) in {dt:.1f} s, scaled by FLOPs; PyTorch-CPU fp32 restatement"}
+    if world == 1 and not args.no_parity:
+        from oracle import graphcast_oracle as O
+        small = GraphcastConfig(n_lat=61, n_lon=120, splits=3, latent=64, steps=4)
+        se = GraphcastEngine(small, dev)
+        sp = init_synthetic(small, 0)
+        se.load_params(sp)
+        s0, s1 = synthetic_states(small, 0)
+        sf = forcings(small, 1000.0)
+        y = se.step(s0.to(dev), s1.to(dev), sf.to(dev)).cpu()
+        ref = O.forward(sp, se.graph, s0, s1, sf, small)
+        out["parity"] = {"grid": "61x120, M3 mesh", "max_rel_err": O.per_channel_rel_err(y, ref).max().item(),
+                         "max_rel_err_of_increment": O.increment_rel_err(y, ref, s1).max().item(), "bar": 1e-3}
+    print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -236,8 +333,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-alt-modes", action="store_true", help="skip the short runs of the other precision modes")
-    ap.add_argument("--model", default="pangu", choices=["pangu", "sfno"],
-                    help="pangu (default; BASELINE.json's headline configuration) or sfno (FourCastNet v2-small, configs[2])")
+    ap.add_argument("--model", default="pangu", choices=["pangu", "sfno", "graphcast"],
+                    help="pangu (default; BASELINE.json's headline configuration), sfno (FourCastNet v2-small, configs[2]) or graphcast (configs[3])")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo only to "
                     "exercise the multi-rank control flow on a box with fewer GPUs than ranks)")
     args = ap.parse_args()
@@ -262,8 +359,8 @@ def main():
         else:
             dist.init_process_group(args.backend)
 
-    if args.model == "sfno":
-        run_sfno(args, rank, local_rank, world, dist)
+    if args.model in ("sfno", "graphcast"):
+        (run_sfno if args.model == "sfno" else run_graphcast)(args, rank, local_rank, world, dist)
         if world > 1:
             dist.destroy_process_group()
         return
