@@ -53,6 +53,13 @@ int skgc_layer_norm(const float* x, const float* gamma, const float* beta, const
 /* out[v][:] = sum of e[j][:] for offsets[v] <= j < offsets[v + 1]   (edges sorted by receiver; nodes without edges get zeros) */
 int skgc_segment_sum(const float* e, const int* offsets, float* out, int n_nodes, int N, void* stream);
 
+/* Second Linear of an MLP fused with its LayerNorm, latent width 512 only:
+ *   out[r][:] = (res ? res[r][:] : 0) + LayerNorm( a[r][0..K) W^T + bias ) * gamma + beta,   r < rows, 512 columns, eps 1e-5
+ * a: fp32 rows with leading dimension lda; W: fp16 hi/lo planes [512][ldw] from skgc_prepare_weight_perm8; out may alias res. */
+int skgc_prepare_weight_perm8(const float* src, int N, int K, void* dst, long long plane, int ldw, void* stream);
+int skgc_linear_layer_norm(const float* a, long long lda, int K, const void* w, long long w_plane, int ldw, const float* bias, const float* gamma,
+                           const float* beta, const float* res, float* out, long long rows, void* stream);
+
 /* dst[i] += src[i], i < n (n % 4 == 0): the residual update of the edge latents */
 int skgc_add_inplace(float* dst, const float* src, long long n, void* stream);
 

@@ -56,6 +56,40 @@ struct ALGather {
     __device__ __forceinline__ uint4 direct(const Raw&) const { return make_uint4(0, 0, 0, 0); }
 };
 
+// second Linear of an MLP fused with its LayerNorm (+ residual): the tile spans the whole latent (N = 512 = LayerNorm width), so
+// the pre-norm activations never go to HBM (for the 3.1 M mesh->grid edges that is 12.8 GB of traffic per step).  The weight is
+// prepared in perm8 row order (common.h): a lane's accumulators of a fragment pair are 8 consecutive columns -> 32-byte row pieces.
+template <bool RES>
+struct SinkRowsF32 {
+    float* out;
+    const float* res;            // RES: out[row] = res[row] + y (out may alias res)
+    static constexpr bool kLoads = RES;
+    __device__ __forceinline__ f32x8 load(long long row, int ld, int c) const {
+        f32x8 o;
+        o.a = *reinterpret_cast<const float4*>(res + row * ld + c);
+        o.b = *reinterpret_cast<const float4*>(res + row * ld + c + 4);
+        return o;
+    }
+    __device__ __forceinline__ void put(long long row, int ld, int c, const float (&y)[8], const f32x8& old) const {
+        float* p = out + row * ld + c;
+        if constexpr (RES) {
+            *reinterpret_cast<float4*>(p) = make_float4(old.a.x + y[0], old.a.y + y[1], old.a.z + y[2], old.a.w + y[3]);
+            *reinterpret_cast<float4*>(p + 4) = make_float4(old.b.x + y[4], old.b.y + y[5], old.b.z + y[6], old.b.w + y[7]);
+        } else {
+            *reinterpret_cast<float4*>(p) = make_float4(y[0], y[1], y[2], y[3]);
+            *reinterpret_cast<float4*>(p + 4) = make_float4(y[4], y[5], y[6], y[7]);
+        }
+    }
+};
+
+typedef TileCfg<64, 512, 32, 1, 8> TLN;
+
+template <bool RES>
+__global__ void __launch_bounds__(TLN::THREADS) linear_ln_kernel(const GemmArgs<PrecF16x3, ALStrided, EpLayerNorm<RowMapIndexed, SinkRowsF32<RES>>> g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    gemm_body<PrecF16x3, TLN, ALStrided, EpLayerNorm<RowMapIndexed, SinkRowsF32<RES>>, true>(g, smem);
+}
+
 __global__ void __launch_bounds__(TG::THREADS) gather_gemm_kernel(const GemmArgs<PrecF16x3, ALGather, EpStrided> g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     gemm_body<PrecF16x3, TG, ALGather, EpStrided, true>(g, smem);
@@ -175,6 +209,41 @@ int skgc_segment_sum(const float* e, const int* offsets, float* out, int n_nodes
     if (!e || !offsets || !out || n_nodes <= 0 || N <= 0 || (N & 3)) return SKGC_E_ARG;
     hipLaunchKernelGGL(segment_sum_kernel, dim3((unsigned)((n_nodes + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream), e, offsets, out, n_nodes, N);
     return hipGetLastError() == hipSuccess ? 0 : SKGC_E_HIP;
+}
+
+int skgc_prepare_weight_perm8(const float* src, int N, int K, void* dst, long long plane, int ldw, void* stream) {
+    if (!src || !dst || N <= 0 || K <= 0 || (N & 31) || ldw < K || (ldw & 7) || plane < (long long)N * ldw) return SKGC_E_ARG;
+    const hipError_t e = prep_weight<f16, 2>(src, static_cast<f16*>(dst), plane, N, K, ldw, K, 1, 0, 1, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? 0 : SKGC_E_HIP;
+}
+
+int skgc_linear_layer_norm(const float* a, long long lda, int K, const void* w, long long w_plane, int ldw, const float* bias, const float* gamma,
+                           const float* beta, const float* res, float* out, long long rows, void* stream) {
+    constexpr int N = TLN::BN;
+    if (!a || !w || !gamma || !beta || !out || rows <= 0 || rows > 0x7fffffff || K <= 0 || lda < K || (ldw & 7) || ldw < K) return SKGC_E_ARG;
+    const dim3 grid(1, (unsigned)((rows + TLN::BM - 1) / TLN::BM));
+    if (grid.y > 65535 * 16) return SKGC_E_ARG;
+    constexpr int smem = gemm_smem_bytes<PrecF16x3, TLN>() + kEpiScratch;
+    const ALStrided al{a, (int)rows, K, 1 << 30, lda, 0, 1, nullptr, nullptr, nullptr, 0, 0};
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    auto launch = [&](auto res_c) {
+        constexpr bool RES = decltype(res_c)::value;
+        typedef EpLayerNorm<RowMapIndexed, SinkRowsF32<RES>> EP;
+        GemmArgs<PrecF16x3, ALStrided, EP> g;
+        g.al = al;
+        g.ep = EP{RowMapIndexed{nullptr}, SinkRowsF32<RES>{out, res}, bias, gamma, beta, 1e-5f};
+        g.W = static_cast<const f16*>(w);
+        g.w_plane = w_plane;
+        g.ldw = ldw;
+        g.M = (int)rows; g.N = N; g.K = K;
+        auto kern = linear_ln_kernel<RES>;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, grid, dim3(TLN::THREADS), smem, st, g);
+        return hipGetLastError();
+    };
+    const hipError_t e = res ? launch(std::true_type{}) : launch(std::false_type{});
+    return e == hipSuccess ? 0 : SKGC_E_HIP;
 }
 
 int skgc_add_inplace(float* dst, const float* src, long long n, void* stream) {

@@ -25,7 +25,8 @@ from .mesh import GraphStructure, build_graph
 from .spec import N_FORCING, N_STATIC, GraphcastConfig, mlp_names, param_spec
 
 _LIB_PATH = Path(__file__).resolve().parent.parent / "lib" / "libskyrim_graphcast.so"
-EXPORTS = ["skgc_abi_version", "skgc_gather_gemm", "skgc_layer_norm", "skgc_segment_sum", "skgc_add_inplace"]
+EXPORTS = ["skgc_abi_version", "skgc_gather_gemm", "skgc_layer_norm", "skgc_segment_sum", "skgc_add_inplace", "skgc_prepare_weight_perm8",
+           "skgc_linear_layer_norm"]
 
 
 class GatherDesc(ctypes.Structure):
@@ -50,6 +51,9 @@ def load_library():
     lib.skgc_layer_norm.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_longlong, ctypes.c_int, ctypes.c_void_p]
     lib.skgc_segment_sum.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
     lib.skgc_add_inplace.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_void_p]
+    lib.skgc_prepare_weight_perm8.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_void_p]
+    lib.skgc_linear_layer_norm.argtypes = [ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int] + \
+        [ctypes.c_void_p] * 5 + [ctypes.c_longlong, ctypes.c_void_p]
     for name in EXPORTS:
         getattr(lib, name).restype = ctypes.c_int
     _lib = lib
@@ -75,6 +79,7 @@ class GraphcastEngine:
         self.prepared = False
         self.profiling = False
         self._events = []
+        self.fused_ln = self.cfg.latent == 512 and not os.environ.get("SKGC_UNFUSED_LN")
         self.state_shape = (self.cfg.n_vars, self.cfg.n_lat, self.cfg.n_lon)
 
     def _stream(self):
@@ -139,6 +144,13 @@ class GraphcastEngine:
         m = self.m[name]
         L = self.cfg.latent
         self._fc1(m["fc1"], m["b1"], sources, rows, self.b_h, label=label or name.split(".")[0])
+        if m.get("fc2p") is not None:                # latent 512: second Linear + LayerNorm (+ residual) in one kernel
+            buf, plane, ldw = m["fc2p"]
+            self._mark(label or name.split(".")[0], 2.0 * rows * L * L)
+            _check(self.lib.skgc_linear_layer_norm(self.b_h.data_ptr(), L, L, buf.data_ptr(), plane, ldw, m["b2"].data_ptr(), m["g"].data_ptr(),
+                                                   m["b"].data_ptr(), res.data_ptr() if res is not None else None, out.data_ptr(), rows, self._stream()),
+                   "skgc_linear_layer_norm")
+            return
         self._gemm(self.b_h, m["fc2"], self.b_t, rows, a_sm=L, a_sk=1, o_sm=L, o_sn=1, bias=m["b2"], label=label or name.split(".")[0])
         self._ln(self.b_t, m["g"], m["b"], res, out, rows)
 
@@ -162,6 +174,12 @@ class GraphcastEngine:
                 self.m[name] = dict(fc1=_sf._Weight(weng, p[name + ".fc1.weight"]), b1=f32(p[name + ".fc1.bias"]),
                                     fc2=_sf._Weight(weng, w2), b2=f32(b2),
                                     g=f32(p[name + ".ln.weight"]) if ln else None, b=f32(p[name + ".ln.bias"]) if ln else None)
+                if ln and self.fused_ln:                                 # perm8 copy of the second Linear for the fused Linear + LayerNorm kernel
+                    src = f32(w2)
+                    planes = torch.empty(2 * L * L, dtype=torch.float16, device=dev)
+                    _check(self.lib.skgc_prepare_weight_perm8(src.data_ptr(), L, L, planes.data_ptr(), L * L, L, self._stream()), "skgc_prepare_weight_perm8")
+                    torch.cuda.current_stream(dev).synchronize()
+                    self.m[name]["fc2p"] = (planes, L * L, L)
             n_state = 2 * c.n_vars
             one, zero = torch.ones(N_FORCING + N_STATIC + 3, dtype=torch.float64), torch.zeros(N_FORCING + N_STATIC + 3, dtype=torch.float64)
             self.in_scale = f32(torch.cat([1.0 / std, 1.0 / std, one]))

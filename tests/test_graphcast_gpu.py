@@ -65,6 +65,21 @@ def test_matches_golden_fixture():
     assert (np.abs(y[:, ::2, ::4] - gold["step1_sub"]) / gold["increment_absmax"][:, None, None]).max() < 1e-3
 
 
+def test_latent_512_uses_the_fused_linear_layer_norm_kernel():
+    """The production latent width takes the fused second-Linear + LayerNorm (+ residual) kernel; same parity bar."""
+    from skyrim_amd.graphcast.engine import GraphcastEngine
+    cfg = GraphcastConfig(n_lat=33, n_lon=64, splits=2, latent=512, steps=2, n_vars=7)
+    eng = GraphcastEngine(cfg, "cuda:0")
+    assert eng.fused_ln
+    p = init_synthetic(cfg, 0)
+    eng.load_params(p)
+    x0, x1 = synthetic_states(cfg, 0)
+    f = forcings(cfg, 1000.0)
+    y = eng.step(x0.cuda(), x1.cuda(), f.cuda())
+    ref = O.forward(p, eng.graph, x0, x1, f, cfg)
+    assert O.per_channel_rel_err(y.cpu(), ref).max().item() < 1e-5 and O.increment_rel_err(y.cpu(), ref, x1).max().item() < 1e-3
+
+
 def test_building_blocks_against_torch():
     from skyrim_amd.graphcast import engine as E
     eng = E.GraphcastEngine(CONFIGS["tiny"], "cuda:0")
