@@ -93,7 +93,7 @@ def test_spec():
 def test_graphcast_library_exports_declared_symbols_and_rejects_bad_arguments():
     header = (Path(__file__).resolve().parent.parent / "include" / "skyrim_graphcast.h").read_text()
     header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
-    syms = sorted(set(re.findall(r"\b(skgc_[a-z_]+)\s*\(", header)))
+    syms = sorted(set(re.findall(r"\b(skgc_[a-z0-9_]+)\s*\(", header)))
     lib = E.load_library()
     assert set(syms) == set(E.EXPORTS) and all(hasattr(lib, s) for s in syms)
     assert lib.skgc_abi_version() == 1
