@@ -9,7 +9,7 @@
  *                        (edge latent | sender node | receiver node), bias + swish fused
  *     sksfno_gemm_run    (include/skyrim_sfno.h) second Linear, and the output layer that writes the next state
  *     skgc_layer_norm    LayerNorm over the latent (+ residual)
- *     skgc_segment_sum   sum of edge rows per receiver (edges sorted by receiver, CSR offsets)
+ *     skgc_segment_sum   sum of edge rows per receiver (edges sorted by receiver, CSR offsets), with the edges' residual update
  * All pointers are device pointers; calls are asynchronous on `stream` (a hipStream_t); nothing is allocated inside. */
 #ifndef SKYRIM_GRAPHCAST_H
 #define SKYRIM_GRAPHCAST_H
@@ -50,8 +50,9 @@ int skgc_gather_gemm(const skgc_gather_gemm_desc* desc, void* stream);
 /* out[r][:] = (res ? res[r][:] : 0) + LayerNorm(x[r][:]) * gamma + beta  over N columns (eps 1e-5); out may alias res or x */
 int skgc_layer_norm(const float* x, const float* gamma, const float* beta, const float* res, float* out, long long rows, int N, void* stream);
 
-/* out[v][:] = sum of e[j][:] for offsets[v] <= j < offsets[v + 1]   (edges sorted by receiver; nodes without edges get zeros) */
-int skgc_segment_sum(const float* e, const int* offsets, float* out, int n_nodes, int N, void* stream);
+/* out[v][:] = sum of e[j][:] for offsets[v] <= j < offsets[v + 1]   (edges sorted by receiver; nodes without edges get zeros);
+ * acc (nullable): acc[j][:] += e[j][:] for every edge row on the way (the residual update of the edge latents) */
+int skgc_segment_sum(const float* e, const int* offsets, float* out, float* acc, int n_nodes, int N, void* stream);
 
 /* Second Linear of an MLP fused with its LayerNorm, latent width 512 only:
  *   out[r][:] = (res ? res[r][:] : 0) + LayerNorm( a[r][0..K) W^T + bias ) * gamma + beta,   r < rows, 512 columns, eps 1e-5
@@ -59,9 +60,6 @@ int skgc_segment_sum(const float* e, const int* offsets, float* out, int n_nodes
 int skgc_prepare_weight_perm8(const float* src, int N, int K, void* dst, long long plane, int ldw, void* stream);
 int skgc_linear_layer_norm(const float* a, long long lda, int K, const void* w, long long w_plane, int ldw, const float* bias, const float* gamma,
                            const float* beta, const float* res, float* out, long long rows, void* stream);
-
-/* dst[i] += src[i], i < n (n % 4 == 0): the residual update of the edge latents */
-int skgc_add_inplace(float* dst, const float* src, long long n, void* stream);
 
 #ifdef __cplusplus
 }

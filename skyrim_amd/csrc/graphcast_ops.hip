@@ -134,28 +134,26 @@ __global__ void __launch_bounds__(256) layer_norm_kernel(const float* __restrict
 }
 
 // one wave per node, float4 per lane per pass (N % 4 == 0)
-__global__ void __launch_bounds__(256) segment_sum_kernel(const float* __restrict__ e, const int* __restrict__ offsets, float* __restrict__ out, int n_nodes, int N) {
+// acc (optional): the residual update of the edge latents rides along, acc[j] += e[j], since every edge row is read here anyway
+__global__ void __launch_bounds__(256) segment_sum_kernel(const float* __restrict__ e, const int* __restrict__ offsets, float* __restrict__ out,
+                                                          float* acc, int n_nodes, int N) {
     const int lane = threadIdx.x & 63;
     const int v = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (v >= n_nodes) return;
     const int j0 = offsets[v], j1 = offsets[v + 1];
     for (int c = lane * 4; c < N; c += 256) {
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int j = j0; j < j1; ++j) {
             const float4 t = *reinterpret_cast<const float4*>(e + (long long)j * N + c);
-            acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+            sum.x += t.x; sum.y += t.y; sum.z += t.z; sum.w += t.w;
+            if (acc != nullptr) {
+                float4 u = *reinterpret_cast<float4*>(acc + (long long)j * N + c);
+                u.x += t.x; u.y += t.y; u.z += t.z; u.w += t.w;
+                *reinterpret_cast<float4*>(acc + (long long)j * N + c) = u;
+            }
         }
-        *reinterpret_cast<float4*>(out + (long long)v * N + c) = acc;
+        *reinterpret_cast<float4*>(out + (long long)v * N + c) = sum;
     }
-}
-
-__global__ void __launch_bounds__(256) add_inplace_kernel(float* __restrict__ dst, const float* __restrict__ src, long long n4) {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n4) return;
-    float4 a = reinterpret_cast<float4*>(dst)[i];
-    const float4 b = reinterpret_cast<const float4*>(src)[i];
-    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
-    reinterpret_cast<float4*>(dst)[i] = a;
 }
 
 }  // namespace skp
@@ -205,9 +203,9 @@ int skgc_layer_norm(const float* x, const float* gamma, const float* beta, const
     return hipGetLastError() == hipSuccess ? 0 : SKGC_E_HIP;
 }
 
-int skgc_segment_sum(const float* e, const int* offsets, float* out, int n_nodes, int N, void* stream) {
+int skgc_segment_sum(const float* e, const int* offsets, float* out, float* acc, int n_nodes, int N, void* stream) {
     if (!e || !offsets || !out || n_nodes <= 0 || N <= 0 || (N & 3)) return SKGC_E_ARG;
-    hipLaunchKernelGGL(segment_sum_kernel, dim3((unsigned)((n_nodes + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream), e, offsets, out, n_nodes, N);
+    hipLaunchKernelGGL(segment_sum_kernel, dim3((unsigned)((n_nodes + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream), e, offsets, out, acc, n_nodes, N);
     return hipGetLastError() == hipSuccess ? 0 : SKGC_E_HIP;
 }
 
@@ -244,12 +242,6 @@ int skgc_linear_layer_norm(const float* a, long long lda, int K, const void* w, 
     };
     const hipError_t e = res ? launch(std::true_type{}) : launch(std::false_type{});
     return e == hipSuccess ? 0 : SKGC_E_HIP;
-}
-
-int skgc_add_inplace(float* dst, const float* src, long long n, void* stream) {
-    if (!dst || !src || n <= 0 || (n & 3)) return SKGC_E_ARG;
-    hipLaunchKernelGGL(add_inplace_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), dst, src, n / 4);
-    return hipGetLastError() == hipSuccess ? 0 : SKGC_E_HIP;
 }
 
 }  // extern "C"

@@ -25,7 +25,7 @@ from .mesh import GraphStructure, build_graph
 from .spec import N_FORCING, N_STATIC, GraphcastConfig, mlp_names, param_spec
 
 _LIB_PATH = Path(__file__).resolve().parent.parent / "lib" / "libskyrim_graphcast.so"
-EXPORTS = ["skgc_abi_version", "skgc_gather_gemm", "skgc_layer_norm", "skgc_segment_sum", "skgc_add_inplace", "skgc_prepare_weight_perm8",
+EXPORTS = ["skgc_abi_version", "skgc_gather_gemm", "skgc_layer_norm", "skgc_segment_sum", "skgc_prepare_weight_perm8",
            "skgc_linear_layer_norm"]
 
 
@@ -49,8 +49,7 @@ def load_library():
     lib = ctypes.CDLL(path)
     lib.skgc_gather_gemm.argtypes = [ctypes.POINTER(GatherDesc), ctypes.c_void_p]
     lib.skgc_layer_norm.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_longlong, ctypes.c_int, ctypes.c_void_p]
-    lib.skgc_segment_sum.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
-    lib.skgc_add_inplace.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_void_p]
+    lib.skgc_segment_sum.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
     lib.skgc_prepare_weight_perm8.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_void_p]
     lib.skgc_linear_layer_norm.argtypes = [ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int] + \
         [ctypes.c_void_p] * 5 + [ctypes.c_longlong, ctypes.c_void_p]
@@ -135,9 +134,10 @@ class GraphcastEngine:
         _check(self.lib.skgc_layer_norm(x.data_ptr(), g.data_ptr(), b.data_ptr(), res.data_ptr() if res is not None else None, out.data_ptr(),
                                         rows, self.cfg.latent, self._stream()), "skgc_layer_norm")
 
-    def _segsum(self, e, offsets, out, n_nodes):
+    def _segsum(self, e, offsets, out, n_nodes, acc=None):
         self._mark("segment_sum")
-        _check(self.lib.skgc_segment_sum(e.data_ptr(), offsets.data_ptr(), out.data_ptr(), n_nodes, self.cfg.latent, self._stream()), "skgc_segment_sum")
+        _check(self.lib.skgc_segment_sum(e.data_ptr(), offsets.data_ptr(), out.data_ptr(), acc.data_ptr() if acc is not None else None, n_nodes,
+                                         self.cfg.latent, self._stream()), "skgc_segment_sum")
 
     def _mlp(self, name, sources, rows, out, res=None, label=None):
         """out = (res +) LayerNorm(fc2(swish(fc1(concat(sources)))));  out may alias res."""
@@ -247,10 +247,8 @@ class GraphcastEngine:
             for i in range(c.steps):
                 de = self.de
                 self._mlp(f"proc.{i}.edge", [(self.em, None, L), (self.vm, self.me_s, L), (self.vm, self.me_r, L)], self.EM, de, label="processor")
-                self._segsum(de, self.me_off, self.agg_m, self.graph.n_mesh)
+                self._segsum(de, self.me_off, self.agg_m, self.graph.n_mesh, acc=self.em)      # receiver sum; em += de rides along
                 self._mlp(f"proc.{i}.node", [(self.vm, None, L), (self.agg_m, None, L)], self.graph.n_mesh, self.vm, res=self.vm, label="processor")
-                self._mark("edge_residual")
-                _check(self.lib.skgc_add_inplace(self.em.data_ptr(), de.data_ptr(), self.EM * L, self._stream()), "skgc_add_inplace")
             # decoder: mesh -> grid
             self._mlp("m2g.edge", [(self.e2_0, None, L), (self.vm, self.m2g_s, L), (self.vg, self.m2g_r, L)], self.E2, self.e2, label="decoder")
             self._segsum(self.e2, self.m2g_off, self.agg_g, P)

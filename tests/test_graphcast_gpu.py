@@ -96,9 +96,12 @@ def test_building_blocks_against_torch():
     off = torch.cat([torch.zeros(1, dtype=torch.int64), counts.cumsum(0)]).int()
     e = torch.randn(int(off[-1]), L, generator=gen)
     out = torch.full((50, L), 7.0, device="cuda")
-    eng._segsum(e.cuda(), off.cuda(), out, 50)
+    acc0 = torch.randn(int(off[-1]), L, generator=gen)
+    accd = acc0.cuda()
+    eng._segsum(e.cuda(), off.cuda(), out, 50, acc=accd)
     ref = torch.zeros(50, L).index_add_(0, torch.repeat_interleave(torch.arange(50), counts), e)
     assert torch.allclose(out.cpu(), ref, atol=1e-5) and float(out[7].abs().max()) == 0.0
+    assert torch.allclose(accd.cpu(), acc0 + e, atol=1e-6)
     # gather + concat + Linear + swish
     n0, n1, rows = 300, 40, 777
     s0, s1, s2 = torch.randn(rows, L, generator=gen), torch.randn(n0, L, generator=gen), torch.randn(n1, L, generator=gen)

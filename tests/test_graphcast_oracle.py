@@ -100,5 +100,4 @@ def test_graphcast_library_exports_declared_symbols_and_rejects_bad_arguments():
     assert lib.skgc_gather_gemm(None, None) == -1
     assert lib.skgc_gather_gemm(ctypes.byref(E.GatherDesc()), None) == -1
     assert lib.skgc_layer_norm(None, None, None, None, None, 4, 32, None) == -1
-    assert lib.skgc_segment_sum(None, None, None, 4, 32, None) == -1
-    assert lib.skgc_add_inplace(None, None, 16, None) == -1
+    assert lib.skgc_segment_sum(None, None, None, None, 4, 32, None) == -1
