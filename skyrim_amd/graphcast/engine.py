@@ -21,7 +21,7 @@ import numpy as np
 import torch
 
 from ..sfno import engine as _sf
-from .mesh import GraphStructure, build_graph
+from .mesh import GraphStructure, build_graph, latitude_band, shard_graph
 from .spec import N_FORCING, N_STATIC, GraphcastConfig, mlp_names, param_spec
 
 _LIB_PATH = Path(__file__).resolve().parent.parent / "lib" / "libskyrim_graphcast.so"
@@ -65,8 +65,17 @@ def _check(code: int, what: str):
 
 
 class GraphcastEngine:
-    def __init__(self, cfg: GraphcastConfig | None = None, device: str | torch.device = "cuda:0", graph: GraphStructure | None = None):
+    def __init__(self, cfg: GraphcastConfig | None = None, device: str | torch.device = "cuda:0", graph: GraphStructure | None = None,
+                 shard: tuple[int, int] = (0, 1), reduce_fn=None):
+        """``shard = (rank, world)``: grid-sharded run over ``world`` GPUs (BASELINE configs[3]) -- this engine owns a latitude band
+        of the grid (states, forcings and outputs have ``lat1 - lat0`` rows), the mesh is replicated, and the only exchange of a step
+        is ``reduce_fn(agg)`` = the sum over ranks of the (n_mesh, latent) aggregate of the grid->mesh messages (default:
+        ``torch.distributed.all_reduce`` = RCCL over xGMI; 84 MB at full size).  ``graph``: the FULL graph (built if omitted)."""
         self.cfg = cfg or GraphcastConfig()
+        self.rank, self.world = shard
+        if not (0 <= self.rank < self.world <= self.cfg.n_lat):
+            raise ValueError("shard = (rank, world) with 0 <= rank < world <= n_lat")
+        self.reduce_fn = reduce_fn
         if not torch.cuda.is_available():
             raise RuntimeError("GraphcastEngine needs an MI355X: the GraphCast path has no CPU fallback")
         if self.cfg.latent % 8 != 0:
@@ -74,12 +83,14 @@ class GraphcastEngine:
         self.lib = load_library()
         self.sf = _sf.load_library()
         self.device = torch.device(device)
-        self.graph = graph or build_graph(self.cfg.n_lat, self.cfg.n_lon, self.cfg.splits)
+        full = graph or build_graph(self.cfg.n_lat, self.cfg.n_lon, self.cfg.splits)
+        self.lat0, self.lat1 = latitude_band(self.cfg.n_lat, self.rank, self.world)
+        self.graph = full if self.world == 1 else shard_graph(full, self.cfg.n_lat, self.cfg.n_lon, self.rank, self.world)
         self.prepared = False
         self.profiling = False
         self._events = []
         self.fused_ln = self.cfg.latent == 512 and not os.environ.get("SKGC_UNFUSED_LN")
-        self.state_shape = (self.cfg.n_vars, self.cfg.n_lat, self.cfg.n_lon)
+        self.state_shape = (self.cfg.n_vars, self.lat1 - self.lat0, self.cfg.n_lon)
 
     def _stream(self):
         return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
@@ -200,7 +211,7 @@ class GraphcastEngine:
             rows_max = max(P, E1, E2, EM, g.n_mesh)
             self.b_h, self.b_t = buf(rows_max, L), buf(rows_max, L)
             self.feat = torch.zeros(c.grid_in, P, dtype=torch.float32, device=dev)          # [186][n_grid]: states, forcings, static, structural
-            self.feat[n_state + N_FORCING:n_state + N_FORCING + N_STATIC] = f32(params["static"]).reshape(N_STATIC, P)
+            self.feat[n_state + N_FORCING:n_state + N_FORCING + N_STATIC] = f32(params["static"][:, self.lat0:self.lat1]).reshape(N_STATIC, P)
             self.feat[n_state + N_FORCING + N_STATIC:] = torch.from_numpy(g.grid_node_feat.T.copy()).to(dev)
             self.vg, self.vm = buf(P, L), buf(g.n_mesh, L)
             self.agg_m, self.agg_g = buf(g.n_mesh, L), buf(P, L)
@@ -220,9 +231,10 @@ class GraphcastEngine:
         if not self.prepared:
             raise RuntimeError("GraphcastEngine.step before load_params: not prepared")
         c, L = self.cfg, self.cfg.latent
-        for t, shape in ((x_prev, self.state_shape), (x_cur, self.state_shape), (forcing, (N_FORCING, c.n_lat, c.n_lon))):
+        fshape = (N_FORCING,) + self.state_shape[1:]
+        for t, shape in ((x_prev, self.state_shape), (x_cur, self.state_shape), (forcing, fshape)):
             if t.device != self.device or t.dtype != torch.float32 or tuple(t.shape) != shape or not t.is_contiguous():
-                raise ValueError(f"expected contiguous float32 tensors of shape {self.state_shape} (states) / {(N_FORCING, c.n_lat, c.n_lon)} on {self.device}")
+                raise ValueError(f"expected contiguous float32 tensors of shape {self.state_shape} (states) / {fshape} (forcings) on {self.device}")
         P, V = self.P, c.n_vars
         with torch.cuda.device(self.device):
             y = out if out is not None else torch.empty(self.state_shape, dtype=torch.float32, device=self.device)
@@ -240,6 +252,13 @@ class GraphcastEngine:
             # encoder: grid -> mesh
             self._mlp("g2m.edge", [(self.e1_0, None, L), (self.vg, self.g2m_s, L), (self.vm0, self.g2m_r, L)], self.E1, self.e1, label="encoder")
             self._segsum(self.e1, self.g2m_off, self.agg_m, self.graph.n_mesh)
+            if self.world > 1:                       # the one exchange of a grid-sharded step: sum the partial aggregates over ranks
+                self._mark("exchange")
+                if self.reduce_fn is not None:
+                    self.reduce_fn(self.agg_m)
+                else:
+                    import torch.distributed as dist
+                    dist.all_reduce(self.agg_m, op=dist.ReduceOp.SUM)
             self._mlp("g2m.mesh_node", [(self.vm0, None, L), (self.agg_m, None, L)], self.graph.n_mesh, self.vm, res=self.vm0, label="encoder")
             self._mlp("g2m.grid_node", [(self.vg, None, L)], P, self.vg, res=self.vg, label="encoder")
             # processor on the multi-mesh

@@ -181,3 +181,25 @@ def build_graph(n_lat: int, n_lon: int, splits: int) -> GraphStructure:
         g2m_edge_feat=edge_features(grid_pos[g2m[:, 0]], v[g2m[:, 1]]),
         m2g_edge_feat=edge_features(v[m2g[:, 0]], grid_pos[m2g[:, 1]]),
         mesh_node_feat=node_features(v), grid_node_feat=node_features(grid_pos), faces=f)
+
+
+def latitude_band(n_lat: int, rank: int, world: int) -> tuple[int, int]:
+    """Rows [lat0, lat1) of the grid owned by ``rank`` (contiguous bands, sizes differ by at most one row)."""
+    return rank * n_lat // world, (rank + 1) * n_lat // world
+
+
+def shard_graph(g: GraphStructure, n_lat: int, n_lon: int, rank: int, world: int) -> GraphStructure:
+    """The part of the graph a rank of a grid-sharded run works on: its latitude band of grid nodes, the grid->mesh edges SENT
+    by them and the mesh->grid edges RECEIVED by them; the mesh (nodes, multi-mesh edges) is replicated.  The only exchange of a
+    step is the sum over ranks of the per-mesh-node aggregate of the grid->mesh messages (n_mesh x latent floats)."""
+    lat0, lat1 = latitude_band(n_lat, rank, world)
+    p0, p1 = lat0 * n_lon, lat1 * n_lon
+    keep = (g.g2m_edges[:, 0] >= p0) & (g.g2m_edges[:, 0] < p1)
+    g2m = g.g2m_edges[keep].copy()
+    g2m[:, 0] -= p0
+    m2g = g.m2g_edges[3 * p0:3 * p1].copy()                      # sorted by receiver: a contiguous slice
+    m2g[:, 1] -= p0
+    return GraphStructure(
+        n_grid=p1 - p0, n_mesh=g.n_mesh, mesh_pos=g.mesh_pos, grid_pos=g.grid_pos[p0:p1], mesh_edges=g.mesh_edges, g2m_edges=g2m, m2g_edges=m2g,
+        mesh_edge_feat=g.mesh_edge_feat, g2m_edge_feat=g.g2m_edge_feat[keep], m2g_edge_feat=g.m2g_edge_feat[3 * p0:3 * p1],
+        mesh_node_feat=g.mesh_node_feat, grid_node_feat=g.grid_node_feat[p0:p1], faces=g.faces)

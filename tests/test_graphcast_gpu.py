@@ -80,6 +80,54 @@ def test_latent_512_uses_the_fused_linear_layer_norm_kernel():
     assert O.per_channel_rel_err(y.cpu(), ref).max().item() < 1e-5 and O.increment_rel_err(y.cpu(), ref, x1).max().item() < 1e-3
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_grid_sharded_step_equals_the_single_gpu_step(world):
+    """BASELINE configs[3]: the grid split over `world` ranks (here: `world` engines on one GPU, one thread each, the exchange a
+    barrier + sum standing in for the RCCL all-reduce) reproduces the unsharded step; the only data exchanged is the mesh aggregate."""
+    import threading
+    from skyrim_amd.graphcast.engine import GraphcastEngine
+    from skyrim_amd.graphcast.mesh import build_graph
+    cfg = CONFIGS["tiny"]
+    full = build_graph(cfg.n_lat, cfg.n_lon, cfg.splits)
+    p = init_synthetic(cfg, 0)
+    x0, x1 = synthetic_states(cfg, 0)
+    f = forcings(cfg, 1000.0)
+    single = GraphcastEngine(cfg, "cuda:0", graph=full)
+    single.load_params(p)
+    want = single.step(x0.cuda(), x1.cuda(), f.cuda()).cpu()
+    barrier, lock, total, exchanged = threading.Barrier(world), threading.Lock(), {}, []
+
+    def reduce_fn(t):
+        torch.cuda.synchronize()
+        with lock:
+            total["sum"] = total.get("sum", 0) + t.clone()
+            exchanged.append(t.numel())
+        barrier.wait()
+        t.copy_(total["sum"])
+        torch.cuda.synchronize()
+        barrier.wait()
+
+    outs, errs = [None] * world, []
+
+    def run(r):
+        try:
+            e = GraphcastEngine(cfg, "cuda:0", graph=full, shard=(r, world), reduce_fn=reduce_fn)
+            e.load_params(p)
+            sl = slice(e.lat0, e.lat1)
+            outs[r] = e.step(x0[:, sl].contiguous().cuda(), x1[:, sl].contiguous().cuda(), f[:, sl].contiguous().cuda()).cpu()
+        except Exception as ex:                      # surface thread failures in the main thread
+            errs.append(ex)
+            barrier.abort()
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    assert not errs, errs
+    got = torch.cat(outs, dim=1)
+    assert got.shape == want.shape and exchanged == [full.n_mesh * cfg.latent] * world
+    assert O.increment_rel_err(got, want, x1).max().item() < 1e-4          # summation order of the aggregate differs, nothing else
+
+
 def test_building_blocks_against_torch():
     from skyrim_amd.graphcast import engine as E
     eng = E.GraphcastEngine(CONFIGS["tiny"], "cuda:0")

@@ -10,7 +10,7 @@ import torch
 
 from oracle import graphcast_oracle as O
 from skyrim_amd.graphcast import engine as E
-from skyrim_amd.graphcast.mesh import build_graph, edge_features, faces_to_edges, icosahedron, lat_lon_to_xyz, refine
+from skyrim_amd.graphcast.mesh import build_graph, edge_features, faces_to_edges, icosahedron, lat_lon_to_xyz, latitude_band, refine, shard_graph
 from skyrim_amd.graphcast.spec import CHANNELS, GraphcastConfig, flops_per_step, forcings, init_synthetic, mlp_names, param_spec, synthetic_states
 
 TINY = GraphcastConfig(n_lat=33, n_lon=64, splits=2, latent=32, steps=3)
@@ -60,6 +60,26 @@ def test_edge_features_are_receiver_local():
     assert (fe[:, 2] > 0).all() and (np.abs(fe[:, 3]) < 0.02 * fe[:, 0]).all()
     assert (fn[:, 3] > 0).all() and (np.abs(fn[:, 2]) < 1e-6).all()
     assert np.allclose(fn[:, 0], fn[0, 0], rtol=1e-5)
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_grid_sharding_partitions_the_graph(world):
+    """BASELINE configs[3] / SURVEY 8(e): latitude bands of grid nodes; every grid->mesh edge belongs to the shard of its sender,
+    every mesh->grid edge to the shard of its receiver; the mesh is replicated."""
+    g = build_graph(33, 64, 2)
+    seen_g2m, rows = 0, 0
+    for r in range(world):
+        lat0, lat1 = latitude_band(33, r, world)
+        s = shard_graph(g, 33, 64, r, world)
+        assert s.n_grid == (lat1 - lat0) * 64 and s.n_mesh == g.n_mesh and s.mesh_edges is g.mesh_edges
+        assert s.g2m_edges[:, 0].min() >= 0 and s.g2m_edges[:, 0].max() < s.n_grid and (np.diff(s.g2m_edges[:, 1]) >= 0).all()
+        assert np.array_equal(s.m2g_edges[:, 1], np.repeat(np.arange(s.n_grid), 3))
+        assert np.array_equal(s.m2g_edges[:, 0], g.m2g_edges[3 * lat0 * 64:3 * lat1 * 64, 0])
+        assert len(s.g2m_edge_feat) == len(s.g2m_edges) and len(s.m2g_edge_feat) == len(s.m2g_edges) and len(s.grid_node_feat) == s.n_grid
+        seen_g2m += len(s.g2m_edges)
+        rows += s.n_grid
+    assert seen_g2m == len(g.g2m_edges) and rows == g.n_grid
+    assert latitude_band(33, 0, world)[0] == 0 and latitude_band(33, world - 1, world)[1] == 33
 
 
 def test_oracle_matches_golden_fixture():
