@@ -1,6 +1,7 @@
-"""GlobalModel / GlobalPrediction / GlobalPredictionRollout -- same names, arguments and behaviour as
+"""GlobalModel / GlobalPrediction / GlobalPredictionRollout -- the names, arguments and results of
 /root/reference/skyrim/core/models/base.py (:13-15 adjust_lead_time, :18-146 GlobalModel, :149-274
-GlobalPrediction, :277-303 GlobalPredictionRollout)."""
+GlobalPrediction, :277-303 GlobalPredictionRollout).  The model side drives a HIP TimeLoop; the prediction side works on
+``labeled.DataArray`` with regular-grid index arithmetic (lat / lon are uniform axes, so "nearest" is a division, not a search)."""
 from __future__ import annotations
 
 import datetime
@@ -8,6 +9,8 @@ import logging
 import time
 from pathlib import Path
 from typing import List
+
+import numpy as np
 
 from ...common import generate_forecast_id, save_forecast
 from ...datasource import IC_SOURCES, get_data_source
@@ -62,6 +65,11 @@ class GlobalModel:
     def __repr__(self) -> str:
         return f"{self.__class__.__name__}(model_name={self.model_name})"
 
+    @property
+    def source_label(self) -> str:
+        """What saved files are stamped with: the requested source, or "synthetic" when the data source is the seeded stand-in."""
+        return getattr(self.data_source, "label", None) or self.ic_source
+
     def predict_one_step(self, start_time: datetime.datetime, initial_condition=None) -> DataArray:
         # if initial_condition is None, it is fetched from the self.ic_source
         return run_basic_inference(model=self.model, n=1, data_source=self.data_source, time=start_time, x=initial_condition)
@@ -70,36 +78,61 @@ class GlobalModel:
         da = run_basic_inference(model=self.model, n=n_steps, data_source=self.data_source, time=start_time, x=None)
         return da.sel(channel=channels) if channels else da
 
-    def rollout(self, start_time: datetime.datetime, n_steps: int = 3, save: bool = True, save_config: dict = {}):
-        # returns the final prediction (2 time entries) and the paths of the intermediate predictions
-        pred, output_paths, source = None, [], self.ic_source
-        forecast_id = save_config.get("forecast_id", generate_forecast_id())
-        save_config.update({"forecast_id": forecast_id})
+    def rollout(self, start_time: datetime.datetime, n_steps: int = 3, save: bool = True, save_config: dict | None = None,
+                initial_condition=None):
+        """Final prediction (2 time entries) + the paths of the per-step files.
+
+        ``initial_condition`` (the reference's base.py:127 TODO): a saved forecast path or a DataArray whose last
+        ``n_history_levels`` time entries are the state at ``start_time``; default: fetched from the data source.
+        A ``save_config`` dict handed in by the caller receives the forecast id drawn here, as in the reference
+        (base.py:129-130); there is no shared ``{}`` default, so an id never leaks from one call into the next."""
+        cfg = dict(save_config or {})
+        cfg.setdefault("forecast_id", generate_forecast_id())
+        if save_config is not None:
+            save_config["forecast_id"] = cfg["forecast_id"]
+        pred, output_paths = initial_condition, []
+        source = "file" if initial_condition is not None else self.source_label
         for n in range(n_steps):
             pred = self.predict_one_step(start_time, initial_condition=pred)
             pred_time = start_time + self.time_step
             if save:
-                output_paths.append(save_forecast(pred, self.model_name, start_time, pred_time, source, config=save_config))
+                output_paths.append(save_forecast(pred, self.model_name, start_time, pred_time, source, config=cfg))
             start_time, source = pred_time, "file"
             logger.info(f"Rollout step {n + 1}/{n_steps} completed")
         return pred, output_paths
 
 
+def _axis_index(axis: np.ndarray, x: float) -> tuple[int, bool]:
+    """(index of the axis value nearest to x, whether it is an exact hit).  Uniform axes (lat 90..-90, lon 0..359.75) are
+    inverted arithmetically; anything else falls back to a linear scan."""
+    n = axis.shape[0]
+    if n > 1:
+        step = (float(axis[-1]) - float(axis[0])) / (n - 1)
+        if step != 0.0 and np.allclose(np.diff(axis), step, rtol=0, atol=abs(step) * 1e-6):
+            i = int(min(max(round((x - float(axis[0])) / step), 0), n - 1))
+            return i, bool(axis[i] == x)
+    i = int(np.abs(axis - x).argmin())
+    return i, bool(axis[i] == x)
+
+
 class GlobalPrediction:
+    """A forecast result, in memory or on disk, with point / wind accessors (reference base.py:149-274)."""
+
     filepath = None
     prediction = None
 
     def __init__(self, source, model_name: str = ""):
         self.model = model_name
-        if isinstance(source, (str, Path)):
+        if isinstance(source, DataArray):
+            data, self.filepath = source, None
+        elif isinstance(source, (str, Path)):
             self.filepath = Path(source)
-            self.prediction = open_dataarray(source).squeeze()
-        elif isinstance(source, DataArray):
-            self.filepath = None
-            self.prediction = source.squeeze()
+            data = open_dataarray(self.filepath)
         else:
             raise ValueError("Invalid source type.")
+        self.prediction = data.squeeze()          # size-1 dims dropped, as the reference does
 
+    # ---- what the array carries ----------------------------------------- #
     @property
     def coords(self):
         return self.prediction.coords
@@ -113,47 +146,75 @@ class GlobalPrediction:
         return self.prediction.channel
 
     def __repr__(self) -> str:
-        info = self.filepath if self.filepath else f"{type(self.prediction).__name__} with shape {self.prediction.shape}"
-        return f"GlobalPrediction(model={self.model},source={info})"
+        where = self.filepath or f"{type(self.prediction).__name__} with shape {self.prediction.shape}"
+        return f"GlobalPrediction(model={self.model},source={where})"
 
-    def slice(self, lat=None, lon=None, channel=None, n_step=None):
-        if channel is None:
-            data = self.prediction
-        else:
-            assert channel in self.channels, f"Variable {channel} not found in dataset."
-            data = self.prediction.sel(channel=channel)
-        if lat:
-            data = data.sel(lat=lat)
-        if lon:
-            data = data.sel(lon=lon)
-        if n_step and "time" in data.dims:
-            data = data.isel(time=n_step)
-        return data
-
-    def point(self, lat: float, lon: float, channel: str, n_step=1):
-        if lon < 0:
-            lon = 360 + lon
+    def _need(self, channel: str):
         assert channel in self.channels, f"Variable {channel} not found in dataset."
-        if lat not in self.prediction.coords["lat"].values or lon not in self.prediction.coords["lon"].values:
-            lat = self.prediction.sel(lat=lat, method="nearest").lat.item()
-            lon = self.prediction.sel(lon=lon, method="nearest").lon.item()
-            logger.warning(f"Exact coordinates not found. Using nearest values: Lat {lat}, Lon {lon}")
-        return self.prediction.sel(lat=lat, lon=lon, channel=channel).isel(time=n_step).item()
+
+    # ---- sub-arrays -------------------------------------------------------- #
+    def slice(self, lat=None, lon=None, channel=None, n_step=None):
+        """Sub-array over whichever of (lat range, lon range, one channel, time positions) are given."""
+        out = self.prediction
+        if channel is not None:
+            self._need(channel)
+            out = out.sel(channel=channel)
+        for dim, rng in (("lat", lat), ("lon", lon)):
+            if rng:
+                out = out.sel(**{dim: rng})
+        if n_step and "time" in out.dims:
+            out = out.isel(time=n_step)
+        return out
+
+    # ---- point values --------------------------------------------------------- #
+    def point(self, lat: float, lon: float, channel: str, n_step=1):
+        """Value of ``channel`` at the grid cell nearest to (lat, lon); negative longitudes wrap to [0, 360)."""
+        lon = lon + 360 if lon < 0 else lon
+        self._need(channel)
+        p = self.prediction
+        i, hit_lat = _axis_index(p._coords["lat"], lat)
+        j, hit_lon = _axis_index(p._coords["lon"], lon)
+        if not (hit_lat and hit_lon):
+            logger.warning(f"Exact coordinates not found. Using nearest values: Lat {p._coords['lat'][i]}, Lon {p._coords['lon'][j]}")
+        index = []
+        for dim in p.dims:
+            if dim == "lat":
+                index.append(i)
+            elif dim == "lon":
+                index.append(j)
+            elif dim == "channel":
+                index.append(p._coords["channel"].tolist().index(channel))
+            elif dim == "time":
+                index.append(n_step)
+            else:
+                index.append(slice(None))
+        return p.values[tuple(index)].item()
 
     def point_wind_uv(self, lat: float, lon: float, pressure_level: int = 1000, n_step=1):
-        u = self.point(lat=lat, lon=lon, channel=f"u{pressure_level}", n_step=n_step)
-        v = self.point(lat=lat, lon=lon, channel=f"v{pressure_level}", n_step=n_step)
-        return u, v
+        return tuple(self.point(lat=lat, lon=lon, channel=f"{c}{pressure_level}", n_step=n_step) for c in "uv")
 
     def wind_speed(self, lat: float, lon: float, pressure_level: int, n_step=1):
+        """|(u, v)| at a pressure level in hPa."""
         u, v = self.point_wind_uv(lat, lon, pressure_level, n_step)
-        return (u ** 2 + v ** 2) ** 0.5
+        return float(np.hypot(u, v))
 
     def surface_wind_speed(self, lat: float, lon: float, n_step=1):
         return self.wind_speed(lat, lon, pressure_level=1000, n_step=n_step)
 
+    def wind_speed_field(self, pressure_level: int = 1000, n_step=1, device=None):
+        """Whole-grid |(u, v)| of one time entry (lat, lon).  With ``device`` (e.g. the model's GPU) the reduction runs there
+        through torch; the point accessors above are the reference's surface, this is the field form of the same quantity."""
+        u = self.slice(channel=f"u{pressure_level}").isel(time=n_step).values
+        v = self.slice(channel=f"v{pressure_level}").isel(time=n_step).values
+        if device is None:
+            return np.hypot(u, v)
+        import torch
+        return torch.hypot(torch.as_tensor(u, device=device), torch.as_tensor(v, device=device))
+
 
 class GlobalPredictionRollout:
+    """A list of per-step predictions (paths or arrays) queried together (reference base.py:277-303)."""
+
     def __init__(self, rollout: list):
         self.rollout = [GlobalPrediction(source) for source in rollout]
         self.time_steps = [r.prediction.time.values[-1] for r in self.rollout]

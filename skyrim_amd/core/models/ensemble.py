@@ -27,18 +27,20 @@ class GlobalEnsemble:
 
     def _ensemble_predictions(self, predictions):
         """Average predictions along shared channels."""
+        if not predictions:
+            raise ValueError("No predictions to average or no common channels available.")
         common = [c for c in predictions[0].channel.values.tolist() if all(c in p.channel.values for p in predictions)]
-        if not predictions or not common:
+        if not common:
             raise ValueError("No predictions to average or no common channels available.")
         self.common_channels = common
         return concat([p.sel(channel=common) for p in predictions], dim="model").mean(dim="model")
 
-    def rollout(self, start_time: datetime.datetime, n_steps: int = 3, save: bool = True, save_config: dict = {}):
+    def rollout(self, start_time: datetime.datetime, n_steps: int = 3, save: bool = True, save_config: dict | None = None):
         from . import MODELS
         predictions, output_paths = [], []
         for name in self.model_names:
             model = MODELS[name](ic_source=self.ic_source)
-            pred, paths = model.rollout(start_time=start_time, n_steps=n_steps, save=save, save_config=dict(save_config))
+            pred, paths = model.rollout(start_time=start_time, n_steps=n_steps, save=save, save_config=dict(save_config or {}))
             predictions.append(pred)
             output_paths.extend(paths)
             del model

@@ -32,12 +32,12 @@ class Skyrim:
     def list_available_models():
         return list(MODELS.keys())
 
-    def forecast(self, start_time: datetime.datetime, n_steps: int = 4, channels: list = []):
+    def forecast(self, start_time: datetime.datetime, n_steps: int = 4, channels: list | None = None):
         """Full concatenated forecast (all steps from the IC on) for the channels of interest."""
         start_time = start_time.replace(second=0, microsecond=0)
-        return self.model.forecast(start_time=start_time, n_steps=n_steps, channels=channels)
+        return self.model.forecast(start_time=start_time, n_steps=n_steps, channels=channels or [])
 
-    def predict(self, date: str, time: str, lead_time: int = 6, save: bool = False, save_config: dict = {}):
+    def predict(self, date: str, time: str, lead_time: int = 6, save: bool = False, save_config: dict | None = None):
         """Predict a single lead-time snapshot, optionally saving every intermediate step.
         date: YYYYMMDD, time: HHMM, lead_time in hours (clipped down to a multiple of 6, at least 6)."""
         start_time = datetime.datetime(int(date[:4]), int(date[4:6]), int(date[6:8]), int(time[:2]), int(time[2:4]))

@@ -155,6 +155,16 @@ class DataArray:
         coords = {k: v for k, v in self._coords.items() if k != dim}
         return DataArray(self.values.mean(axis=ax), [d for d in self.dims if d != dim], coords, self.name)
 
+    def expand_dims(self, dim: str) -> "DataArray":
+        """New leading dim of size 1; a scalar coordinate of that name becomes its 1-element index."""
+        coords = dict(self._coords)
+        if dim in coords:
+            coords[dim] = np.atleast_1d(coords[dim])
+        return DataArray(self.values[None], (dim,) + self.dims, coords, self.name)
+
+    def rename(self, names: dict) -> "DataArray":
+        return DataArray(self.values, [names.get(d, d) for d in self.dims], {names.get(k, k): v for k, v in self._coords.items()}, self.name)
+
     def transpose(self, *dims) -> "DataArray":
         return DataArray(self.values.transpose([self.dims.index(d) for d in dims]), dims, dict(self._coords), self.name)
 
@@ -166,6 +176,38 @@ class DataArray:
     def to_zarr(self, store, mode: str = "w", append_dim: str | None = None, consolidated: bool = True):
         from .zarrio import write_dataarray_zarr
         write_dataarray_zarr(self, store, mode=mode, append_dim=append_dim, consolidated=consolidated)
+
+
+class Dataset:
+    """Named DataArrays over shared dims -- the part of ``xarray.Dataset`` GraphCast's stepper state is read through
+    (/root/reference/skyrim/core/models/graphcast.py:68-91: ``ds.squeeze(dim=...)``, ``ds[name]``, ``.isel``, ``.expand_dims``)."""
+
+    def __init__(self, data_vars: dict[str, DataArray]):
+        self.data_vars = dict(data_vars)
+
+    def __getitem__(self, name: str) -> DataArray:
+        return self.data_vars[name]
+
+    def __contains__(self, name) -> bool:
+        return name in self.data_vars
+
+    def keys(self):
+        return self.data_vars.keys()
+
+    def _map(self, fn) -> "Dataset":
+        return Dataset({k: fn(v) for k, v in self.data_vars.items()})
+
+    def squeeze(self, dim: str) -> "Dataset":
+        return self._map(lambda v: v.isel(**{dim: 0}) if dim in v.dims else v)
+
+    def isel(self, **kw) -> "Dataset":
+        return self._map(lambda v: v.isel(**{d: i for d, i in kw.items() if d in v.dims}))
+
+    def expand_dims(self, dim: str) -> "Dataset":
+        return self._map(lambda v: v.expand_dims(dim))
+
+    def __repr__(self):
+        return f"<Dataset {list(self.data_vars)}>"
 
 
 def concat(arrays: list[DataArray], dim: str) -> DataArray:

@@ -20,6 +20,7 @@ from dataclasses import dataclass
 
 import torch
 
+from .. import weights
 from .engine import DEFAULT_PRECISION, PanguEngine
 from .spec import CHANNELS, PanguGeometry, init_synthetic
 
@@ -64,8 +65,7 @@ class PanguTimeLoop:
         self.geom = geom or PanguGeometry()
         self.engine = PanguEngine(self.geom, precision, device)
         if params is None:
-            path = os.environ.get("SKYRIM_PANGU_WEIGHTS")
-            params = _load_weights(path, self.geom) if path else init_synthetic(self.geom, seed)
+            params = weights.resolve("SKYRIM_PANGU_WEIGHTS", lambda p: _load_weights(p, self.geom), lambda: init_synthetic(self.geom, seed), "pangu")
         self.engine.load_params(params)
         if params24 is None and os.environ.get("SKYRIM_PANGU_WEIGHTS_24"):
             params24 = _load_weights(os.environ["SKYRIM_PANGU_WEIGHTS_24"], self.geom)
@@ -90,6 +90,8 @@ class PanguTimeLoop:
         state = x[0, 0].to(self.device, torch.float32).contiguous()
         yield time, state.unsqueeze(0).clone(), restart
         state24, k = state, 0
+        guard = weights.FiniteGuard(f"precision {self.engine.precision!r} keeps activations as fp16 planes (|x| < 65504); "
+                                    "use PanguModel(precision='bf16x3') for the wide-range mode")
         while True:
             k += 1
             if self.engine24 is not None and k % 4 == 0:
@@ -97,4 +99,5 @@ class PanguTimeLoop:
             else:
                 state = self.engine.step(state)                    # new buffer each step: the caller keeps the yielded one
             time = time + self.time_step
+            guard.push(state, k)
             yield time, state.unsqueeze(0), restart

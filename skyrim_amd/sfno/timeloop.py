@@ -12,6 +12,7 @@ from dataclasses import dataclass
 import numpy as np
 import torch
 
+from .. import weights
 from .engine import SfnoEngine
 from .spec import CHANNELS, SfnoConfig, init_synthetic, synthetic_state
 
@@ -36,8 +37,7 @@ class SfnoTimeLoop:
         self.cfg = cfg or SfnoConfig()
         self.engine = SfnoEngine(self.cfg, device)
         if params is None:
-            path = os.environ.get("SKYRIM_SFNO_WEIGHTS")
-            params = torch.load(path, map_location="cpu") if path else init_synthetic(self.cfg, seed)
+            params = weights.resolve("SKYRIM_SFNO_WEIGHTS", lambda p: torch.load(p, map_location="cpu"), lambda: init_synthetic(self.cfg, seed), "fourcastnet_v2")
         self.engine.load_params(params)
         names = CHANNELS if self.cfg.in_chans == len(CHANNELS) else [f"c{i}" for i in range(self.cfg.in_chans)]
         self.in_channel_names = list(names)

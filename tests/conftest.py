@@ -1,3 +1,4 @@
+import os
 import sys
 from pathlib import Path
 
@@ -5,6 +6,12 @@ import pytest
 
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
+
+
+# Tests run on seeded synthetic initial conditions and random-init parameters; both are explicit opt-ins of the product
+# (skyrim_amd/datasource.py, skyrim_amd/weights.py), which refuses to substitute them silently.
+os.environ.setdefault("SKYRIM_SYNTHETIC_IC", "1")
+os.environ.setdefault("SKYRIM_SYNTHETIC_WEIGHTS", "1")
 
 
 def pytest_configure(config):

@@ -193,3 +193,11 @@ def test_reference_api_forecast_on_the_graphcast_engine():
     assert da.dims == ("time", "channel", "lat", "lon") and da.values.shape == (3, 83, cfg.n_lat, cfg.n_lon)
     assert list(da.time.values) == [np.datetime64(t0 + k * datetime.timedelta(hours=6), "ns") for k in range(3)]
     assert np.isfinite(da.values).all()
+    # the wrapper's own loop (stepper.initialize / step, _to_global_da in CHANNEL_MAP order, forecast-only latitude flip,
+    # reference graphcast.py:68-142) against the generic TimeLoop drive of the same engine
+    from skyrim_amd.core.models.base import GlobalModel
+    generic = GlobalModel.forecast(model, t0, n_steps=2)
+    assert da.channel.values.tolist()[:2] == ["q50", "q100"] and da.lat.values[0] == 90.0
+    assert np.array_equal(da.sel(channel=generic.channel.values.tolist()).values, generic.values)
+    pred, _ = model.rollout(t0, n_steps=2, save=False)
+    assert pred.lat.values[0] == -90.0 and np.array_equal(pred.values[1, :, ::-1], da.values[2])

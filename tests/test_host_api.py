@@ -111,7 +111,7 @@ def test_rollout_saves_one_file_per_step(tmp_path):
     pred, paths = m.rollout(T0, n_steps=3, save=True, save_config=cfg)
     assert len(paths) == 3 and "forecast_id" in cfg                   # rollout mutates save_config (base.py:129-130)
     names = [Path(p).name for p in paths]
-    assert names[0] == "boring__gfs__20240513_18:00__20240514_00:00.nc"
+    assert names[0] == "boring__synthetic__20240513_18:00__20240514_00:00.nc"      # never stamped with a source that was not read
     assert names[1] == "boring__file__20240514_00:00__20240514_06:00.nc"      # source flips to "file" (base.py:144)
     assert all(Path(p).parent.name == cfg["forecast_id"] for p in paths)
     assert pred.shape == (2, 3, 9, 96)
@@ -224,3 +224,165 @@ def test_forecast_cli_mirrors_reference_options(boring_registry, tmp_path, monke
     assert open_dataarray(paths[0]).channel.values.tolist() == ["t2m"]
     res = CliRunner().invoke(forecast.main, ["--modal"])
     assert res.exit_code != 0
+
+
+# ---- round 2: explicit opt-ins, restart from a given state, GraphCast wrapper semantics ---------------------------------- #
+def test_network_sources_refuse_silent_substitution(monkeypatch, tmp_path):
+    monkeypatch.delenv("SKYRIM_SYNTHETIC_IC", raising=False)
+    monkeypatch.delenv("SKYRIM_IC_DIR", raising=False)
+    for src in ("gfs", "cds", "ifs"):
+        with pytest.raises(RuntimeError, match="SKYRIM_SYNTHETIC_IC"):
+            BoringGlobalModel(ic_source=src)
+    assert BoringGlobalModel(ic_source="synthetic").source_label == "synthetic"          # the explicit name always works
+    # a local archive in the saved-forecast layout stands in for the fetcher, and then the files carry the real source name
+    m = BoringGlobalModel(ic_source="synthetic")
+    ic = m.predict_one_step(T0)
+    (tmp_path / "gfs").mkdir()
+    ic.to_netcdf(tmp_path / "gfs" / (T0 + datetime.timedelta(hours=6)).strftime("%Y%m%d_%H%M.nc"))
+    monkeypatch.setenv("SKYRIM_IC_DIR", str(tmp_path))
+    g = BoringGlobalModel(ic_source="gfs")
+    t1 = T0 + datetime.timedelta(hours=6)
+    pred, paths = g.rollout(t1, n_steps=1, save=True, save_config={"output_dir": str(tmp_path / "out")})
+    assert Path(paths[0]).name.startswith("boring__gfs__") and np.allclose(pred.values[0], ic.values[1])
+    with pytest.raises(FileNotFoundError):
+        g.predict_one_step(T0)
+
+
+def test_missing_weights_raise_unless_opted_in(monkeypatch):
+    from skyrim_amd import weights
+    monkeypatch.delenv("SKYRIM_SYNTHETIC_WEIGHTS", raising=False)
+    monkeypatch.delenv("SKYRIM_X_WEIGHTS", raising=False)
+    with pytest.raises(RuntimeError, match="SKYRIM_X_WEIGHTS"):
+        weights.resolve("SKYRIM_X_WEIGHTS", lambda p: {"from": p}, lambda: {"synthetic": True}, "x")
+    monkeypatch.setenv("SKYRIM_SYNTHETIC_WEIGHTS", "1")
+    assert weights.resolve("SKYRIM_X_WEIGHTS", lambda p: {"from": p}, lambda: {"synthetic": True}, "x") == {"synthetic": True}
+    monkeypatch.setenv("SKYRIM_X_WEIGHTS", "/w.pt")
+    assert weights.resolve("SKYRIM_X_WEIGHTS", lambda p: {"from": p}, lambda: {"synthetic": True}, "x") == {"from": "/w.pt"}
+    guard = weights.FiniteGuard("hint")
+    guard.push(torch.ones(3), 1)
+    guard.push(torch.tensor([1.0, float("inf")]), 2)            # step 1 was fine
+    with pytest.raises(FloatingPointError, match="after step 2: hint"):
+        guard.push(torch.ones(3), 3)
+
+
+def test_rollout_from_a_given_initial_condition_and_no_id_leak(tmp_path):
+    m = BoringGlobalModel(ic_source="synthetic")
+    first, paths = m.rollout(T0, n_steps=2, save=True, save_config={"output_dir": str(tmp_path)})
+    t2 = T0 + datetime.timedelta(hours=12)
+    # reference base.py:127 TODO: continue from a saved step (path) or from an in-memory prediction
+    for ic in (paths[-1], first):
+        cont, p2 = m.rollout(t2, n_steps=1, save=True, save_config={"output_dir": str(tmp_path)}, initial_condition=ic)
+        assert np.allclose(cont.values[0], first.values[1]) and np.allclose(cont.values[1], first.values[1] + 1.0)
+        assert Path(p2[0]).name.startswith("boring__file__")
+    # no shared default: two calls without a config draw different forecast ids
+    _, a = m.rollout(T0, n_steps=1, save=True, save_config={"output_dir": str(tmp_path)})
+    _, b = m.rollout(T0, n_steps=1, save=True, save_config={"output_dir": str(tmp_path)})
+    assert Path(a[0]).parent != Path(b[0]).parent
+    import inspect
+    assert inspect.signature(GlobalModel.rollout).parameters["save_config"].default is None
+    assert inspect.signature(Skyrim.predict).parameters["save_config"].default is None
+
+
+def test_ensemble_of_nothing_is_a_value_error():
+    with pytest.raises(ValueError):
+        GlobalEnsemble(["pangu"])._ensemble_predictions([])
+
+
+def test_wind_speed_field_matches_point_accessor():
+    m = BoringGlobalModel(ic_source="synthetic")
+    gp = GlobalPrediction(m.predict_one_step(T0), model_name="boring")
+    f = gp.wind_speed_field(1000, n_step=1)
+    assert f.shape == (9, 96) and f[4, 48] == pytest.approx(gp.wind_speed(0.0, 180.0, 1000))
+
+
+def _cpu_graphcast_model():
+    """GraphcastModel over the real GraphcastTimeLoop stepper / dataset code with the HIP engine replaced by `+1 per step`."""
+    from skyrim_amd.core.models.graphcast import GraphcastModel
+    from skyrim_amd.graphcast import timeloop as TL
+    from skyrim_amd.graphcast.spec import CHANNELS as GC, GraphcastConfig
+
+    cfg = GraphcastConfig(n_lat=9, n_lon=16)
+
+    class FakeEngine:
+        state_shape = (83, 9, 16)
+        device = torch.device("cpu")
+
+        def step(self, prev, cur, forcing):
+            assert forcing.shape == (15, 9, 16)
+            return cur + 1.0
+
+    loop = object.__new__(TL.GraphcastTimeLoop)
+    loop.cfg, loop.engine = cfg, FakeEngine()
+    loop.in_channel_names = loop.out_channel_names = list(GC)
+    loop.grid = TL.Grid(list(np.linspace(90.0, -90.0, 9)), list(np.arange(16) * 22.5))
+    loop.stepper = TL._Stepper(loop)
+    lat = torch.deg2rad(torch.linspace(90.0, -90.0, 9, dtype=torch.float64))[:, None]
+    loop._sin_lat, loop._cos_lat = torch.sin(lat), torch.cos(lat)
+    loop._lon = torch.deg2rad(torch.arange(16, dtype=torch.float64) * 22.5)[None, :]
+
+    class M(GraphcastModel):
+        def build_model(self):
+            return loop
+
+    src = SyntheticDataSource(GC, state_fn=lambda seed: torch.arange(83.0)[:, None, None] * 100 + torch.arange(9.0)[None, :, None] + torch.zeros(83, 9, 16))
+    m = M(ic_source="synthetic")
+    m.data_source = src
+    return m, loop, cfg
+
+
+def test_graphcast_wrapper_channel_map_order_and_forecast_only_flip(tmp_path):
+    """/root/reference/skyrim/core/models/graphcast.py: _to_global_da emits CHANNEL_MAP order (:29-41, q first, t2m before u10m),
+    forecast flips latitude back to 90..-90 (:138), rollout does not (:163-177)."""
+    from skyrim_amd.core.models.graphcast import CHANNEL_MAP
+    from skyrim_amd.graphcast.spec import CHANNELS as GC
+    m, loop, cfg = _cpu_graphcast_model()
+    levels = [50, 100, 150, 200, 250, 300, 400, 500, 600, 700, 850, 925, 1000]
+    want = [f"{c}{l}" for _, c in CHANNEL_MAP[:6] for l in levels] + [c for _, c in CHANNEL_MAP[6:]]
+    assert want[:2] == ["q50", "q100"] and want[-5:] == ["t2m", "u10m", "v10m", "msl", "tp06"] and sorted(want) == sorted(GC)
+    fc = m.forecast(T0, n_steps=3)
+    assert fc.dims == ("time", "channel", "lat", "lon") and fc.shape == (4, 83, 9, 16)
+    assert fc.channel.values.tolist() == want
+    assert fc.lat.values[0] == 90.0 and fc.lat.values[-1] == -90.0                       # flipped back
+    assert list(fc.time.values) == [np.datetime64(T0 + i * datetime.timedelta(hours=6), "ns") for i in range(4)]
+    # values: synthetic field = 100 * (index in CHANNELS) + row index (row 0 = 90N); each step adds 1
+    z500, t2m = GC.index("z500"), GC.index("t2m")
+    assert fc.sel(channel="z500").values[0, 2, 5] == 100.0 * z500 + 2 and fc.sel(channel="t2m").values[3, 7, 0] == 100.0 * t2m + 7 + 3
+    sub = m.forecast(T0, n_steps=1, channels=["t2m", "q50"])
+    assert sub.channel.values.tolist() == ["t2m", "q50"] and sub.shape == (2, 2, 9, 16)
+    pred, paths = m.rollout(T0, n_steps=2, save=True, save_config={"output_dir": str(tmp_path)})
+    assert pred.lat.values[0] == -90.0 and pred.channel.values.tolist() == want          # the stepper's ascending latitudes
+    assert pred.sel(channel="z500").values[1, 0, 0] == 100.0 * z500 + 8 + 2               # row 0 = 90S = source row 8
+    assert list(pred.time.values) == [np.datetime64(T0 + i * datetime.timedelta(hours=6), "ns") for i in (1, 2)]
+    back = open_dataarray(paths[0])
+    assert back.lat.values[0] == -90.0 and back.shape == (2, 83, 9, 16) and Path(paths[0]).name.startswith("graphcast__synthetic__")
+    # restart from the saved file: channel order and latitude direction are read off its coordinates
+    cont, _ = m.rollout(T0 + datetime.timedelta(hours=12), n_steps=1, save=False, initial_condition=paths[-1])
+    assert np.allclose(cont.values[0], pred.values[1]) and np.allclose(cont.values[1], pred.values[1] + 1.0)
+
+
+def test_graphcast_stepper_protocol_and_time_loop_protocol_agree():
+    m, loop, cfg = _cpu_graphcast_model()
+    x = torch.stack([torch.zeros(83, 9, 16), torch.ones(83, 9, 16)])[None]
+    state = loop.stepper.initialize(x, T0)
+    assert state[0] == T0 and state[2].dtype == np.uint32
+    ds = state[1]
+    assert ds["geopotential"].dims == ("batch", "time", "level", "lat", "lon") and ds["2m_temperature"].dims == ("batch", "time", "lat", "lon")
+    assert ds["geopotential"].lat.values[0] == -90.0 and ds["geopotential"].level.values.tolist()[0] == 50
+    state2, out = loop.stepper.step(state)
+    assert state2[0] == T0 + datetime.timedelta(hours=6) and out.shape == (1, 83, 9, 16) and float(out.mean()) == 2.0
+    it = loop(T0, x)
+    t0, y0, _ = next(it)
+    t1, y1, _ = next(it)
+    assert t0 == T0 and float(y0.mean()) == 1.0 and t1 == state2[0] and torch.equal(y1, out)
+    da = run_basic_inference(loop, 2, None, T0, x=None if False else DataArray(x[0].numpy(), ["time", "channel", "lat", "lon"],
+                             dict(time=[T0 - datetime.timedelta(hours=6), T0], channel=loop.in_channel_names, lat=loop.grid.lat, lon=loop.grid.lon)))
+    assert da.shape == (3, 83, 9, 16) and np.allclose(da.values[2], 3.0)
+
+
+def test_graphcast_device_forcings_match_the_spec_closed_form():
+    from skyrim_amd.graphcast.spec import forcings
+    from skyrim_amd.graphcast.timeloop import _EPOCH
+    m, loop, cfg = _cpu_graphcast_model()
+    t = datetime.datetime(2024, 5, 13, 18, 0)
+    want = forcings(cfg, (t - _EPOCH).total_seconds() / 3600.0)
+    assert torch.allclose(loop.forcing(t), want, atol=1e-6)

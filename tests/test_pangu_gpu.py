@@ -221,7 +221,7 @@ def test_pangu_model_rollout_through_reference_api(toy, tmp_path):
     assert m.in_channel_names == m.out_channel_names and len(m.out_channel_names) == 69
     pred, paths = m.rollout(t0, n_steps=2, save=True, save_config={"output_dir": str(tmp_path), "file_type": "netcdf"})
     assert pred.dims == ("time", "channel", "lat", "lon") and pred.shape == (2, 69, g.n_lat, g.n_lon)
-    assert [p.rsplit("/", 1)[1] for p in paths] == ["pangu__gfs__20240513_18:00__20240514_00:00.nc",
+    assert [p.rsplit("/", 1)[1] for p in paths] == ["pangu__synthetic__20240513_18:00__20240514_00:00.nc",
                                                      "pangu__file__20240514_00:00__20240514_06:00.nc"]
     ic = torch.from_numpy(m.data_source[t0])
     want = O.rollout(params, ic, 2)
