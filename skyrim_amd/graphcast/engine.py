@@ -20,6 +20,7 @@ from pathlib import Path
 import numpy as np
 import torch
 
+from .. import ops
 from ..sfno import engine as _sf
 from .mesh import GraphStructure, build_graph, latitude_band, shard_graph
 from .spec import N_FORCING, N_STATIC, GraphcastConfig, mlp_names, param_spec
@@ -118,37 +119,23 @@ class GraphcastEngine:
     # ---- kernels ------------------------------------------------------------------------------------- #
     def _fc1(self, W, bias, sources, rows, out, kscale=None, kshift=None, label="mlp"):
         """sources: [(tensor [n][ld], index tensor or None, width)] -> out[rows][latent] = swish(concat(...) W^T + b)."""
-        d = GatherDesc()
-        for s, (t, idx, width) in enumerate(sources):
-            d.src[s] = t.data_ptr()
-            d.idx[s] = idx.data_ptr() if idx is not None else None
-            d.ld[s] = t.shape[-1] if t.dim() == 2 else width
-            d.width[s] = width
-        d.n_src = len(sources)
-        d.kscale = kscale.data_ptr() if kscale is not None else None
-        d.kshift = kshift.data_ptr() if kshift is not None else None
-        d.w, d.w_plane, d.ldw = W.buf.data_ptr(), W.plane, W.ldw
-        d.bias = bias.data_ptr()
-        d.out, d.ldo, d.M, d.N, d.act = out.data_ptr(), W.N, rows, W.N, 2
         self._mark(label, 2.0 * rows * W.N * W.K)
-        _check(self.lib.skgc_gather_gemm(ctypes.byref(d), self._stream()), "skgc_gather_gemm")
+        ops.hip.gc_gather_gemm([t for t, _, _ in sources], [i for _, i, _ in sources], [w for _, _, w in sources], W.buf, W.plane, W.ldw, bias, out,
+                               rows, W.N, 2, kscale, kshift)
 
     def _gemm(self, a, W, out, M, *, a_sm, a_sk, o_sm, o_sn, bias=None, res_post=None, act=0, kscale=None, kshift=None, label="mlp"):
-        ptr = lambda t: None if t is None else t.data_ptr()  # noqa: E731
-        d = _sf.GemmDesc(a.data_ptr(), 0, 1 << 30, a_sm, 0, a_sk, W.buf.data_ptr(), 0, W.plane, W.ldw, ptr(bias), None, ptr(res_post),
-                         out.data_ptr(), 0, 1 << 30, o_sm, 0, o_sn, M, W.N, W.K, 1, act, 0, 0, 0, ptr(kscale), ptr(kshift), None, 0, 0, 3)
         self._mark(label, 2.0 * M * W.N * W.K)
-        _check(self.sf.sksfno_gemm_run(ctypes.byref(d), self._stream()), "sksfno_gemm_run")
+        big = 1 << 30
+        geom = [0, 0, big, a_sm, 0, a_sk, 0, W.plane, W.ldw, 0, 0, big, o_sm, 0, o_sn, M, W.N, W.K, 1, act, 0, 0, 0, 0, 0, 3]
+        ops.hip.sfno_gemm(a, W.buf, out, bias, None, res_post, kscale, kshift, None, geom)
 
     def _ln(self, x, g, b, res, out, rows, label="layer_norm"):
         self._mark(label)
-        _check(self.lib.skgc_layer_norm(x.data_ptr(), g.data_ptr(), b.data_ptr(), res.data_ptr() if res is not None else None, out.data_ptr(),
-                                        rows, self.cfg.latent, self._stream()), "skgc_layer_norm")
+        ops.hip.gc_layer_norm(x, g, b, res, out, rows, self.cfg.latent)
 
     def _segsum(self, e, offsets, out, n_nodes, acc=None):
         self._mark("segment_sum")
-        _check(self.lib.skgc_segment_sum(e.data_ptr(), offsets.data_ptr(), out.data_ptr(), acc.data_ptr() if acc is not None else None, n_nodes,
-                                         self.cfg.latent, self._stream()), "skgc_segment_sum")
+        ops.hip.gc_segment_sum(e, offsets, out, acc, n_nodes, self.cfg.latent)
 
     def _mlp(self, name, sources, rows, out, res=None, label=None):
         """out = (res +) LayerNorm(fc2(swish(fc1(concat(sources)))));  out may alias res."""
@@ -158,9 +145,7 @@ class GraphcastEngine:
         if m.get("fc2p") is not None:                # latent 512: second Linear + LayerNorm (+ residual) in one kernel
             buf, plane, ldw = m["fc2p"]
             self._mark(label or name.split(".")[0], 2.0 * rows * L * L)
-            _check(self.lib.skgc_linear_layer_norm(self.b_h.data_ptr(), L, L, buf.data_ptr(), plane, ldw, m["b2"].data_ptr(), m["g"].data_ptr(),
-                                                   m["b"].data_ptr(), res.data_ptr() if res is not None else None, out.data_ptr(), rows, self._stream()),
-                   "skgc_linear_layer_norm")
+            ops.hip.gc_linear_layer_norm(self.b_h, L, L, buf, plane, ldw, m["b2"], m["g"], m["b"], res, out, rows)
             return
         self._gemm(self.b_h, m["fc2"], self.b_t, rows, a_sm=L, a_sk=1, o_sm=L, o_sn=1, bias=m["b2"], label=label or name.split(".")[0])
         self._ln(self.b_t, m["g"], m["b"], res, out, rows)

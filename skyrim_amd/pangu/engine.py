@@ -1,8 +1,9 @@
-"""ctypes binding of the C-ABI Pangu engine (include/skyrim_pangu.h) + torch plumbing.
+"""Binding of the C-ABI Pangu engine (include/skyrim_pangu.h) + torch plumbing.
 
-PyTorch is used for device memory and streams only: every tensor handed to the library is a raw
-device pointer, every launch goes to ``torch.cuda.current_stream()``.  There is no CPU fallback:
-constructing an engine without the built HIP library (or without a GPU) raises.
+Context management (sizes, create, prepare, profiling) is plain ctypes; every call that launches kernels on the hot path goes
+through the ``torch.ops.skyrim_hip.pangu_*`` custom ops (skyrim_amd/ops.py), which hand raw device pointers and torch's current
+stream to the C ABI.  PyTorch is device memory, streams and the dispatcher only.  There is no CPU fallback: constructing an
+engine without the built HIP library (or without a GPU) raises, and the ops have no CPU kernel.
 """
 from __future__ import annotations
 
@@ -12,6 +13,7 @@ from pathlib import Path
 
 import torch
 
+from .. import ops
 from .spec import PanguGeometry
 
 PREC_BF16X3 = 0
@@ -174,9 +176,8 @@ class PanguEngine:
     def step(self, x: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
         if out is None:
             out = torch.empty_like(x)
-        with torch.cuda.device(self.device):
-            _check(self.lib.skpangu_step(self._ctx, self._chk_dev(x, self.state_shape), self._chk_dev(out, self.state_shape),
-                                         self._stream()), "skpangu_step")
+        self._chk_dev(x, self.state_shape), self._chk_dev(out, self.state_shape)
+        ops.hip.pangu_step(self._ctx.value, x, out)
         return out
 
     def profile(self, on: bool):
@@ -196,36 +197,35 @@ class PanguEngine:
 
     def patch_embed(self, x: torch.Tensor) -> torch.Tensor:
         out = torch.empty(self.tokens(1), dtype=torch.float32, device=self.device)
-        with torch.cuda.device(self.device):
-            _check(self.lib.skpangu_patch_embed(self._ctx, self._chk_dev(x, self.state_shape), self._chk_dev(out), self._stream()),
-                   "skpangu_patch_embed")
+        self._chk_dev(x, self.state_shape)
+        ops.hip.pangu_patch_embed(self._ctx.value, x, out)
         return out
 
     def block(self, layer: int, i: int, x: torch.Tensor) -> torch.Tensor:
         y = x.contiguous().clone()
-        with torch.cuda.device(self.device):
-            _check(self.lib.skpangu_block(self._ctx, layer, i, self._chk_dev(y, self.tokens(layer)), self._stream()), "skpangu_block")
+        self._chk_dev(y, self.tokens(layer))
+        ops.hip.pangu_block(self._ctx.value, layer, i, y)
         return y
 
     def downsample(self, x1: torch.Tensor) -> torch.Tensor:
         out = torch.empty(self.tokens(2), dtype=torch.float32, device=self.device)
-        with torch.cuda.device(self.device):
-            _check(self.lib.skpangu_downsample(self._ctx, self._chk_dev(x1.contiguous(), self.tokens(1)), self._chk_dev(out), self._stream()),
-                   "skpangu_downsample")
+        x1 = x1.contiguous()
+        self._chk_dev(x1, self.tokens(1))
+        ops.hip.pangu_downsample(self._ctx.value, x1, out)
         return out
 
     def upsample(self, x2: torch.Tensor) -> torch.Tensor:
         out = torch.empty(self.tokens(1), dtype=torch.float32, device=self.device)
-        with torch.cuda.device(self.device):
-            _check(self.lib.skpangu_upsample(self._ctx, self._chk_dev(x2.contiguous(), self.tokens(2)), self._chk_dev(out), self._stream()),
-                   "skpangu_upsample")
+        x2 = x2.contiguous()
+        self._chk_dev(x2, self.tokens(2))
+        ops.hip.pangu_upsample(self._ctx.value, x2, out)
         return out
 
     def patch_recover(self, skip: torch.Tensor, x4: torch.Tensor) -> torch.Tensor:
         out = torch.zeros(self.state_shape, dtype=torch.float32, device=self.device)
-        with torch.cuda.device(self.device):
-            _check(self.lib.skpangu_patch_recover(self._ctx, self._chk_dev(skip.contiguous(), self.tokens(1)), self._chk_dev(x4.contiguous(), self.tokens(1)),
-                                                  self._chk_dev(out), self._stream()), "skpangu_patch_recover")
+        skip, x4 = skip.contiguous(), x4.contiguous()
+        self._chk_dev(skip, self.tokens(1)), self._chk_dev(x4, self.tokens(1))
+        ops.hip.pangu_patch_recover(self._ctx.value, skip, x4, out)
         return out
 
     def debug_buffer(self, name: str, dtype: torch.dtype) -> torch.Tensor:

@@ -22,6 +22,7 @@ from pathlib import Path
 import numpy as np
 import torch
 
+from .. import ops
 from .sht import ShtMatrices
 from .spec import SfnoConfig, param_spec
 
@@ -218,17 +219,13 @@ class SfnoEngine:
         if N != W.N or K != W.K:
             raise ValueError(f"GEMM {M}x{N}x{K} against a prepared [{W.N}][{W.K}] matrix")
         self._mark(self._label, 2.0 * M * N * K * batch, 4.0 * batch * (M * K + M * N * (1 + (res_pre is not None) + (res_post is not None))))
-        ptr = lambda t, off=0: None if t is None else t.data_ptr() + 4 * off  # noqa: E731
-        d = GemmDesc(ptr(a, a_off), a_sb, a_m1, a_sm, a_sm2, a_sk,
-                     W.buf.data_ptr(), (W.w_sb if (batch > 1 if w_batched is None else w_batched) else 0), W.plane, W.ldw,
-                     ptr(bias), ptr(res_pre, o_off), ptr(res_post, o_off),
-                     ptr(out, o_off), o_sb, o_m1, o_sm, o_sm2, o_sn, M, N, K, batch, act, k_lo_step, m_cap0, m_cap_step, ptr(a_kscale), ptr(a_kshift), ptr(a2), a2_sk, a2_k_split, self.terms)
-        _check(self.lib.sksfno_gemm_run(ctypes.byref(d), self._stream()), "sksfno_gemm_run")
+        geom = [a_off, a_sb, a_m1, a_sm, a_sm2, a_sk, (W.w_sb if (batch > 1 if w_batched is None else w_batched) else 0), W.plane, W.ldw,
+                o_off, o_sb, o_m1, o_sm, o_sm2, o_sn, M, N, K, batch, act, k_lo_step, m_cap0, m_cap_step, a2_sk, a2_k_split, self.terms]
+        ops.hip.sfno_gemm(a, W.buf, out, bias, res_pre, res_post, a_kscale, a_kshift, a2, geom)
 
     def _norm(self, x, g, b, out, C, HW):
         self._mark("norm", 8.0 * C * HW, 16.0 * C * HW)
-        _check(self.lib.sksfno_instance_norm(x.data_ptr(), g.data_ptr(), b.data_ptr(), out.data_ptr(), C, HW, self.cfg.eps, self._stream()),
-               "sksfno_instance_norm")
+        ops.hip.sfno_instance_norm(x, g, b, out, C, HW, self.cfg.eps)
 
     def _pointwise(self, a, W, out, hw, cin, cout, label="conv1x1", **kw):
         """1x1 convolution on [C][hw] activations: rows = pixels (contiguous), k = channel (stride hw)."""

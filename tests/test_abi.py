@@ -68,3 +68,20 @@ def test_engine_refuses_to_run_without_gpu_or_library(monkeypatch, tmp_path):
     monkeypatch.setenv("SKYRIM_PANGU_LIB", str(tmp_path / "missing.so"))
     with pytest.raises(RuntimeError, match="not found"):
         E.load_library()
+
+
+def test_custom_ops_are_registered_and_have_no_cpu_kernel():
+    """SURVEY 8b: the Python call path is torch.library custom ops (skyrim_hip::*) over the C ABI; only the CUDA (ROCm) key
+    has an implementation, so CPU tensors fail in the dispatcher instead of falling back."""
+    import torch
+    from skyrim_amd import ops
+    assert {"pangu_step", "sfno_gemm", "sfno_instance_norm", "gc_gather_gemm", "gc_linear_layer_norm", "gc_segment_sum"} <= set(ops.OP_NAMES)
+    for name in ops.OP_NAMES:
+        assert hasattr(torch.ops.skyrim_hip, name)
+    with pytest.raises(NotImplementedError):
+        torch.ops.skyrim_hip.pangu_step(0, torch.zeros(4), torch.zeros(4))
+    with pytest.raises(NotImplementedError):
+        torch.ops.skyrim_hip.gc_segment_sum(torch.zeros(4, 8), torch.zeros(3, dtype=torch.int32), torch.zeros(2, 8), None, 2, 8)
+    schema = torch.ops.skyrim_hip.pangu_step.default._schema
+    assert str(schema) == "skyrim_hip::pangu_step(int ctx, Tensor x, Tensor(a!) out) -> ()"
+    ops.register()          # idempotent

@@ -282,3 +282,28 @@ def test_skyrim_facade_default_grid():
     assert np.isfinite(pred.prediction.values).all()
     assert pred.prediction.time.values[1] == np.datetime64("2024-05-14T00:00")
     assert abs(pred.point(48.0, 11.5, "t2m", n_step=1)) < 1e4
+
+
+def test_step_through_the_custom_op_boundary(toy):
+    """torch.ops.skyrim_hip.pangu_* called directly (the engine's own call path): same result as PanguEngine.step, honours the
+    current stream, refuses CPU tensors and wrong dtypes."""
+    from skyrim_amd import ops  # noqa: F401
+    g, params, x = toy
+    eng = PanguEngine(g, device="cuda:0")
+    eng.load_params(params)
+    xd = x.cuda()
+    want = eng.step(xd)
+    out = torch.empty_like(xd)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        torch.ops.skyrim_hip.pangu_step(eng._ctx.value, xd, out)
+    side.synchronize()
+    assert torch.equal(out, want)
+    x1 = torch.empty(eng.tokens(1), dtype=torch.float32, device="cuda:0")
+    torch.ops.skyrim_hip.pangu_patch_embed(eng._ctx.value, xd, x1)
+    assert torch.equal(x1, eng.patch_embed(xd))
+    with pytest.raises(NotImplementedError):
+        torch.ops.skyrim_hip.pangu_step(eng._ctx.value, x, torch.empty_like(x))
+    with pytest.raises(ValueError):
+        torch.ops.skyrim_hip.pangu_step(eng._ctx.value, xd.double(), out)
