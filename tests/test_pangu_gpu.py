@@ -288,6 +288,7 @@ def test_step_through_the_custom_op_boundary(toy):
     """torch.ops.skyrim_hip.pangu_* called directly (the engine's own call path): same result as PanguEngine.step, honours the
     current stream, refuses CPU tensors and wrong dtypes."""
     from skyrim_amd import ops  # noqa: F401
+    from skyrim_amd.pangu.engine import PanguEngine
     g, params, x = toy
     eng = PanguEngine(g, device="cuda:0")
     eng.load_params(params)
