@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SKPANGU_ABI_VERSION 1
+#define SKPANGU_ABI_VERSION 2
 
 /* precision modes: how each matrix product is formed on the MFMA pipe */
 #define SKPANGU_PREC_BF16X3 0 /* bf16 hi/lo split, 3 MFMA terms, fp32 range (wide-range mode; ~8e-5 per-channel error per step) */
@@ -44,10 +44,19 @@ extern "C" {
 
 typedef struct skpangu_ctx skpangu_ctx;
 
+/* Conventions the public Pangu pseudocode leaves open; a real pangu_weather_6.onnx can settle each either way, so each is a
+ * configuration value here and in the CPU oracle (oracle/pangu_oracle.py: Conventions).  0 selects the default. */
+#define SKPANGU_PAD_CENTRE 0 /* zero padding split front = total / 2, back = rest (default) */
+#define SKPANGU_PAD_BACK   1 /* all zero padding behind the data */
+
 typedef struct skpangu_config {
     int n_lat;     /* 721; any n_lat >= 8 */
     int n_lon;     /* 1440; must be a multiple of 96 */
     int precision; /* SKPANGU_PREC_* */
+    int roll_sign; /* shifted-window blocks: -1 (default, also 0) roll by -(1,3,6) first (Swin); +1 roll by +(1,3,6) first
+                      (roll3D(x, shift=[wz/2, wh/2, ww/2]) as the pseudocode's call is written).  The masked window follows. */
+    int pad_mode;  /* SKPANGU_PAD_* for every zero padding on the path (input latitude, window latitude, 2x2 merge) */
+    float mask_value; /* additive shifted-window mask; 0 = default -100 (Swin); the pseudocode's comment suggests -1000 */
 } skpangu_config;
 
 typedef struct skpangu_sizes {

@@ -19,12 +19,19 @@ pseudocode.py) -- in plain PyTorch-CPU fp32/fp64, written independently of the
 HIP kernels.  Golden vectors under tests/golden/ are produced by THIS file
 ("self-oracle"); see DESIGN.md.
 
-Conventions fixed here (the pseudocode leaves them open):
-  * zero padding is "centre" padding: front = total // 2, back = the rest
-    (13->14 levels: 0/1; 721->724 lat: 1/2; 181->186 tokens: 2/3; 181->182: 0/1)
-  * shifted windows roll by -(wz//2, wh//2, ww//2) = -(1, 3, 6) (Swin convention)
-    and the attention mask (-100) is generated over Z and lat only: longitude is
-    periodic, so rolled lon windows are genuine neighbours
+Conventions the pseudocode leaves open.  The three that a real ``pangu_weather_6.onnx`` could
+settle either way are SWITCHABLE (``Conventions``; the engine takes the same three through
+``skpangu_config``), each default with its source:
+  * ``pad``: "centre" (default) = front = total // 2, back = the rest (13->14 levels: 0/1;
+    721->724 lat: 1/2; 181->186 tokens: 2/3; 181->182: 0/1) -- the pseudocode only says
+    "zero-pad"; public re-implementations centre.  "back" puts all of it at the end.
+  * ``roll_sign``: -1 (default) = shifted windows roll by -(wz//2, wh//2, ww//2) = -(1, 3, 6),
+    the Swin convention; +1 = ``roll3D(x, shift=[+1, +3, +6])`` as the pseudocode's call is
+    literally written (then -half to restore).  The mask regions follow the sign (the window
+    that mixes wrapped and unwrapped rows is the last one for -1, the first one for +1).
+  * ``mask_value``: -100 (default, Swin) -- the pseudocode's comment suggests -1000.
+    The mask is generated over Z and lat only: longitude is periodic, so rolled lon windows
+    are genuine neighbours
   * the surface slab is token level 0, the 7 upper-air slabs follow
     (PatchRecovery reads x[:, :, 0] as surface, x[:, :, 1:] as upper air)
   * the network sees (x - mean_c) / std_c and its output is de-normalised with the
@@ -54,11 +61,21 @@ LN_EPS = 1e-5
 MASK_VALUE = -100.0
 
 
-def _centre_pad(n: int, mult: int) -> tuple[int, int, int]:
+@dataclass(frozen=True)
+class Conventions:
+    pad: str = "centre"          # "centre" | "back"
+    roll_sign: int = -1          # -1: torch.roll(x, -half) first (Swin);  +1: torch.roll(x, +half) first (pseudocode as written)
+    mask_value: float = MASK_VALUE
+
+
+DEFAULT = Conventions()
+
+
+def _centre_pad(n: int, mult: int, pad: str = "centre") -> tuple[int, int, int]:
     """(padded size, front, back) so that padded is the next multiple of mult."""
     padded = (n + mult - 1) // mult * mult
     total = padded - n
-    front = total // 2
+    front = total // 2 if pad == "centre" else 0
     return padded, front, total - front
 
 
@@ -67,14 +84,15 @@ class Geometry:
     """Derived sizes for a (n_lat, n_lon) grid with 13 pressure levels."""
     n_lat: int
     n_lon: int
+    pad: str = "centre"
 
     @property
     def lat_pad(self):          # input latitude -> multiple of 4
-        return _centre_pad(self.n_lat, PATCH[1])
+        return _centre_pad(self.n_lat, PATCH[1], self.pad)
 
     @property
     def lev_pad(self):          # 13 -> 14
-        return _centre_pad(N_LEVELS, PATCH[0])
+        return _centre_pad(N_LEVELS, PATCH[0], self.pad)
 
     @property
     def Z(self):                # token levels: surface + 7 upper
@@ -91,7 +109,7 @@ class Geometry:
 
     @property
     def H2(self):
-        return _centre_pad(self.H1, 2)[0] // 2
+        return _centre_pad(self.H1, 2, self.pad)[0] // 2
 
     @property
     def W2(self):
@@ -103,7 +121,7 @@ class Geometry:
 
     def window_types(self, layer: int) -> int:
         Z, H, W = self.res(layer)
-        Hp = _centre_pad(H, WINDOW[1])[0]
+        Hp = _centre_pad(H, WINDOW[1], self.pad)[0]
         return (Z // WINDOW[0]) * (Hp // WINDOW[1])
 
 
@@ -141,20 +159,26 @@ def position_index() -> torch.Tensor:
     return coords.sum(-1)
 
 
-def shifted_window_mask(Z: int, Hp: int, Wp: int, dtype) -> torch.Tensor:
+def shifted_window_mask(Z: int, Hp: int, Wp: int, dtype, conv: Conventions = DEFAULT) -> torch.Tensor:
     """(nZ*nH, 1(nW), 144, 144) additive mask for rolled windows; Z and lat only."""
     wz, wh, ww = WINDOW
     sz, sh = wz // 2, wh // 2
     img = torch.zeros(Z, Hp, Wp)
     cnt = 0
-    for zs in (slice(0, -wz), slice(-wz, -sz), slice(-sz, None)):
-        for hs in (slice(0, -wh), slice(-wh, -sh), slice(-sh, None)):
+    if conv.roll_sign < 0:       # rolled by -half: the LAST window holds [unwrapped | wrapped] rows
+        z_regions = (slice(0, -wz), slice(-wz, -sz), slice(-sz, None))
+        h_regions = (slice(0, -wh), slice(-wh, -sh), slice(-sh, None))
+    else:                        # rolled by +half: the FIRST window holds [wrapped | unwrapped] rows
+        z_regions = (slice(0, sz), slice(sz, wz), slice(wz, None))
+        h_regions = (slice(0, sh), slice(sh, wh), slice(wh, None))
+    for zs in z_regions:
+        for hs in h_regions:
             img[zs, hs, :] = cnt
             cnt += 1
     win = img.reshape(Z // wz, wz, Hp // wh, wh, Wp // ww, ww)
     win = win.permute(0, 2, 4, 1, 3, 5).reshape(Z // wz * (Hp // wh), Wp // ww, wz * wh * ww)
     diff = win[:, :, None, :] - win[:, :, :, None]
-    mask = torch.where(diff != 0, torch.tensor(MASK_VALUE), torch.tensor(0.0)).to(dtype)
+    mask = torch.where(diff != 0, torch.tensor(float(conv.mask_value)), torch.tensor(0.0)).to(dtype)
     # identical for every longitude window: keep one
     return mask[:, :1]
 
@@ -180,18 +204,19 @@ def earth_attention(p, x_win, n_types, heads, mask, emu=None):
     return _linear(out, p["attn.proj.weight"], p["attn.proj.bias"], emu)
 
 
-def earth_block(p, x, res, heads, roll, emu=None):
+def earth_block(p, x, res, heads, roll, emu=None, conv: Conventions = DEFAULT):
     """One EarthSpecificBlock.  x: (Z*H*W, C)."""
     Z, H, W = res
     wz, wh, ww = WINDOW
     C = x.shape[-1]
     shortcut = x
     x = x.reshape(Z, H, W, C)
-    Hp, top, bot = _centre_pad(H, wh)
+    Hp, top, bot = _centre_pad(H, wh, conv.pad)
     x = F.pad(x, (0, 0, 0, 0, top, bot))                               # pad lat only (Z, W already fit)
+    sg = 1 if conv.roll_sign > 0 else -1
     if roll:
-        x = torch.roll(x, shifts=(-(wz // 2), -(wh // 2), -(ww // 2)), dims=(0, 1, 2))
-        mask = shifted_window_mask(Z, Hp, W, x.dtype)
+        x = torch.roll(x, shifts=(sg * (wz // 2), sg * (wh // 2), sg * (ww // 2)), dims=(0, 1, 2))
+        mask = shifted_window_mask(Z, Hp, W, x.dtype, conv)
     else:
         mask = None
     nZ, nH, nW = Z // wz, Hp // wh, W // ww
@@ -200,7 +225,7 @@ def earth_block(p, x, res, heads, roll, emu=None):
     xw = earth_attention(p, xw, nZ * nH, heads, mask, emu)
     x = xw.reshape(nZ, nH, nW, wz, wh, ww, C).permute(0, 3, 1, 4, 2, 5, 6).reshape(Z, Hp, W, C)
     if roll:
-        x = torch.roll(x, shifts=(wz // 2, wh // 2, ww // 2), dims=(0, 1, 2))
+        x = torch.roll(x, shifts=(-sg * (wz // 2), -sg * (wh // 2), -sg * (ww // 2)), dims=(0, 1, 2))
     x = x[:, top:top + H].reshape(Z * H * W, C)
     x = shortcut + F.layer_norm(x, (C,), p["norm1.weight"], p["norm1.bias"], LN_EPS)
     h = _linear(x, p["mlp.fc1.weight"], p["mlp.fc1.bias"], emu)
@@ -228,7 +253,7 @@ def downsample(p, g: Geometry, x, emu=None):
     Z, H, W = g.res(1)
     C = x.shape[-1]
     x = x.reshape(Z, H, W, C)
-    He, top, bot = _centre_pad(H, 2)
+    He, top, bot = _centre_pad(H, 2, g.pad)
     x = F.pad(x, (0, 0, 0, 0, top, bot))
     x = x.reshape(Z, He // 2, 2, W // 2, 2, C).permute(0, 1, 3, 2, 4, 5).reshape(-1, 4 * C)
     x = F.layer_norm(x, (4 * C,), p["down.norm.weight"], p["down.norm.bias"], LN_EPS)
@@ -241,7 +266,7 @@ def upsample(p, g: Geometry, x, emu=None):
     x = _linear(x, p["up.linear1.weight"], None, emu)                  # (N2, 4*C_out)
     C = x.shape[-1] // 4
     x = x.reshape(Z, H2, W2, 2, 2, C).permute(0, 1, 3, 2, 4, 5).reshape(Z, 2 * H2, 2 * W2, C)
-    _, top, _ = _centre_pad(H1, 2)
+    _, top, _ = _centre_pad(H1, 2, g.pad)
     x = x[:, top:top + H1, :W1].reshape(-1, C)
     x = F.layer_norm(x, (C,), p["up.norm.weight"], p["up.norm.bias"], LN_EPS)
     return _linear(x, p["up.linear2.weight"], None, emu)
@@ -274,14 +299,14 @@ def split_state(x):
     return x[:nu].reshape(N_UPPER_VARS, N_LEVELS, *x.shape[1:]), x[nu:]
 
 
-def forward(params: dict, x: torch.Tensor, emu=None, taps: dict | None = None) -> torch.Tensor:
+def forward(params: dict, x: torch.Tensor, emu=None, taps: dict | None = None, conv: Conventions = DEFAULT) -> torch.Tensor:
     """One 6-h step.  x: (69, n_lat, n_lon) physical units -> same shape.
 
-    ``taps`` (optional dict) receives intermediate activations for kernel-level tests.
+    ``taps`` (optional dict) receives intermediate activations for kernel-level tests; ``conv`` selects the open conventions.
     """
     dt = x.dtype
     params = {k: (v.to(dt) if v.is_floating_point() else v) for k, v in params.items()}
-    g = Geometry(x.shape[1], x.shape[2])
+    g = Geometry(x.shape[1], x.shape[2], conv.pad)
     mean = params["norm.mean"][:, None, None]
     std = params["norm.std"][:, None, None]
     xn = (x - mean) / std
@@ -290,7 +315,7 @@ def forward(params: dict, x: torch.Tensor, emu=None, taps: dict | None = None) -
     if taps is not None:
         taps["embed"] = t
     for i in range(DEPTHS[0]):
-        t = earth_block(_block_params(params, 1, i), t, g.res(1), HEADS[0], i % 2 == 1, emu)
+        t = earth_block(_block_params(params, 1, i), t, g.res(1), HEADS[0], i % 2 == 1, emu, conv)
         if taps is not None:
             taps[f"layer1.block{i}"] = t
     skip = t
@@ -299,14 +324,14 @@ def forward(params: dict, x: torch.Tensor, emu=None, taps: dict | None = None) -
         taps["down"] = t
     for layer in (2, 3):
         for i in range(DEPTHS[layer - 1]):
-            t = earth_block(_block_params(params, layer, i), t, g.res(layer), HEADS[layer - 1], i % 2 == 1, emu)
+            t = earth_block(_block_params(params, layer, i), t, g.res(layer), HEADS[layer - 1], i % 2 == 1, emu, conv)
     if taps is not None:
         taps["layer3"] = t
     t = upsample(params, g, t, emu)
     if taps is not None:
         taps["up"] = t
     for i in range(DEPTHS[3]):
-        t = earth_block(_block_params(params, 4, i), t, g.res(4), HEADS[3], i % 2 == 1, emu)
+        t = earth_block(_block_params(params, 4, i), t, g.res(4), HEADS[3], i % 2 == 1, emu, conv)
     if taps is not None:
         taps["layer4"] = t
     t = torch.cat([skip, t], -1)
@@ -315,13 +340,13 @@ def forward(params: dict, x: torch.Tensor, emu=None, taps: dict | None = None) -
     return y * std + mean
 
 
-def rollout(params: dict, x: torch.Tensor, n_steps: int, emu=None):
+def rollout(params: dict, x: torch.Tensor, n_steps: int, emu=None, conv: Conventions = DEFAULT):
     """Autoregressive rollout with the 6-h network on every step -- the behaviour of
     GlobalModel.rollout (/root/reference/skyrim/core/models/base.py:119-146), which
     re-instantiates the time loop each step."""
     outs = []
     for _ in range(n_steps):
-        x = forward(params, x, emu)
+        x = forward(params, x, emu, conv=conv)
         outs.append(x)
     return outs
 

@@ -16,21 +16,25 @@ namespace {
 constexpr int kDepths[4] = {2, 6, 6, 2};
 constexpr int kBiasRows = 3312;
 
-int pad_to(int n, int mult, int* front) {
+int pad_to(int n, int mult, int* front, int pad_mode) {
     const int padded = (n + mult - 1) / mult * mult;
-    if (front) *front = (padded - n) / 2;
+    if (front) *front = pad_mode == SKPANGU_PAD_CENTRE ? (padded - n) / 2 : 0;
     return padded;
 }
 
 bool make_geom(const skpangu_config& c, Geom& g) {
     if (c.n_lat < 8 || c.n_lon <= 0 || c.n_lon % 96 != 0) return false;
+    if (c.roll_sign < -1 || c.roll_sign > 1 || (c.pad_mode != SKPANGU_PAD_CENTRE && c.pad_mode != SKPANGU_PAD_BACK)) return false;
+    if (c.mask_value > 0.f || c.mask_value < -60000.f) return false;      // the mask lives in the fp16 bias tiles
+    g.roll_sign = c.roll_sign > 0 ? 1 : -1;
+    g.mask_value = c.mask_value == 0.f ? -100.f : c.mask_value;
     g.n_lat = c.n_lat; g.n_lon = c.n_lon; g.n_levels = 13; g.n_channels = 69; g.surf0 = 65;
-    const int latp = pad_to(c.n_lat, 4, &g.lat_top);
+    const int latp = pad_to(c.n_lat, 4, &g.lat_top, c.pad_mode);
     g.Z = 8; g.H1 = latp / 4; g.W1 = c.n_lon / 4;
-    g.H2 = pad_to(g.H1, 2, nullptr) / 2; g.W2 = g.W1 / 2;
+    g.H2 = pad_to(g.H1, 2, nullptr, c.pad_mode) / 2; g.W2 = g.W1 / 2;       // 2x2 merge: an odd H1 pads ONE row, behind the data in both modes
     const int H[2] = {g.H1, g.H2}, W[2] = {g.W1, g.W2};
     for (int r = 0; r < 2; ++r) {
-        g.Hp[r] = pad_to(H[r], 6, &g.top[r]);
+        g.Hp[r] = pad_to(H[r], 6, &g.top[r], c.pad_mode);
         g.nH[r] = g.Hp[r] / 6; g.nW[r] = W[r] / 12;
         g.types[r] = (g.Z / 2) * g.nH[r];
         g.nwin[r] = g.types[r] * g.nW[r];
@@ -305,7 +309,7 @@ struct Engine : IEngine {
                 CK(copyf(bw.n1_b, P_(m, p + "norm1.bias"), c, s));
                 CK(copyf(bw.n2_g, P_(m, p + "norm2.weight"), c, s));
                 CK(copyf(bw.n2_b, P_(m, p + "norm2.bias"), c, s));
-                CK(prep_bias_expand(P_(m, p + "attn.bias_table"), const_cast<f16*>(bw.bias_exp), g.types[res], heads, g.nH[res], i & 1, s));
+                CK(prep_bias_expand(P_(m, p + "attn.bias_table"), const_cast<f16*>(bw.bias_exp), g.types[res], heads, g.nH[res], (i & 1) ? g.roll_sign : 0, g.mask_value, s));
             }
         }
         CK(copyf(w.down_g, P_(m, "down.norm.weight"), 768, s));
@@ -323,7 +327,7 @@ struct Engine : IEngine {
         const int H[2] = {g.H1, g.H2}, W[2] = {g.W1, g.W2};
         for (int r = 0; r < 2; ++r)
             for (int roll = 0; roll < 2; ++roll)
-                CK(prep_window_index(const_cast<int*>(w.widx[r][roll]), g.Z, H[r], W[r], g.Hp[r], g.top[r], roll, s));
+                CK(prep_window_index(const_cast<int*>(w.widx[r][roll]), g.Z, H[r], W[r], g.Hp[r], g.top[r], roll ? g.roll_sign : 0, s));
         return hipSuccess;
     }
 

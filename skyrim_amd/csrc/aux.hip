@@ -38,9 +38,11 @@ template hipError_t prep_weight<f16, 2>(const float*, f16*, long long, int, int,
 //   [lane][4]              keys 128 + 4 (lane >> 4) + [0..3]    (fragment 8)
 // with q = 16 qf + (lane & 15) and
 //   index = (z_q + 2 z_k) * 23*36 + (h_q + 6 h_k) * 23 + (w_q - w_k + 11)   (pseudocode _construct_index)
-// Odd (rolled) blocks fold the shifted-window mask in: -100 where q and key sit in different Swin
-// regions of the last Z window / last latitude window (longitude is periodic -> never masked).
-__global__ void prep_bias_expand_kernel(const float* __restrict__ table, f16* __restrict__ out, int types, int heads, int nH, int roll) {
+// Odd (rolled) blocks fold the shifted-window mask in: mask_value where q and key sit in different Swin
+// regions of the Z window / latitude window that mixes wrapped and unwrapped rows -- the LAST one when the block
+// rolls by -(1,3,6) first (roll = -1), the FIRST one when it rolls by +(1,3,6) first (roll = +1); longitude is
+// periodic -> never masked.
+__global__ void prep_bias_expand_kernel(const float* __restrict__ table, f16* __restrict__ out, int types, int heads, int nH, int roll, float mask_value) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long total = (long long)types * heads * 81 * 256;
     if (i >= total) return;
@@ -60,16 +62,16 @@ __global__ void prep_bias_expand_kernel(const float* __restrict__ table, f16* __
     if (roll) {
         const int zi = type / nH, hi = type % nH;
         const int nZ = types / nH;
-        const bool mz = (zi == nZ - 1) && (zq != zk);
-        const bool mh = (hi == nH - 1) && ((hq < 3) != (hk < 3));
-        if (mz || mh) v += -100.0f;
+        const bool mz = (zi == (roll < 0 ? nZ - 1 : 0)) && (zq != zk);
+        const bool mh = (hi == (roll < 0 ? nH - 1 : 0)) && ((hq < 3) != (hk < 3));
+        if (mz || mh) v += mask_value;
     }
     out[i] = (f16)v;
 }
 
-hipError_t prep_bias_expand(const float* table, f16* out, int types, int heads, int nH, int roll, hipStream_t s) {
+hipError_t prep_bias_expand(const float* table, f16* out, int types, int heads, int nH, int roll, float mask_value, hipStream_t s) {
     const long long total = (long long)types * heads * 81 * 256;
-    hipLaunchKernelGGL(prep_bias_expand_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, table, out, types, heads, nH, roll);
+    hipLaunchKernelGGL(prep_bias_expand_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, table, out, types, heads, nH, roll, mask_value);
     return hipGetLastError();
 }
 
@@ -84,7 +86,9 @@ __global__ void prep_window_index_kernel(int* __restrict__ idx, int Z, int H, in
     const int win = (int)(m / WIN_TOKENS);
     const int wi = win % nW, hi = (win / nW) % nH, zi = win / (nW * nH);
     int pz = 2 * zi + t / 72, ph = 6 * hi + (t / 12) % 6, pw = 12 * wi + t % 12;
-    if (roll) { pz = (pz + 1) % Z; ph = (ph + 3) % Hp; pw = (pw + 6) % W; }
+    // rolled[p] = x[(p - roll * shift) mod n]  (torch.roll semantics; roll = -1 | +1 selects the direction of the first roll)
+    if (roll < 0) { pz = (pz + 1) % Z; ph = (ph + 3) % Hp; pw = (pw + 6) % W; }
+    if (roll > 0) { pz = (pz + Z - 1) % Z; ph = (ph + Hp - 3) % Hp; pw = (pw + W - 6) % W; }
     const int h = ph - top;
     idx[m] = (h >= 0 && h < H) ? (pz * H + h) * W + pw : -1;
 }

@@ -32,7 +32,8 @@ _LIB_PATH = Path(__file__).resolve().parent.parent / "lib" / "libskyrim_pangu.so
 
 
 class SkConfig(ctypes.Structure):
-    _fields_ = [("n_lat", ctypes.c_int), ("n_lon", ctypes.c_int), ("precision", ctypes.c_int)]
+    _fields_ = [("n_lat", ctypes.c_int), ("n_lon", ctypes.c_int), ("precision", ctypes.c_int),
+                ("roll_sign", ctypes.c_int), ("pad_mode", ctypes.c_int), ("mask_value", ctypes.c_float)]
 
 
 class SkSizes(ctypes.Structure):
@@ -99,8 +100,18 @@ def _check(code: int, what: str):
         raise RuntimeError(f"{what} failed: {msg} (code {code})")
 
 
+PAD_MODES = {"centre": 0, "back": 1}
+
+
+def make_config(geom: PanguGeometry, precision: str = DEFAULT_PRECISION, roll_sign: int = -1, mask_value: float = -100.0) -> SkConfig:
+    """``skpangu_config`` of a geometry + the switchable conventions (include/skyrim_pangu.h; oracle: pangu_oracle.Conventions)."""
+    if roll_sign not in (-1, 1):
+        raise ValueError("roll_sign is -1 (Swin: roll by -(1,3,6) first) or +1 (pseudocode as written)")
+    return SkConfig(geom.n_lat, geom.n_lon, PRECISIONS[precision], roll_sign, PAD_MODES[geom.pad], float(mask_value))
+
+
 def query_sizes(geom: PanguGeometry, precision: str = DEFAULT_PRECISION) -> SkSizes:
-    cfg = SkConfig(geom.n_lat, geom.n_lon, PRECISIONS[precision])
+    cfg = make_config(geom, precision)
     out = SkSizes()
     _check(load_library().skpangu_query_sizes(ctypes.byref(cfg), ctypes.byref(out)), "skpangu_query_sizes")
     return out
@@ -109,7 +120,7 @@ def query_sizes(geom: PanguGeometry, precision: str = DEFAULT_PRECISION) -> SkSi
 def param_table(geom: PanguGeometry, precision: str = DEFAULT_PRECISION) -> list[tuple[str, int, tuple[int, ...]]]:
     """(name, element offset, shape) of every master parameter, as the library lays them out."""
     lib = load_library()
-    cfg = SkConfig(geom.n_lat, geom.n_lon, PRECISIONS[precision])
+    cfg = make_config(geom, precision)
     n = query_sizes(geom, precision).n_params
     out = []
     for i in range(n):
@@ -124,14 +135,16 @@ def param_table(geom: PanguGeometry, precision: str = DEFAULT_PRECISION) -> list
 class PanguEngine:
     """Device-resident Pangu 6-h step.  ``step`` maps a (69, n_lat, n_lon) fp32 CUDA tensor to the next state."""
 
-    def __init__(self, geom: PanguGeometry | None = None, precision: str = DEFAULT_PRECISION, device: str | torch.device = "cuda:0"):
+    def __init__(self, geom: PanguGeometry | None = None, precision: str = DEFAULT_PRECISION, device: str | torch.device = "cuda:0",
+                 roll_sign: int = -1, mask_value: float = -100.0):
+        """``roll_sign`` / ``mask_value`` / ``geom.pad``: the conventions the public pseudocode leaves open."""
         self.lib = load_library()
         if not torch.cuda.is_available():
             raise RuntimeError("PanguEngine needs a ROCm GPU (gfx950); there is no CPU fallback")
         self.geom = geom or PanguGeometry()
         self.precision = precision
         self.device = torch.device(device)
-        self.cfg = SkConfig(self.geom.n_lat, self.geom.n_lon, PRECISIONS[precision])
+        self.cfg = make_config(self.geom, precision, roll_sign, mask_value)
         self.sizes = query_sizes(self.geom, precision)
         with torch.cuda.device(self.device):
             self._prepared = torch.empty(self.sizes.prepared_bytes, dtype=torch.uint8, device=self.device)

@@ -32,18 +32,21 @@ BIAS_TABLE_ROWS = (2 * WINDOW[2] - 1) * WINDOW[1] ** 2 * WINDOW[0] ** 2   # 3312
 N_CONST_MASKS = 3
 
 
-def _pad_to(n: int, mult: int) -> tuple[int, int]:
-    """(padded, front) with centre padding: front = total // 2."""
+def _pad_to(n: int, mult: int, pad: str = "centre") -> tuple[int, int]:
+    """(padded, front): "centre" puts total // 2 zeros in front, "back" none (all padding behind the data)."""
     padded = (n + mult - 1) // mult * mult
-    return padded, (padded - n) // 2
+    return padded, ((padded - n) // 2 if pad == "centre" else 0)
 
 
 @dataclass(frozen=True)
 class PanguGeometry:
     n_lat: int = 721
     n_lon: int = 1440
+    pad: str = "centre"          # zero-padding placement, one of the conventions the pseudocode leaves open ("centre" | "back")
 
     def __post_init__(self):
+        if self.pad not in ("centre", "back"):
+            raise ValueError("pad is 'centre' or 'back'")
         if self.n_lon % (PATCH[2] * 2 * WINDOW[2]) != 0:
             raise ValueError("n_lon must be a multiple of 96 (patch 4 x merge 2 x window 12)")
         if self.n_lat < 8:
@@ -51,9 +54,9 @@ class PanguGeometry:
 
     # ---- input grid ------------------------------------------------------ #
     @cached_property
-    def lat_padded(self): return _pad_to(self.n_lat, PATCH[1])[0]
+    def lat_padded(self): return _pad_to(self.n_lat, PATCH[1], self.pad)[0]
     @cached_property
-    def lat_pad_top(self): return _pad_to(self.n_lat, PATCH[1])[1]
+    def lat_pad_top(self): return _pad_to(self.n_lat, PATCH[1], self.pad)[1]
     @property
     def n_levels(self): return len(LEVELS)
     @property
@@ -66,7 +69,7 @@ class PanguGeometry:
     @cached_property
     def W1(self): return self.n_lon // PATCH[2]
     @cached_property
-    def H2(self): return _pad_to(self.H1, 2)[0] // 2
+    def H2(self): return _pad_to(self.H1, 2, self.pad)[0] // 2
     @cached_property
     def W2(self): return self.W1 // 2
 
@@ -74,8 +77,8 @@ class PanguGeometry:
     def dim(self, layer: int): return DIM if layer in (1, 4) else 2 * DIM
     def tokens(self, layer: int):
         z, h, w = self.res(layer); return z * h * w
-    def padded_lat(self, layer: int): return _pad_to(self.res(layer)[1], WINDOW[1])[0]
-    def pad_top(self, layer: int): return _pad_to(self.res(layer)[1], WINDOW[1])[1]
+    def padded_lat(self, layer: int): return _pad_to(self.res(layer)[1], WINDOW[1], self.pad)[0]
+    def pad_top(self, layer: int): return _pad_to(self.res(layer)[1], WINDOW[1], self.pad)[1]
     def n_windows(self, layer: int):
         z, _, w = self.res(layer)
         return (z // WINDOW[0]) * (self.padded_lat(layer) // WINDOW[1]) * (w // WINDOW[2])

@@ -102,3 +102,27 @@ def test_rollout_is_repeated_6h_step(toy):
     g, params, x = toy
     outs = O.rollout(params, x, 2)
     assert torch.equal(outs[1], O.forward(params, outs[0]))
+
+
+def test_switchable_conventions_roll_sign_mask_value_pad(toy):
+    """The three conventions the pseudocode leaves open (oracle header; include/skyrim_pangu.h skpangu_config) each change the
+    result, so a real ONNX file can discriminate them; the defaults reproduce the golden vectors (test_golden_vectors)."""
+    g, params, x = toy
+    base = O.forward(params, x)
+    # +1: roll3D(x, shift=+half) first -> the FIRST Z / latitude window mixes wrapped rows and is the masked one
+    plus = O.Conventions(roll_sign=+1)
+    m = O.shifted_window_mask(8, 18, 48, torch.float32, plus)
+    for t in range(12):
+        zi, hi = divmod(t, 3)
+        assert bool((m[t] != 0).any()) == (zi == 0 or hi == 0)
+    xr = torch.arange(8 * 18 * 48.0).reshape(8, 18, 48)
+    assert torch.roll(xr, (1, 3, 6), (0, 1, 2))[1, 3, 6] == xr[0, 0, 0]          # what "+1" means: rolled[p] = x[p - shift]
+    assert set(O.shifted_window_mask(8, 18, 48, torch.float32, O.Conventions(mask_value=-1000.0)).unique().tolist()) == {-1000.0, 0.0}
+    for conv in (plus, O.Conventions(pad="back"), O.Conventions(mask_value=-3.0)):
+        y = O.forward(params, x, conv=conv)
+        assert torch.isfinite(y).all() and O.per_channel_rel_err(y, base).max() > 1e-3, conv
+    # -100 vs -1000 is numerically the same mask (exp underflows either way)
+    assert O.per_channel_rel_err(O.forward(params, x, conv=O.Conventions(mask_value=-1000.0)), base).max() < 1e-5
+    gb = O.Geometry(721, 1440, "back")
+    assert gb.lat_pad == (724, 0, 3) and gb.res(1) == (8, 181, 360) and spec.PanguGeometry(721, 1440, "back").pad_top(1) == 0
+    assert spec.PanguGeometry(721, 1440).pad_top(1) == 2 and spec.PanguGeometry(721, 1440).lat_pad_top == 1

@@ -175,16 +175,36 @@ def full():
     return g, params, x, e
 
 
-@pytest.mark.timeout(900)
-def test_full_size_step_vs_oracle(full):
+@pytest.fixture(scope="module")
+def full_ref(full):
+    """BASELINE configs[1]: the oracle's 24-h rollout (4 steps) at 721x1440 -- ~1 min of host time per step."""
+    g, params, x, e = full
+    return O.rollout(params, x, 4)
+
+
+@pytest.mark.timeout(1500)
+def test_full_size_step_vs_oracle(full, full_ref):
     """The headline configuration against the CPU oracle, per channel (the north star's 1e-3 bar)."""
     g, params, x, e = full
     y = e.step(x.cuda())
-    want = O.forward(params, x)
-    err = O.per_channel_rel_err(y.cpu(), want)
+    err = O.per_channel_rel_err(y.cpu(), full_ref[0])
     assert torch.isfinite(y).all()
     assert err.max().item() < 1e-3, err
     assert err.max().item() < 3e-4, err          # what the default mode actually delivers (~1.5e-4)
+
+
+@pytest.mark.timeout(1500)
+def test_full_size_24h_rollout_vs_oracle(full, full_ref):
+    """BASELINE configs[1] as named: Pangu 24-h rollout = 4 autoregressive 6-h steps at 721x1440, each engine state fed back in
+    place, against the oracle's own rollout -- every step inside the bar, with the 2x margin the default mode is chosen for."""
+    g, params, x, e = full
+    state = x.cuda().clone()
+    errs = []
+    for k in range(4):
+        e.step(state, out=state)                # in place, as bench.py times it
+        errs.append(O.per_channel_rel_err(state.cpu(), full_ref[k]).max().item())
+    assert torch.isfinite(state).all()
+    assert max(errs) < 5e-4, errs
 
 
 @pytest.mark.timeout(900)
@@ -308,3 +328,20 @@ def test_step_through_the_custom_op_boundary(toy):
         torch.ops.skyrim_hip.pangu_step(eng._ctx.value, x, torch.empty_like(x))
     with pytest.raises(ValueError):
         torch.ops.skyrim_hip.pangu_step(eng._ctx.value, xd.double(), out)
+
+
+@pytest.mark.parametrize("conv", [dict(roll_sign=+1), dict(pad="back"), dict(roll_sign=+1, pad="back", mask_value=-1000.0)])
+def test_switchable_conventions_match_the_oracle(toy, conv):
+    """roll_sign / pad / mask_value (include/skyrim_pangu.h skpangu_config <-> oracle Conventions): the engine follows the oracle
+    under each setting, and does NOT match the oracle of the other setting -- the test that flips the convention."""
+    from skyrim_amd.pangu.engine import PanguEngine
+    g0, params, x = toy
+    g = PanguGeometry(g0.n_lat, g0.n_lon, conv.get("pad", "centre"))
+    eng = PanguEngine(g, device="cuda:0", roll_sign=conv.get("roll_sign", -1), mask_value=conv.get("mask_value", -100.0))
+    eng.load_params(params)
+    y = eng.step(x.cuda()).cpu()
+    want = O.forward(params, x, conv=O.Conventions(**conv))
+    assert O.per_channel_rel_err(y, want).max().item() < 3e-4
+    assert O.per_channel_rel_err(y, O.forward(params, x)).max().item() > 1e-3
+    y2 = eng.step(eng.step(x.cuda())).cpu()                     # rolled + unrolled blocks compose over steps
+    assert O.per_channel_rel_err(y2, O.rollout(params, x, 2, conv=O.Conventions(**conv))[1]).max().item() < 3e-4
