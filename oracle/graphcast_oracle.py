@@ -7,15 +7,25 @@ available here and the reference's tests hold no numerical vector
 Methods (Lam et al. 2023): grid-node / mesh-node / edge embedders, a grid->mesh interaction network, 16 interaction
 networks on the multi-mesh, a mesh->grid interaction network, an output MLP predicting the normalised residual of the
 latest state; every MLP = Linear -> swish -> Linear (-> LayerNorm), latent 512, sum aggregation at the receiver,
-residual updates of nodes and edges.  The graph itself (multi-mesh, grid<->mesh edges, structural features) is data
-and comes from skyrim_amd/graphcast/mesh.py, pinned in tests by the published node / edge counts.
+residual updates of nodes and edges.  The graph (multi-mesh, grid<->mesh edges, structural features) has its OWN restatement in
+oracle/graphcast_graph.py (``build``); parity tests hand ``forward`` that graph, not the product's (skyrim_amd/graphcast/mesh.py is
+compared with it edge set by edge set in tests/test_graphcast_oracle.py).  Nothing under oracle/ imports skyrim_amd.
+
+What deepmind/graphcast's typed-graph network has beyond what is computed here (none of it can change the output): the
+mesh->grid GNN also updates its MESH nodes (an MLP 512 -> 512 -> 512 + LayerNorm whose result is never read: 0.53 M parameters),
+and the grid->mesh embedder pads the mesh nodes' 3 structural features with zeros to the grid-node input width (zero inputs:
++0.24 M weights at 474 inputs).  Together with the 37-level model's wider input / output layers (474 / 227 vs 186 / 83: 0.22 M)
+they account for 1.0 M of the 1.3 M between this network's 35.4 M parameters and the paper's 36.7 M; 0.35 M (1 %) are not
+identified.
 """
 from __future__ import annotations
 
 import torch
 import torch.nn.functional as F
 
-from skyrim_amd.graphcast.spec import GraphcastConfig
+
+def processor_steps(p: dict) -> int:
+    return 1 + max(int(k.split(".")[1]) for k in p if k.startswith("proc."))
 
 
 def mlp(p: dict, name: str, x: torch.Tensor) -> torch.Tensor:
@@ -30,8 +40,10 @@ def aggregate(e: torch.Tensor, receivers: torch.Tensor, n: int) -> torch.Tensor:
     return torch.zeros(n, e.shape[1], dtype=e.dtype).index_add_(0, receivers, e)
 
 
-def forward(p: dict, graph, x_prev: torch.Tensor, x_cur: torch.Tensor, forcing: torch.Tensor, cfg: GraphcastConfig, taps: dict | None = None):
-    """(n_vars, n_lat, n_lon) x 2 + (15, n_lat, n_lon) forcings -> next state (n_vars, n_lat, n_lon)."""
+def forward(p: dict, graph, x_prev: torch.Tensor, x_cur: torch.Tensor, forcing: torch.Tensor, cfg=None, taps: dict | None = None):
+    """(n_vars, n_lat, n_lon) x 2 + (15, n_lat, n_lon) forcings -> next state (n_vars, n_lat, n_lon).  ``graph``: graphcast_graph.build(...)
+    (any object with its fields; edge order is free).  ``cfg`` is accepted for call-site symmetry with the engine and not read: the
+    number of processor steps is what the parameter dict holds."""
     t = lambda a: torch.from_numpy(a)  # noqa: E731
     mean, std = p["norm.mean"][:, None, None], p["norm.std"][:, None, None]
     feats = torch.cat([(x_prev - mean) / std, (x_cur - mean) / std, forcing, p["static"]], dim=0).flatten(1).T      # [n_grid][2V + 17]
@@ -48,7 +60,7 @@ def forward(p: dict, graph, x_prev: torch.Tensor, x_cur: torch.Tensor, forcing: 
     if taps is not None:
         taps["encoder.vm"], taps["encoder.vg"] = vm, vg
     # processor
-    for i in range(cfg.steps):
+    for i in range(processor_steps(p)):
         de = mlp(p, f"proc.{i}.edge", torch.cat([em, vm[me[:, 0]], vm[me[:, 1]]], dim=1))
         vm = vm + mlp(p, f"proc.{i}.node", torch.cat([vm, aggregate(de, me[:, 1], graph.n_mesh)], dim=1))
         em = em + de

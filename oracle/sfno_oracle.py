@@ -28,7 +28,17 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-from skyrim_amd.sfno.spec import CHANNELS, SfnoConfig, flops_per_step, init_synthetic, param_spec, synthetic_state  # noqa: F401  (shapes and synthetic inputs: one definition)
+
+
+class Shape:
+    """Derived sizes of a configuration, computed HERE from its primary fields (n_lat, n_lon, scale_factor, num_layers, eps,
+    out_chans) -- the oracle reads a configuration object as data and derives nothing from the product's code."""
+
+    def __init__(self, cfg):
+        self.n_lat, self.n_lon, self.num_layers, self.eps, self.out_chans = cfg.n_lat, cfg.n_lon, cfg.num_layers, cfg.eps, cfg.out_chans
+        self.h, self.w = cfg.n_lat // cfg.scale_factor, cfg.n_lon // cfg.scale_factor      # internal Legendre-Gauss grid
+        self.lmax = self.h                                                                 # triangular-ish truncation: l < h
+        self.mmax = min(self.w // 2 + 1, self.lmax)                                        # m < min(w/2 + 1, lmax)
 
 
 # ---- quadrature + Legendre functions (torch-harmonics quadrature.py / legendre.py) ---------------- #
@@ -113,12 +123,13 @@ def _instance_norm(x, g, b, eps):
 class Transforms:
     """The four SHTs of the network (sfnonet.py: trans_down, itrans_up, trans, itrans)."""
 
-    def __init__(self, cfg: SfnoConfig, dtype=torch.float64):
+    def __init__(self, cfg, dtype=torch.float64):
+        cfg = Shape(cfg)
         self.down = SHT(cfg.n_lat, cfg.n_lon, cfg.lmax, cfg.mmax, "equiangular", dtype)
         self.inner = SHT(cfg.h, cfg.w, cfg.lmax, cfg.mmax, "legendre-gauss", dtype)
 
 
-def block(p: dict, prefix: str, x: torch.Tensor, fwd: SHT, inv: SHT, cfg: SfnoConfig, taps: dict | None = None):
+def block(p: dict, prefix: str, x: torch.Tensor, fwd: SHT, inv: SHT, cfg, taps: dict | None = None):
     g = lambda n: p[prefix + n]  # noqa: E731
     xn = _instance_norm(x, g("norm0.weight"), g("norm0.bias"), cfg.eps)
     coef = fwd.forward(xn)                                                     # (C, L, M) complex
@@ -136,9 +147,11 @@ def block(p: dict, prefix: str, x: torch.Tensor, fwd: SHT, inv: SHT, cfg: SfnoCo
     return y
 
 
-def forward(params: dict, x: torch.Tensor, cfg: SfnoConfig, tr: Transforms | None = None, taps: dict | None = None) -> torch.Tensor:
-    """One 6-h step: (in_chans, n_lat, n_lon) -> (out_chans, n_lat, n_lon), physical units in and out."""
+def forward(params: dict, x: torch.Tensor, cfg, tr: Transforms | None = None, taps: dict | None = None) -> torch.Tensor:
+    """One 6-h step: (in_chans, n_lat, n_lon) -> (out_chans, n_lat, n_lon), physical units in and out.  ``cfg``: any object with
+    n_lat, n_lon, scale_factor, num_layers, eps, out_chans."""
     tr = tr or Transforms(cfg)
+    cfg = Shape(cfg)
     p = params
     mean, std = p["norm.mean"][:, None, None], p["norm.std"][:, None, None]
     xin = (x - mean) / std

@@ -5,7 +5,7 @@
   (splits = 6: 40 962 nodes, 81 920 finest faces, 327 660 directed edges);
 * grid -> mesh edges: every lat/lon grid point sends to the finest-mesh nodes within 0.6 x (longest finest-mesh edge);
 * mesh -> grid edges: every grid point receives from the 3 vertices of the finest-mesh triangle that contains it;
-* structural features: nodes (cos lat, sin lon, cos lon); edges (length, and the sender's position relative to the receiver in
+* structural features: nodes (sin lat, cos lon, sin lon); edges (length, and the sender's position relative to the receiver in
   the receiver's local frame -- rotated so that the receiver sits at lat = lon = 0), scaled by the longest edge of the set.
 
 Everything here is host-side preparation (numpy / scipy.spatial), done once per geometry.
@@ -41,15 +41,11 @@ def icosahedron():
                     if np.dot(np.cross(v[j] - v[i], v[k] - v[i]), v[i] + v[j] + v[k]) < 0:      # outward orientation
                         f = [i, k, j]
                     faces.append(f)
-    # rotate so that two opposite vertices sit on the poles (deepmind's mesh does the same; any fixed orientation works)
-    z = v[0]
-    x = np.cross([0.0, 0.0, 1.0], z)
-    if np.linalg.norm(x) > 1e-12:
-        x /= np.linalg.norm(x)
-        c, s = z[2], np.sqrt(1.0 - z[2] ** 2)
-        k = np.array([[0, -x[2], x[1]], [x[2], 0, -x[0]], [-x[1], x[0], 0]])
-        r = np.eye(3) + (-s) * k + (1 - c) * (k @ k)        # Rodrigues rotation taking z to the north pole
-        v = v @ r.T
+    # orientation of deepmind/graphcast's icosahedral_mesh.get_icosahedron: out of the box the top is an edge parallel to y; a turn
+    # about y by half the supplement of the dihedral angle lays one of its two faces flat on top (a FACE faces the north pole)
+    turn = (np.pi - 2.0 * np.arcsin(phi / np.sqrt(3.0))) / 2.0
+    c, s = np.cos(turn), np.sin(turn)
+    v = v @ np.array([[c, 0.0, s], [0.0, 1.0, 0.0], [-s, 0.0, c]])
     return v, np.array(faces, dtype=np.int64)
 
 
@@ -89,9 +85,11 @@ def xyz_to_lat_lon(p):
     return np.arcsin(np.clip(p[..., 2], -1.0, 1.0)), np.arctan2(p[..., 1], p[..., 0])
 
 
-def edge_features(pos_send: np.ndarray, pos_recv: np.ndarray) -> np.ndarray:
-    """(length, dx, dy, dz of the sender relative to the receiver in the receiver's local frame) / longest length."""
-    lat, lon = xyz_to_lat_lon(pos_recv)
+def edge_features(pos_send: np.ndarray, pos_recv: np.ndarray, recv_lat_lon=None) -> np.ndarray:
+    """(length, dx, dy, dz of the sender relative to the receiver in the receiver's local frame) / longest length.
+    ``recv_lat_lon`` (radians): the receiver's own latitude / longitude when it is a grid point -- the grid points on a pole share
+    one position but keep their own longitude as local frame (deepmind/graphcast rotates by the node's lat / lon)."""
+    lat, lon = xyz_to_lat_lon(pos_recv) if recv_lat_lon is None else recv_lat_lon
     # rotate about z by -lon, then about y so that the receiver goes to (1, 0, 0)
     cl, sl, cp, sp = np.cos(lon), np.sin(lon), np.cos(lat), np.sin(lat)
 
@@ -107,9 +105,11 @@ def edge_features(pos_send: np.ndarray, pos_recv: np.ndarray) -> np.ndarray:
     return (f / length.max()).astype(np.float32)
 
 
-def node_features(pos: np.ndarray) -> np.ndarray:
-    lat, lon = xyz_to_lat_lon(pos)
-    return np.stack([np.cos(lat), np.sin(lon), np.cos(lon)], axis=-1).astype(np.float32)
+def node_features(pos: np.ndarray, lat_lon=None) -> np.ndarray:
+    """(sin lat, cos lon, sin lon): deepmind/graphcast's model_utils takes the cosine of the POLAR angle ("from 1 at the north pole
+    to -1 at the south pole") and then cos / sin of the longitude."""
+    lat, lon = xyz_to_lat_lon(pos) if lat_lon is None else lat_lon
+    return np.stack([np.sin(lat), np.cos(lon), np.sin(lon)], axis=-1).astype(np.float32)
 
 
 @dataclass
@@ -135,7 +135,9 @@ def _sort_by_receiver(edges: np.ndarray) -> np.ndarray:
 
 
 def containing_triangles(points: np.ndarray, verts: np.ndarray, faces: np.ndarray) -> np.ndarray:
-    """Index of the spherical triangle containing each unit vector (ties on edges / vertices go to the best candidate)."""
+    """Index of the spherical triangle containing each unit vector.  A point lying ON an edge or a vertex belongs to several
+    triangles; the tie goes to the one whose centroid is largest in (z, y, x) order (a geometric rule, so that any two
+    constructions of the same mesh agree whatever their face numbering)."""
     cent = verts[faces].mean(axis=1)
     cent /= np.linalg.norm(cent, axis=1, keepdims=True)
     tree = cKDTree(cent)
@@ -145,12 +147,18 @@ def containing_triangles(points: np.ndarray, verts: np.ndarray, faces: np.ndarra
     nab, nbc, nca = np.cross(a, b), np.cross(b, c), np.cross(c, a)          # inward-pointing for outward-oriented faces
     best = np.full(len(points), -1, dtype=np.int64)
     best_margin = np.full(len(points), -np.inf)
+    best_key = np.full((len(points), 3), -np.inf)
+    tol = 1e-9
     for j in range(k):
         f = cand[:, j]
-        m = np.minimum(np.minimum(np.einsum("ij,ij->i", nab[f], points), np.einsum("ij,ij->i", nbc[f], points)), np.einsum("ij,ij->i", nca[f], points))
-        upd = m > best_margin
-        best[upd], best_margin[upd] = f[upd], m[upd]
-    if (best_margin < -1e-9).any():
+        d1, d2, d3 = np.einsum("ij,ij->i", nab[f], points), np.einsum("ij,ij->i", nbc[f], points), np.einsum("ij,ij->i", nca[f], points)
+        m = np.minimum(np.minimum(d1, d2), d3) / (d1 + d2 + d3)   # smallest barycentric weight of the point's central projection
+        m = np.minimum(m + tol, 0.0)                             # every containing triangle (within tol) counts the same; only "outside" is worse
+        d = cent[f][:, ::-1] - best_key
+        lex = (d[:, 0] > tol) | ((np.abs(d[:, 0]) <= tol) & ((d[:, 1] > tol) | ((np.abs(d[:, 1]) <= tol) & (d[:, 2] > tol))))
+        upd = (m > best_margin) | ((m == 0.0) & (best_margin == 0.0) & lex)
+        best[upd], best_margin[upd], best_key[upd] = f[upd], m[upd], cent[f][:, ::-1][upd]
+    if (best_margin < 0.0).any():
         raise RuntimeError("a grid point lies in none of its candidate triangles")
     return best
 
@@ -165,7 +173,8 @@ def build_graph(n_lat: int, n_lon: int, splits: int) -> GraphStructure:
     mesh_edges = _sort_by_receiver(mesh_edges)
     lat = np.linspace(90.0, -90.0, n_lat)
     lon = np.arange(n_lon) * (360.0 / n_lon)
-    grid_pos = lat_lon_to_xyz(np.repeat(lat, n_lon), np.tile(lon, n_lat))
+    glat, glon = np.repeat(lat, n_lon), np.tile(lon, n_lat)
+    grid_pos = lat_lon_to_xyz(glat, glon)
     fine_edges = faces_to_edges(f)
     longest = np.linalg.norm(v[fine_edges[:, 0]] - v[fine_edges[:, 1]], axis=1).max()
     tree = cKDTree(v)
@@ -179,8 +188,8 @@ def build_graph(n_lat: int, n_lon: int, splits: int) -> GraphStructure:
         n_grid=len(grid_pos), n_mesh=len(v), mesh_pos=v, grid_pos=grid_pos, mesh_edges=mesh_edges, g2m_edges=g2m, m2g_edges=m2g,
         mesh_edge_feat=edge_features(v[mesh_edges[:, 0]], v[mesh_edges[:, 1]]),
         g2m_edge_feat=edge_features(grid_pos[g2m[:, 0]], v[g2m[:, 1]]),
-        m2g_edge_feat=edge_features(v[m2g[:, 0]], grid_pos[m2g[:, 1]]),
-        mesh_node_feat=node_features(v), grid_node_feat=node_features(grid_pos), faces=f)
+        m2g_edge_feat=edge_features(v[m2g[:, 0]], grid_pos[m2g[:, 1]], (np.deg2rad(glat[m2g[:, 1]]), np.deg2rad(glon[m2g[:, 1]]))),
+        mesh_node_feat=node_features(v), grid_node_feat=node_features(grid_pos, (np.deg2rad(glat), np.deg2rad(glon))), faces=f)
 
 
 def latitude_band(n_lat: int, rank: int, world: int) -> tuple[int, int]:

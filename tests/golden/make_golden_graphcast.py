@@ -15,7 +15,7 @@ import torch
 ROOT = Path(__file__).resolve().parents[2]
 sys.path.insert(0, str(ROOT))
 from oracle import graphcast_oracle as O  # noqa: E402
-from skyrim_amd.graphcast.mesh import build_graph  # noqa: E402
+from oracle import graphcast_graph as OG  # noqa: E402
 from skyrim_amd.graphcast.spec import GraphcastConfig, forcings, init_synthetic, synthetic_states  # noqa: E402
 
 TINY = dict(n_lat=33, n_lon=64, splits=2, latent=32, steps=3)
@@ -23,12 +23,12 @@ TINY = dict(n_lat=33, n_lon=64, splits=2, latent=32, steps=3)
 if __name__ == "__main__":
     torch.set_num_threads(8)
     cfg = GraphcastConfig(**TINY)
-    g = build_graph(cfg.n_lat, cfg.n_lon, cfg.splits)
+    g = OG.build(cfg.n_lat, cfg.n_lon, cfg.splits)          # the oracle's own graph construction
     p = init_synthetic(cfg, 0)
     x0, x1 = synthetic_states(cfg, 0)
     f = forcings(cfg, 1000.0)
     taps = {}
-    y = O.forward(p, g, x0, x1, f, cfg, taps=taps)
+    y = O.forward(p, g, x0, x1, f, taps=taps)
     np.savez_compressed(Path(__file__).with_name("graphcast_tiny_33x64.npz"),
                         x_prev_sub=x0[:, ::4, ::8].numpy(), x_cur_sub=x1[:, ::2, ::4].numpy(), forcing_sub=f[:, ::4, ::8].numpy(), step1_sub=y[:, ::2, ::4].numpy(),
                         increment_absmax=(y - x1).abs().amax(dim=(1, 2)).numpy(),

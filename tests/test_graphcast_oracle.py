@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 import torch
 
+from oracle import graphcast_graph as OG
 from oracle import graphcast_oracle as O
 from skyrim_amd.graphcast import engine as E
 from skyrim_amd.graphcast.mesh import build_graph, edge_features, faces_to_edges, icosahedron, lat_lon_to_xyz, latitude_band, refine, shard_graph
@@ -22,7 +23,9 @@ def test_icosahedron_and_refinement_invariants():
     assert v.shape == (12, 3) and f.shape == (20, 3) and np.allclose(np.linalg.norm(v, axis=1), 1.0)
     e = faces_to_edges(f)
     assert len(e) == 60 and np.allclose(np.linalg.norm(v[e[:, 0]] - v[e[:, 1]], axis=1), np.linalg.norm(v[e[0, 0]] - v[e[0, 1]]))
-    assert abs(abs(v[:, 2]).max() - 1.0) < 1e-12                       # two vertices on the poles
+    top = np.argsort(-v[:, 2])[:3]                                       # deepmind's orientation: a FACE on top, not a vertex
+    assert np.allclose(v[top, 2], v[top[0], 2]) and sorted(top.tolist()) in [sorted(t) for t in f.tolist()]
+    assert abs(np.linalg.norm(v[top].mean(0)[:2])) < 1e-12                # its centroid is the north pole
     for _ in range(3):
         v0 = v
         v, f = refine(v, f)
@@ -82,9 +85,79 @@ def test_grid_sharding_partitions_the_graph(world):
     assert latitude_band(33, 0, world)[0] == 0 and latitude_band(33, world - 1, world)[1] == 33
 
 
+def _edge_set(edges):
+    return set(map(tuple, np.asarray(edges).tolist()))
+
+
+def _node_map(a_pos, b_pos):
+    """index in b of every node of a (the two constructions number the mesh nodes differently)."""
+    from scipy.spatial import cKDTree
+    d, j = cKDTree(b_pos).query(a_pos)
+    assert d.max() < 1e-9 and len(set(j.tolist())) == len(a_pos)
+    return j
+
+
+@pytest.mark.parametrize("grid,splits", [((33, 64), 2), ((61, 120), 3), ((181, 360), 4)])
+def test_product_graph_equals_the_oracles_own_construction(grid, splits):
+    """mesh.py (product) against oracle/graphcast_graph.py (written separately, restating deepmind/graphcast's modules): same
+    node positions up to numbering, identical edge SETS, identical features edge by edge -- so parity tests that hand the
+    oracle ITS graph and the engine the product's would expose any error in either construction."""
+    g = build_graph(*grid, splits)
+    o = OG.build(*grid, splits)
+    assert (g.n_mesh, g.n_grid) == (o.n_mesh, o.n_grid) and np.allclose(g.grid_pos, o.grid_pos, atol=1e-12)
+    to_o = _node_map(g.mesh_pos, o.mesh_pos)                                          # product mesh index -> oracle mesh index
+    assert _edge_set(np.stack([to_o[g.mesh_edges[:, 0]], to_o[g.mesh_edges[:, 1]]], 1)) == _edge_set(o.mesh_edges)
+    assert _edge_set(np.stack([g.g2m_edges[:, 0], to_o[g.g2m_edges[:, 1]]], 1)) == _edge_set(o.g2m_edges)
+    # mesh -> grid: the same triangle for EVERY grid point -- points on a mesh edge / vertex follow the shared geometric tie rule
+    tg = np.sort(to_o[g.m2g_edges[:, 0]].reshape(-1, 3), axis=1)
+    to_ = np.sort(o.m2g_edges[:, 0].reshape(-1, 3), axis=1)
+    differ = np.nonzero((tg != to_).any(axis=1))[0]
+    assert len(differ) == 0
+    # features, matched edge by edge through (sender, receiver) keys
+
+    def table(edges, feat):
+        return {tuple(e): f for e, f in zip(np.asarray(edges).tolist(), feat)}
+
+    for ge, gf, oe, of, map_s, map_r in ((g.mesh_edges, g.mesh_edge_feat, o.mesh_edges, o.mesh_edge_feat, to_o, to_o),
+                                         (g.g2m_edges, g.g2m_edge_feat, o.g2m_edges, o.g2m_edge_feat, None, to_o)):
+        ot = table(oe, of)
+        keys = np.stack([map_s[ge[:, 0]] if map_s is not None else ge[:, 0], map_r[ge[:, 1]] if map_r is not None else ge[:, 1]], 1)
+        assert np.allclose(np.stack([ot[tuple(k)] for k in keys.tolist()]), gf, atol=2e-6)
+    same = np.setdiff1d(np.arange(g.n_grid), differ)
+    ot = table(o.m2g_edges, o.m2g_edge_feat)
+    rows = np.repeat(same, 3) * 3 + np.tile(np.arange(3), len(same))
+    keys = np.stack([to_o[g.m2g_edges[rows, 0]], g.m2g_edges[rows, 1]], 1)
+    assert np.allclose(np.stack([ot[tuple(k)] for k in keys.tolist()]), g.m2g_edge_feat[rows], atol=2e-6)
+    assert np.allclose(g.grid_node_feat, o.grid_node_feat, atol=1e-6) and np.allclose(g.mesh_node_feat, o.mesh_node_feat[to_o], atol=1e-6)
+
+
+def test_oracle_graph_follows_the_published_conventions():
+    """oracle/graphcast_graph.py header: face-up icosahedron, (sin lat, cos lon, sin lon) node features, receiver-local edge
+    features normalised by the longest edge, 0.6 x longest-edge radius."""
+    pts, tri = OG.base_icosahedron()
+    assert len(tri) == 20 and np.allclose(np.linalg.norm(pts, axis=1), 1.0)
+    top = np.argsort(-pts[:, 2])[:3]
+    assert np.allclose(pts[top, 2], pts[top[0], 2]) and np.allclose(pts[top].mean(0)[:2], 0.0, atol=1e-12)
+    # before the rotation the top is an edge parallel to y: vertices 1 and 7 of the construction order
+    raw = np.array([(0.0, 1.0, OG.PHI), (0.0, -1.0, OG.PHI)]) / np.hypot(1.0, OG.PHI)
+    assert np.allclose(raw[:, 2], raw[0, 2]) and np.allclose(raw[:, 0], 0.0)
+    nf = OG.node_features(OG.lat_lon_to_unit(np.array([90.0, 0.0, -30.0]), np.array([0.0, 90.0, 180.0])))
+    assert np.allclose(nf, [[1.0, 1.0, 0.0], [0.0, 0.0, 1.0], [-0.5, -1.0, 0.0]], atol=1e-6)
+    recv = OG.lat_lon_to_unit(np.array([0.0, 40.0, -70.0]), np.array([0.0, 100.0, 250.0]))
+    east = OG.lat_lon_to_unit(np.array([0.0, 40.0, -70.0]), np.array([1.0, 101.0, 251.0]))
+    north = OG.lat_lon_to_unit(np.array([1.0, 41.0, -69.0]), np.array([0.0, 100.0, 250.0]))
+    fe, fn = OG.edge_features(east, recv), OG.edge_features(north, recv)
+    assert (fe[:, 2] > 0).all() and (fn[:, 3] > 0).all() and (np.abs(fn[:, 2]) < 1e-6).all() and abs(fe[:, 0].max() - 1.0) < 1e-6
+    o = OG.build(33, 64, 2)
+    fine = OG.directed_edges(o.faces)
+    longest = np.linalg.norm(o.mesh_pos[fine[:, 0]] - o.mesh_pos[fine[:, 1]], axis=1).max()
+    d = np.linalg.norm(o.grid_pos[o.g2m_edges[:, 0]] - o.mesh_pos[o.g2m_edges[:, 1]], axis=1)
+    assert d.max() <= 0.6 * longest and len(o.mesh_edges) == 2 * (30 + 120 + 480)      # edges of M0 + M1 + M2, both directions
+
+
 def test_oracle_matches_golden_fixture():
     gold = np.load(GOLD)
-    g = build_graph(TINY.n_lat, TINY.n_lon, TINY.splits)
+    g = OG.build(TINY.n_lat, TINY.n_lon, TINY.splits)                      # the oracle's own graph
     assert np.array_equal(g.mesh_edges, gold["mesh_edges"]) and np.array_equal(g.g2m_edges[::13], gold["g2m_edges_sub"])
     assert np.array_equal(g.m2g_edges[::11, 0], gold["m2g_senders_sub"]) and np.allclose(g.mesh_edge_feat[::9], gold["mesh_edge_feat_sub"], atol=1e-6)
     p = init_synthetic(TINY, 0)
@@ -92,11 +165,14 @@ def test_oracle_matches_golden_fixture():
     f = forcings(TINY, 1000.0)
     assert np.array_equal(x1[:, ::2, ::4].numpy(), gold["x_cur_sub"]) and np.allclose(f[:, ::4, ::8].numpy(), gold["forcing_sub"], atol=1e-6)
     taps = {}
-    y = O.forward(p, g, x0, x1, f, TINY, taps=taps)
+    y = O.forward(p, g, x0, x1, f, taps=taps)
     assert (np.abs(y[:, ::2, ::4].numpy() - gold["step1_sub"]) / gold["increment_absmax"][:, None, None]).max() < 1e-4
     assert np.allclose(taps["encoder.vm"][::7].numpy(), gold["encoder_vm_sub"], atol=1e-4)
     assert np.allclose(taps["processor.vm"][::7].numpy(), gold["processor_vm_sub"], atol=1e-3)
-    assert torch.equal(y, O.forward(p, g, x0, x1, f, TINY))
+    assert torch.equal(y, O.forward(p, g, x0, x1, f))
+    # the product's graph (different node numbering and edge order) gives the same function
+    y2 = O.forward(p, build_graph(TINY.n_lat, TINY.n_lon, TINY.splits), x0, x1, f)
+    assert O.increment_rel_err(y2, y, x1).max().item() < 1e-4
 
 
 def test_spec():
