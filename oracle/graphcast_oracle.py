@@ -36,6 +36,16 @@ def mlp(p: dict, name: str, x: torch.Tensor) -> torch.Tensor:
     return y
 
 
+def edge_update(p: dict, name: str, e: torch.Tensor, v_send: torch.Tensor, v_recv: torch.Tensor, edges: torch.Tensor, chunk: int = 1 << 18) -> torch.Tensor:
+    """MLP(concat(edge latent, sender latent, receiver latent)), in row chunks so that the concatenated rows of the 3.1 M
+    mesh->grid edges (19 GB at once) never exist as one tensor."""
+    out = []
+    for i in range(0, len(edges), chunk):
+        s = slice(i, i + chunk)
+        out.append(mlp(p, name, torch.cat([e[s], v_send[edges[s, 0]], v_recv[edges[s, 1]]], dim=1)))
+    return torch.cat(out)
+
+
 def aggregate(e: torch.Tensor, receivers: torch.Tensor, n: int) -> torch.Tensor:
     return torch.zeros(n, e.shape[1], dtype=e.dtype).index_add_(0, receivers, e)
 
@@ -54,20 +64,20 @@ def forward(p: dict, graph, x_prev: torch.Tensor, x_cur: torch.Tensor, forcing: 
     e2 = mlp(p, "embed.m2g_edge", t(graph.m2g_edge_feat))
     g2m, me, m2g = t(graph.g2m_edges), t(graph.mesh_edges), t(graph.m2g_edges)
     # encoder: grid -> mesh
-    e1 = mlp(p, "g2m.edge", torch.cat([e1, vg[g2m[:, 0]], vm[g2m[:, 1]]], dim=1))
+    e1 = edge_update(p, "g2m.edge", e1, vg, vm, g2m)
     vm = vm + mlp(p, "g2m.mesh_node", torch.cat([vm, aggregate(e1, g2m[:, 1], graph.n_mesh)], dim=1))
     vg = vg + mlp(p, "g2m.grid_node", vg)
     if taps is not None:
         taps["encoder.vm"], taps["encoder.vg"] = vm, vg
     # processor
     for i in range(processor_steps(p)):
-        de = mlp(p, f"proc.{i}.edge", torch.cat([em, vm[me[:, 0]], vm[me[:, 1]]], dim=1))
+        de = edge_update(p, f"proc.{i}.edge", em, vm, vm, me)
         vm = vm + mlp(p, f"proc.{i}.node", torch.cat([vm, aggregate(de, me[:, 1], graph.n_mesh)], dim=1))
         em = em + de
     if taps is not None:
         taps["processor.vm"] = vm
     # decoder: mesh -> grid
-    e2 = mlp(p, "m2g.edge", torch.cat([e2, vm[m2g[:, 0]], vg[m2g[:, 1]]], dim=1))
+    e2 = edge_update(p, "m2g.edge", e2, vm, vg, m2g)
     vg = vg + mlp(p, "m2g.grid_node", torch.cat([vg, aggregate(e2, m2g[:, 1], graph.n_grid)], dim=1))
     out = mlp(p, "out", vg)                                                       # [n_grid][n_vars], normalised residual
     return x_cur + (out * p["norm.diff_std"][None, :]).T.reshape(x_cur.shape)

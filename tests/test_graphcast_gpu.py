@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 import torch
 
+from oracle import graphcast_graph as OG
 from oracle import graphcast_oracle as O
 from skyrim_amd.graphcast.spec import GraphcastConfig, forcings, init_synthetic, synthetic_states
 
@@ -27,13 +28,14 @@ def case(request):
     p = init_synthetic(cfg, 0)
     eng.load_params(p)
     x0, x1 = synthetic_states(cfg, 0)
+    eng.oracle_graph = OG.build(cfg.n_lat, cfg.n_lon, cfg.splits)       # the oracle's OWN graph construction (never eng.graph)
     return cfg, p, x0, x1, forcings(cfg, 1000.0), eng
 
 
 def test_step_vs_oracle(case):
     cfg, p, x0, x1, f, eng = case
     y = eng.step(x0.cuda(), x1.cuda(), f.cuda())
-    ref = O.forward(p, eng.graph, x0, x1, f, cfg)
+    ref = O.forward(p, eng.oracle_graph, x0, x1, f)
     assert torch.isfinite(y).all() and tuple(y.shape) == (cfg.n_vars, cfg.n_lat, cfg.n_lon)
     assert O.per_channel_rel_err(y.cpu(), ref).max().item() < 1e-5
     assert O.increment_rel_err(y.cpu(), ref, x1).max().item() < 1e-3
@@ -45,7 +47,7 @@ def test_rollout_and_determinism(case):
     for k in range(3):
         fk = forcings(cfg, 1000.0 + 6.0 * k)
         a, b = b, eng.step(a, b, fk.cuda())
-        ra, rb = rb, O.forward(p, eng.graph, ra, rb, fk, cfg)
+        ra, rb = rb, O.forward(p, eng.oracle_graph, ra, rb, fk)
     assert O.per_channel_rel_err(b.cpu(), rb).max().item() < 1e-5
     y1, y2 = eng.step(x0.cuda(), x1.cuda(), f.cuda()), eng.step(x0.cuda(), x1.cuda(), f.cuda())
     assert torch.equal(y1, y2)
@@ -76,7 +78,7 @@ def test_latent_512_uses_the_fused_linear_layer_norm_kernel():
     x0, x1 = synthetic_states(cfg, 0)
     f = forcings(cfg, 1000.0)
     y = eng.step(x0.cuda(), x1.cuda(), f.cuda())
-    ref = O.forward(p, eng.graph, x0, x1, f, cfg)
+    ref = O.forward(p, OG.build(cfg.n_lat, cfg.n_lon, cfg.splits), x0, x1, f)
     assert O.per_channel_rel_err(y.cpu(), ref).max().item() < 1e-5 and O.increment_rel_err(y.cpu(), ref, x1).max().item() < 1e-3
 
 
@@ -201,3 +203,49 @@ def test_reference_api_forecast_on_the_graphcast_engine():
     assert np.array_equal(da.sel(channel=generic.channel.values.tolist()).values, generic.values)
     pred, _ = model.rollout(t0, n_steps=2, save=False)
     assert pred.lat.values[0] == -90.0 and np.array_equal(pred.values[1, :, ::-1], da.values[2])
+
+
+# ---- BASELINE configs[3]: GraphCast at its real size, and a 10-day (40-step) rollout ------------------------------------------- #
+@pytest.mark.timeout(1800)
+def test_full_size_step_vs_oracle_per_channel():
+    """721x1440x83, M6 multi-mesh, latent 512, 16 processor layers (GraphcastConfig()) against the CPU oracle on the ORACLE's own
+    graph: per channel against max|x(t+6h)| and against the size of the predicted increment."""
+    from skyrim_amd.graphcast.engine import GraphcastEngine
+    cfg = GraphcastConfig()
+    assert (cfg.n_lat, cfg.n_lon, cfg.splits, cfg.latent, cfg.steps, cfg.n_vars) == (721, 1440, 6, 512, 16, 83)
+    eng = GraphcastEngine(cfg, "cuda:0")
+    p = init_synthetic(cfg, 0)
+    eng.load_params(p)
+    x0, x1 = synthetic_states(cfg, 0)
+    f = forcings(cfg, 1000.0)
+    y = eng.step(x0.cuda(), x1.cuda(), f.cuda())
+    assert torch.isfinite(y).all()
+    y = y.cpu()
+    del eng
+    torch.cuda.empty_cache()
+    with torch.no_grad():
+        ref = O.forward(p, OG.build(cfg.n_lat, cfg.n_lon, cfg.splits), x0, x1, f)
+    assert O.per_channel_rel_err(y, ref).max().item() < 1e-5
+    assert O.increment_rel_err(y, ref, x1).max().item() < 1e-3
+
+
+@pytest.mark.timeout(1500)
+def test_ten_day_rollout_stays_inside_the_bar():
+    """configs[3] is a 10-day rollout = 40 autoregressive steps with two history levels (61x120 grid, M3 mesh, latent 64, 4 layers):
+    engine and oracle each feed their own outputs back, the error is asserted at every step."""
+    from skyrim_amd.graphcast.engine import GraphcastEngine
+    cfg = GraphcastConfig(n_lat=61, n_lon=120, splits=3, latent=64, steps=4)
+    eng = GraphcastEngine(cfg, "cuda:0")
+    p = init_synthetic(cfg, 0)
+    eng.load_params(p)
+    og = OG.build(cfg.n_lat, cfg.n_lon, cfg.splits)
+    x0, x1 = synthetic_states(cfg, 0)
+    a, b, ra, rb, worst = x0.cuda(), x1.cuda(), x0, x1, 0.0
+    for k in range(40):
+        fk = forcings(cfg, 1000.0 + 6.0 * k)
+        a, b = b, eng.step(a, b, fk.cuda())
+        ra, rb = rb, O.forward(p, og, ra, rb, fk)
+        e = O.per_channel_rel_err(b.cpu(), rb).max().item()
+        worst = max(worst, e)
+        assert e < 1e-3, (k, e)
+    assert torch.isfinite(b).all() and worst < 1e-4, worst

@@ -154,3 +154,43 @@ def test_reference_api_forecast_on_the_sfno_engine():
     x0 = torch.from_numpy(np.ascontiguousarray(da.values[0]))
     want = O.forward(params, O.forward(params, x0, cfg), cfg)
     assert O.per_channel_rel_err(torch.from_numpy(np.ascontiguousarray(da.values[2])), want).max().item() < 3e-4
+
+
+# ---- BASELINE configs[2]: FourCastNet-v2 (SFNO) at its real size, and a 10-day (40-step) rollout ---------------------------- #
+@pytest.mark.timeout(1500)
+def test_full_size_step_vs_oracle_per_channel():
+    """721x1440x73, embed 256, 8 layers, scale factor 3 (the production hyper-parameters of SfnoConfig()) against the CPU oracle,
+    per channel; plus one autoregressive step more on the engine's own output (finite, bounded)."""
+    from skyrim_amd.sfno.engine import SfnoEngine
+    cfg = SfnoConfig()
+    assert (cfg.n_lat, cfg.n_lon, cfg.in_chans, cfg.embed_dim, cfg.num_layers) == (721, 1440, 73, 256, 8)
+    params, x = init_synthetic(cfg, 0), synthetic_state(cfg, 0)
+    eng = SfnoEngine(cfg, "cuda:0")
+    eng.load_params(params)
+    y = eng.step(x.cuda())
+    y2 = eng.step(y)
+    with torch.no_grad():
+        ref = O.forward(params, x, cfg)
+    err = O.per_channel_rel_err(y.cpu(), ref)
+    assert torch.isfinite(y).all() and torch.isfinite(y2).all()
+    assert err.max().item() < 1e-4, err           # bar 1e-3; the 3-term GEMMs deliver ~1e-6 .. 1e-5
+
+
+@pytest.mark.timeout(1500)
+def test_ten_day_rollout_stays_inside_the_bar():
+    """configs[2] is a 10-day rollout = 40 autoregressive steps: engine and oracle each feed their own output back (97x192 grid,
+    scale factor 3, 4 layers); the per-channel error is asserted at every step, so fp16-split error growth would show."""
+    from skyrim_amd.sfno.engine import SfnoEngine
+    cfg = SfnoConfig(n_lat=97, n_lon=192, in_chans=11, out_chans=11, embed_dim=40, num_layers=4, scale_factor=3)
+    params, x = init_synthetic(cfg, 0), synthetic_state(cfg, 0)
+    eng = SfnoEngine(cfg, "cuda:0")
+    eng.load_params(params)
+    tr = O.Transforms(cfg)
+    xs, xr, worst = x.cuda().clone(), x, 0.0
+    for k in range(40):
+        eng.step(xs, xs)
+        xr = O.forward(params, xr, cfg, tr=tr)
+        e = O.per_channel_rel_err(xs.cpu(), xr).max().item()
+        worst = max(worst, e)
+        assert e < 1e-3, (k, e)
+    assert torch.isfinite(xs).all() and worst < 5e-4, worst
