@@ -107,3 +107,45 @@ def test_sfno_library_exports_declared_symbols_and_rejects_bad_arguments():
     assert lib.sksfno_gemm_run(ctypes.byref(d), None) == -1                       # null pointers / zero sizes
     assert lib.sksfno_instance_norm(None, None, None, None, 4, 16, 1e-6, None) == -1
     assert lib.sksfno_prepare_weight(None, 1, 1, 4, 4, None, 0, 8, None) == -1
+
+
+@pytest.mark.parametrize("grid,n_lat,n_lon,lmax", [("equiangular", 33, 64, 16), ("legendre-gauss", 24, 48, 24), ("equiangular", 97, 192, 32)])
+def test_sht_pinned_against_scipy_spherical_harmonics(grid, n_lat, n_lon, lmax):
+    """An INDEPENDENT implementation pins the transform conventions: scipy.special's spherical harmonics (orthonormal, Condon-Shortley
+    phase) and associated Legendre functions.  (1) the oracle's / the product's Legendre tables equal sqrt((2l+1)/(4 pi) (l-m)!/(l+m)!)
+    P_l^m; (2) analysing a field built from scipy's Y_l^m returns exactly its coefficients (torch-harmonics' convention: the m >= 0
+    coefficients of a real field f = sum_l [c_l0 Y_l0 + 2 Re sum_{m>0} c_lm Y_lm]); (3) synthesis gives the field back."""
+    from scipy import special
+    mmax = min(n_lon // 2, lmax)
+    theta = (O.legendre_gauss(n_lat) if grid == "legendre-gauss" else O.clenshaw_curtis(n_lat))[0]
+    lon = np.arange(n_lon) * (2 * np.pi / n_lon)
+    # (1) Legendre tables
+    tab_o = O.legendre_ortho(mmax, lmax, theta)
+    from skyrim_amd.sfno.sht import legendre_functions
+    tab_p = legendre_functions(mmax, lmax, theta)
+    for m in range(mmax):
+        for l in range(m, lmax):
+            norm = math.sqrt((2 * l + 1) / (4 * math.pi) * math.exp(special.gammaln(l - m + 1) - special.gammaln(l + m + 1)))
+            want = norm * special.lpmv(m, l, np.cos(theta))
+            assert np.allclose(tab_o[m, l], want, atol=1e-11) and np.allclose(tab_p[m, l], want, atol=1e-11), (m, l)
+    # (2) + (3): a real field from scipy's complex harmonics, below the grid's exact-quadrature degree
+    lcut = lmax if grid == "legendre-gauss" else lmax // 2
+    gen = np.random.default_rng(4)
+    c = (gen.standard_normal((lmax, mmax)) + 1j * gen.standard_normal((lmax, mmax))) * (np.arange(lmax)[:, None] >= np.arange(mmax)[None, :])
+    c[lcut:] = 0
+    c[:, 0] = c[:, 0].real
+    sph = getattr(special, "sph_harm_y", None)
+    field = np.zeros((n_lat, n_lon))
+    for l in range(lcut):
+        for m in range(min(l, mmax - 1) + 1):
+            y = sph(l, m, theta[:, None], lon[None, :]) if sph is not None else special.sph_harm(m, l, lon[None, :], theta[:, None])
+            field += (c[l, m] * y).real * (1.0 if m == 0 else 2.0)
+    t = O.SHT(n_lat, n_lon, lmax, mmax, grid)
+    got = t.forward(torch.from_numpy(field))
+    assert np.abs(got.numpy() - c).max() < 1e-10
+    assert np.abs(t.inverse(torch.from_numpy(c)).numpy() - field).max() < 1e-10
+    # the product's GEMM matrices reproduce the same coefficients (fp32 tables: 1e-6)
+    m_ = ShtMatrices(n_lat, n_lon, lmax, mmax, grid)
+    f = field @ m_.dft.astype(np.float64).T                                                  # [lat][2m]
+    coef = np.einsum("km,mlk->lm", f[:, 0::2] + 1j * f[:, 1::2], m_.analysis.astype(np.float64))
+    assert np.abs(coef - c).max() < 2e-6 * np.abs(c).max()
