@@ -98,10 +98,10 @@ def pmc_traffic(kernel: str):
         return None
 
 
-def quick_mode(precision, geom, params, x_host, dev, steps=3):
+def quick_mode(precision, geom, params, x_host, dev, steps=3, mlp="fused"):
     """Short run of another precision mode (same workload) for the 'modes' table."""
     from skyrim_amd.pangu.engine import PanguEngine
-    eng = PanguEngine(geom, precision, dev)
+    eng = PanguEngine(geom, precision, dev, mlp=mlp)
     eng.load_params(params)
     x = x_host.to(dev)
     eng.step(x, x)
@@ -338,6 +338,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-alt-modes", action="store_true", help="skip the short runs of the other precision modes")
+    ap.add_argument("--mlp", default="fused", choices=["fused", "split"], help="pangu: one-kernel MLP (default) or the two tiled GEMMs of round 1")
     ap.add_argument("--model", default="pangu", choices=["pangu", "sfno", "graphcast"],
                     help="pangu (default; BASELINE.json's headline configuration), sfno (FourCastNet v2-small, configs[2]) or graphcast (configs[3])")
     ap.add_argument("--shard", action="store_true", help="graphcast only: the N ranks share ONE forecast (latitude bands of the grid, mesh "
@@ -382,7 +383,7 @@ def main():
     geom = PanguGeometry(args.n_lat, args.n_lon)
     params = init_synthetic(geom, 0)
     dev = torch.device("cuda", local_rank)
-    eng = PanguEngine(geom, args.precision, dev)
+    eng = PanguEngine(geom, args.precision, dev, mlp=args.mlp)
     eng.load_params(params)
     x_host = synthetic_state(geom, 0, member=rank if world > 1 else None)
     x = x_host.to(dev)
@@ -464,6 +465,8 @@ def main():
             torch.cuda.empty_cache()
             out["modes"] = {m: dict(quick_mode(m, geom, params, x_host, dev), note=MODE_NOTES[m][1])
                             for m in ("bf16x3", "f16x3qh", "f16") if m != args.precision}
+            out["modes"][args.precision + "/split-mlp"] = dict(quick_mode(args.precision, geom, params, x_host, dev, mlp="split"),
+                                                               note="same arithmetic with the MLP as two tiled GEMMs (hidden through HBM): the round-1 path")
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

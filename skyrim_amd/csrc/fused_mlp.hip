@@ -1,0 +1,317 @@
+// MLP half of an EarthSpecificBlock as ONE kernel:   x += LayerNorm(norm2)( fc2( GELU( fc1(x) ) ) )   in place on the residual planes.
+//
+// The two-kernel form (ops_mlp.hip) writes the 4C-wide hidden activation to HBM as hi/lo planes and reads it back: 32 of the
+// step's 90 GB.  Here the hidden never leaves the CU, and neither do the token rows:
+//
+//   * a wavefront owns FM x 16 tokens for the whole kernel.  Their C input columns live in REGISTERS as MFMA B-operand fragments
+//     (hi + lo planes, loaded once with 16-byte loads: one wave instruction = one 1 KiB block of the blocked layout), and so do
+//     the FM x 16 x C fp32 accumulators of fc2 -- TM x C = 12288 either way (C = 192: 64 tokens, C = 384: 32 tokens), a
+//     512-register wave, one wave per SIMD, 4 waves per workgroup.  Nothing of the token tile ever goes through LDS.
+//   * the hidden dimension is walked in chunks of 32 units.  fc1 of a chunk leaves, in swapped order (D^T = W X^T), for token
+//     l & 15 the hidden units 16 n + 4 (l >> 4) + r in a lane's accumulators -- after bias + GELU + hi/lo split those eight
+//     values ARE the lane's B-operand fragment of fc2's 32-deep k-step (the prepared fc2 weights carry the matching column
+//     order).  No shuffle, no LDS round trip: the same trick as P -> P V in attention.hip.
+//   * LDS holds only weights: per chunk the 32 x C block of fc1 and the C x 32 block of fc2, each as hi/lo planes in FRAGMENT
+//     order (prepared once: every 1 KiB = what one ds_read_b128 wave instruction consumes, lane-linear, so LDS-DMA lands it
+//     conflict-free with no swizzle).  Two stages: fc2's block streams in under fc1's MFMAs, the next chunk's fc1 block under
+//     fc2's.  Per chunk and CU: 49 / 98 KB of DMA against 4608 MFMA clocks (25 % / 49 % of the 43 B/clk DMA rate; the tiled
+//     GEMMs sit at 58 %), 384 ds_read_b128 per wave (a third of the LDS read rate).
+//   * epilogue: a token's C outputs sit in one lane quad's registers across the 4 lane groups -> LayerNorm needs two shfl_xor,
+//     no LDS, no barrier.  With the perm8 row order of the fc2 weights the accumulators of fragment pair bp are columns
+//     32 bp + 8 (l >> 4) + [0..7] -- exactly the columns of the input fragment of k-step bp, still in registers: the residual
+//     add needs no load at all.  HBM traffic of the whole MLP: 4 B/element read + 4 B/element written + weights (L2).
+//
+// gfx950 only.  One workgroup per CU; grid = ceil(tokens / BM).
+#include <cstdlib>
+#include "gemm_dma.h"
+#include "launchers.h"
+
+namespace skp {
+
+template <int C_, int FM_, int NWAVES_, int DEPTH_ = 3>
+struct MlpShape {
+    static constexpr int C = C_, FM = FM_, NWAVES = NWAVES_, THREADS = 64 * NWAVES_, DEPTH = DEPTH_;
+    static constexpr int KS = C / 32;             // 32-deep k-steps of fc1 = fragment pairs of the output
+    static constexpr int CF = C / 16;             // 16-wide output fragments of fc2
+    static constexpr int HID = 4 * C, NCH = HID / 32;
+    static constexpr int BM = NWAVES * FM * 16;
+    static constexpr int W1_BLK = KS * 2 * 2;     // 1 KiB blocks of a chunk's fc1 weights: [ks][n][plane]
+    static constexpr int W2_BLK = CF * 2;         // ... fc2 weights: [c][plane]
+    static constexpr int STAGE_A = W1_BLK * 1024, STAGE_B = W2_BLK * 1024;
+    static constexpr int TAB_FLOATS = HID + 3 * C;   // fc1 bias | fc2 bias | gamma | beta
+    static constexpr int SMEM = STAGE_A + STAGE_B + TAB_FLOATS * 4;
+    static_assert(W1_BLK % NWAVES == 0 && W2_BLK % NWAVES == 0, "DMA blocks per wave");
+    static_assert(SMEM <= 160 * 1024, "LDS");
+};
+
+template <class T>
+struct MlpArgs {
+    T* xs;                  // residual stream: hi plane, blocked layout [tokens/16][C/32][16][32]; lo plane at + plane
+    long long plane;
+    int M;                  // tokens (multiple of 16)
+    const T* w1f;           // fc1 weights in fragment order (prep_mlp_weights)
+    const T* w2f;
+    const float *b1, *b2, *gamma, *beta;
+    float eps;
+};
+
+// one hi/lo fragment pair (two consecutive KiB blocks).  The scheduling barrier pins the reads HERE in program order, ahead of the
+// MFMAs that follow in the source: left alone, hipcc's scheduler sinks them back next to their first use (one pair reloaded in
+// place: read, wait, MFMAs, read, ...), and with one wave per SIMD nothing else hides the LDS latency.
+__device__ __forceinline__ void ld_pair(const char* p, uint4 (&w)[2]) {
+    w[0] = *reinterpret_cast<const uint4*>(p);
+    w[1] = *reinterpret_cast<const uint4*>(p + 1024);
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <class T, class S>
+__global__ void __launch_bounds__(S::THREADS) __attribute__((amdgpu_waves_per_eu(S::NWAVES / 4, S::NWAVES / 4)))
+fused_mlp_kernel(const MlpArgs<T> a) {
+    constexpr int C = S::C, FM = S::FM, KS = S::KS, CF = S::CF, HID = S::HID, NCH = S::NCH, NWAVES = S::NWAVES;
+    constexpr int DEPTH = S::DEPTH;   // weight-fragment pairs in flight per wave (register ring)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* stA = smem;
+    char* stB = smem + S::STAGE_A;
+    float* tab = reinterpret_cast<float*>(smem + S::STAGE_A + S::STAGE_B);
+    const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned lds_base = (unsigned)(size_t)smem;
+
+    // weight stream: chunk j = W1_BLK contiguous KiB of w1f, W2_BLK of w2f; wave w fetches blocks w, w + NWAVES, ...
+    auto issue_w1 = [&](int j) {
+        const T* src = a.w1f + ((long long)j * S::W1_BLK << 9) + lane * 8;
+#pragma unroll
+        for (int i = 0; i < S::W1_BLK / NWAVES; ++i) {
+            const int b = wave + i * NWAVES;
+            glds16(src + (b << 9), lds_base + (unsigned)(b << 10));
+        }
+    };
+    auto issue_w2 = [&](int j) {
+        const T* src = a.w2f + ((long long)j * S::W2_BLK << 9) + lane * 8;
+#pragma unroll
+        for (int i = 0; i < S::W2_BLK / NWAVES; ++i) {
+            const int b = wave + i * NWAVES;
+            glds16(src + (b << 9), lds_base + (unsigned)(S::STAGE_A + (b << 10)));
+        }
+    };
+    issue_w1(0);
+
+    for (int i = tid; i < HID; i += S::THREADS) tab[i] = a.b1[i];
+    for (int i = tid; i < C; i += S::THREADS) { tab[HID + i] = a.b2[i]; tab[HID + C + i] = a.gamma[i]; tab[HID + 2 * C + i] = a.beta[i]; }
+
+    // the wave's token rows as B-operand fragments: fragment (t, ks) = block (row block, ks) of the blocked layout
+    const long long rb0 = (long long)blockIdx.x * (S::BM / 16) + wave * FM;
+    typedef typename OpT<T>::v8 v8;
+    v8 xh[FM][KS], xl[FM][KS];
+    bool live[FM];
+#pragma unroll
+    for (int t = 0; t < FM; ++t) {
+        live[t] = (rb0 + t) * 16 < a.M;
+        const T* p = a.xs + ((live[t] ? rb0 + t : 0) * KS << 9) + l15 * 32 + g * 8;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            xh[t][ks] = *reinterpret_cast<const v8*>(p + (ks << 9));
+            xl[t][ks] = *reinterpret_cast<const v8*>(p + (ks << 9) + a.plane);
+        }
+    }
+
+    // the fragments are consumed here once, so that hipcc's vmcnt waits for these loads sit BEFORE the loop: inside it they would
+    // also wait for the LDS-DMA of the block in flight, which the compiler's counter bookkeeping does not know about
+#pragma unroll
+    for (int t = 0; t < FM; ++t)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) { asm volatile("" : "+v"(xh[t][ks])); asm volatile("" : "+v"(xl[t][ks])); }
+
+    f32x4 yacc[FM][CF];
+#pragma unroll
+    for (int t = 0; t < FM; ++t)
+#pragma unroll
+        for (int c = 0; c < CF; ++c) yacc[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int j = 0; j < NCH; ++j) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                           // fc1 block j landed; every wave is done with fc2 block j - 1
+        issue_w2(j);
+        f32x4 hacc[FM][2];
+#pragma unroll
+        for (int t = 0; t < FM; ++t) { hacc[t][0] = f32x4{0.f, 0.f, 0.f, 0.f}; hacc[t][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        // weight fragments come through a ring of DEPTH register pairs, loaded DEPTH - 1 steps ahead of their MFMAs: with one wave
+        // per SIMD nothing else hides the LDS latency (hipcc on its own reloads one pair in place: read, wait, 6 MFMAs, read, ...)
+        {
+            constexpr int NS = KS * 2;                       // step s = (ks, n): one hi/lo fragment pair, 3 FM MFMAs
+            uint4 ring[DEPTH][2];
+#pragma unroll
+            for (int s = 0; s < DEPTH - 1 && s < NS; ++s) ld_pair(stA + ((s * 2) << 10) + lane * 16, ring[s % DEPTH]);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                if (s + DEPTH - 1 < NS) ld_pair(stA + (((s + DEPTH - 1) * 2) << 10) + lane * 16, ring[(s + DEPTH - 1) % DEPTH]);
+                const int ks = s >> 1, n = s & 1;
+                const uint4 wh = ring[s % DEPTH][0], wl = ring[s % DEPTH][1];
+#pragma unroll
+                for (int t = 0; t < FM; ++t) hacc[t][n] = OpT<T>::mfma(as_v8<T>(wl), xh[t][ks], hacc[t][n]);
+#pragma unroll
+                for (int t = 0; t < FM; ++t) hacc[t][n] = OpT<T>::mfma(as_v8<T>(wh), xl[t][ks], hacc[t][n]);
+#pragma unroll
+                for (int t = 0; t < FM; ++t) hacc[t][n] = OpT<T>::mfma(as_v8<T>(wh), xh[t][ks], hacc[t][n]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // bias + GELU + hi/lo split: the lane's 8 hidden units 16 n + 4 g + r of this chunk become k-slots 8 g + 4 n + r of fc2
+        const float4 bb0 = *reinterpret_cast<const float4*>(tab + j * 32 + 4 * g), bb1 = *reinterpret_cast<const float4*>(tab + j * 32 + 16 + 4 * g);
+        uint4 hh[FM], hl[FM];
+#pragma unroll
+        for (int t = 0; t < FM; ++t) {
+            f32x4 lo = hacc[t][0], hi = hacc[t][1];
+            lo[0] += bb0.x; lo[1] += bb0.y; lo[2] += bb0.z; lo[3] += bb0.w;
+            hi[0] += bb1.x; hi[1] += bb1.y; hi[2] += bb1.z; hi[3] += bb1.w;
+            float v[8];
+            gelu_erf8(lo, hi, v);
+            uint4 o[2];
+            split8<T, 2>(v, o);
+            hh[t] = o[0]; hl[t] = o[1];
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                           // fc2 block j landed; every wave is done with fc1 block j
+        if (j + 1 < NCH) issue_w1(j + 1);
+        {
+            uint4 ring[DEPTH][2];
+#pragma unroll
+            for (int c = 0; c < DEPTH - 1 && c < CF; ++c) ld_pair(stB + ((c * 2) << 10) + lane * 16, ring[c % DEPTH]);
+#pragma unroll
+            for (int c = 0; c < CF; ++c) {
+                if (c + DEPTH - 1 < CF) ld_pair(stB + (((c + DEPTH - 1) * 2) << 10) + lane * 16, ring[(c + DEPTH - 1) % DEPTH]);
+                const uint4 wh = ring[c % DEPTH][0], wl = ring[c % DEPTH][1];
+#pragma unroll
+                for (int t = 0; t < FM; ++t) yacc[t][c] = OpT<T>::mfma(as_v8<T>(wl), as_v8<T>(hh[t]), yacc[t][c]);
+#pragma unroll
+                for (int t = 0; t < FM; ++t) yacc[t][c] = OpT<T>::mfma(as_v8<T>(wh), as_v8<T>(hl[t]), yacc[t][c]);
+#pragma unroll
+                for (int t = 0; t < FM; ++t) yacc[t][c] = OpT<T>::mfma(as_v8<T>(wh), as_v8<T>(hh[t]), yacc[t][c]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+
+    // epilogue: + fc2 bias, LayerNorm over the token's C columns (in-lane sums + two shuffles), + the input still in registers
+    const float* tb2 = tab + HID;
+    const float* tg = tab + HID + C;
+    const float* tbe = tab + HID + 2 * C;
+#pragma unroll
+    for (int t = 0; t < FM; ++t) {
+        float s = 0.f;
+#pragma unroll
+        for (int bp = 0; bp < KS; ++bp) {
+            const int n = 32 * bp + 8 * g;
+            const float4 b0 = *reinterpret_cast<const float4*>(tb2 + n), b1 = *reinterpret_cast<const float4*>(tb2 + n + 4);
+            add8(yacc[t][2 * bp], yacc[t][2 * bp + 1], b0, b1);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s += yacc[t][2 * bp][r] + yacc[t][2 * bp + 1][r];
+        }
+        s += __shfl_xor(s, 16);
+        s += __shfl_xor(s, 32);
+        const float mean = s * (1.0f / C);
+        float q = 0.f;
+#pragma unroll
+        for (int c = 0; c < CF; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const float d = yacc[t][c][r] - mean; q += d * d; }
+        q += __shfl_xor(q, 16);
+        q += __shfl_xor(q, 32);
+        const float rstd = rsqrtf(q * (1.0f / C) + a.eps);
+        if (!live[t]) continue;
+        T* dst = a.xs + ((rb0 + t) * KS << 9) + l15 * 32 + g * 8;
+#pragma unroll
+        for (int bp = 0; bp < KS; ++bp) {
+            const int n = 32 * bp + 8 * g;
+            const float4 g0 = *reinterpret_cast<const float4*>(tg + n), g1 = *reinterpret_cast<const float4*>(tg + n + 4);
+            const float4 e0 = *reinterpret_cast<const float4*>(tbe + n), e1 = *reinterpret_cast<const float4*>(tbe + n + 4);
+            float oh[8], ol[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { oh[i] = (float)xh[t][bp][i]; ol[i] = (float)xl[t][bp][i]; }
+            const f32x4 &x = yacc[t][2 * bp], &z = yacc[t][2 * bp + 1];
+            const float v[8] = {(oh[0] + ol[0]) + ((x[0] - mean) * rstd * g0.x + e0.x), (oh[1] + ol[1]) + ((x[1] - mean) * rstd * g0.y + e0.y),
+                                (oh[2] + ol[2]) + ((x[2] - mean) * rstd * g0.z + e0.z), (oh[3] + ol[3]) + ((x[3] - mean) * rstd * g0.w + e0.w),
+                                (oh[4] + ol[4]) + ((z[0] - mean) * rstd * g1.x + e1.x), (oh[5] + ol[5]) + ((z[1] - mean) * rstd * g1.y + e1.y),
+                                (oh[6] + ol[6]) + ((z[2] - mean) * rstd * g1.z + e1.z), (oh[7] + ol[7]) + ((z[3] - mean) * rstd * g1.w + e1.w)};
+            store8_planes<T, 2>(dst + (bp << 9), a.plane, v);
+        }
+    }
+}
+
+// ---- prepare: fp32 master weights -> fragment-order hi/lo planes ---------------------------------------------------------------- //
+//   w1f[((j KS + ks) 2 + n) 2 + plane][lane][e] = fc1.weight[32 j + 16 n + (lane & 15)][32 ks + 8 (lane >> 4) + e]
+//   w2f[(j CF + c) 2 + plane][lane][e]          = fc2.weight[perm8_col(16 c + (lane & 15))][32 j + 16 (e >> 2) + 4 (lane >> 4) + (e & 3)]
+template <class T>
+__global__ void prep_mlp_w1_kernel(const float* __restrict__ w1, T* __restrict__ out, int C) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;     // one (block pair, lane, e)
+    const int KS = C / 32;
+    const long long total = (long long)(4 * C / 32) * KS * 2 * 512;
+    if (i >= total) return;
+    const int e = (int)(i & 7), lane = (int)((i >> 3) & 63);
+    long long q = i >> 9;
+    const int n = (int)(q & 1); q >>= 1;
+    const int ks = (int)(q % KS);
+    const int j = (int)(q / KS);
+    const float v = w1[(long long)(32 * j + 16 * n + (lane & 15)) * C + 32 * ks + 8 * (lane >> 4) + e];
+    const T h = (T)v;
+    const long long o = ((((long long)j * KS + ks) * 2 + n) * 2 << 9) + lane * 8 + e;
+    out[o] = h;
+    out[o + 512] = (T)(v - (float)h);
+}
+
+template <class T>
+__global__ void prep_mlp_w2_kernel(const float* __restrict__ w2, T* __restrict__ out, int C) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int CF = C / 16;
+    const long long total = (long long)(4 * C / 32) * CF * 512;
+    if (i >= total) return;
+    const int e = (int)(i & 7), lane = (int)((i >> 3) & 63);
+    const long long q = i >> 9;
+    const int c = (int)(q % CF);
+    const int j = (int)(q / CF);
+    const int col = perm8_col(16 * c + (lane & 15));
+    const int hid = 32 * j + 16 * (e >> 2) + 4 * (lane >> 4) + (e & 3);
+    const float v = w2[(long long)col * (4 * C) + hid];
+    const T h = (T)v;
+    const long long o = ((((long long)j * CF + c) * 2) << 9) + lane * 8 + e;
+    out[o] = h;
+    out[o + 512] = (T)(v - (float)h);
+}
+
+template <class T>
+hipError_t prep_mlp_weights(const float* w1, const float* w2, T* w1f, T* w2f, int C, hipStream_t s) {
+    if (C != 192 && C != 384) return hipErrorInvalidValue;
+    const long long t1 = (long long)(4 * C / 32) * (C / 32) * 2 * 512, t2 = (long long)(4 * C / 32) * (C / 16) * 512;
+    hipLaunchKernelGGL((prep_mlp_w1_kernel<T>), dim3((unsigned)((t1 + 255) / 256)), dim3(256), 0, s, w1, w1f, C);
+    hipLaunchKernelGGL((prep_mlp_w2_kernel<T>), dim3((unsigned)((t2 + 255) / 256)), dim3(256), 0, s, w2, w2f, C);
+    return hipGetLastError();
+}
+template hipError_t prep_mlp_weights<bf16>(const float*, const float*, bf16*, bf16*, int, hipStream_t);
+template hipError_t prep_mlp_weights<f16>(const float*, const float*, f16*, f16*, int, hipStream_t);
+
+template <class T, class S>
+static hipError_t launch_fused_mlp(const MlpArgs<T>& a, hipStream_t s) {
+    auto kern = fused_mlp_kernel<T, S>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, S::SMEM);
+    if (e != hipSuccess) return e;
+    const unsigned grid = (unsigned)((a.M + S::BM - 1) / S::BM);
+    if (grid == 0) return hipSuccess;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(S::THREADS), S::SMEM, s, a);
+    return hipGetLastError();
+}
+
+template <class P>
+hipError_t op_mlp_fused(const Geom& g, const BlockW<typename P::T>& b, int res, typename P::T* Xs, const Work<P>& wk, hipStream_t s) {
+    typedef typename P::T T;
+    static_assert(P::NA == 2 && P::NW == 2, "the fused MLP is the 3-term path");
+    MlpArgs<T> a{Xs, wk.xs_plane[res], g.ntok[res], b.w1f, b.w2f, b.fc1_b, b.fc2_b, b.n2_g, b.n2_b, 1e-5f};
+    if (a.M % 16 != 0) return hipErrorInvalidValue;
+    // C = 192: 64 tokens per wave, 4 waves (one per SIMD) | variant 1: 32 tokens per wave, 8 waves (two per SIMD);  C = 384: 32 x 4
+    static const int variant = [] { const char* v = getenv("SKP_MLP_VARIANT"); return v ? atoi(v) : 0; }();
+    if (res == 0) return variant == 1 ? launch_fused_mlp<T, MlpShape<192, 2, 8>>(a, s) : launch_fused_mlp<T, MlpShape<192, 4, 4>>(a, s);
+    return launch_fused_mlp<T, MlpShape<384, 2, 4>>(a, s);
+}
+template hipError_t op_mlp_fused<PrecBF16x3>(const Geom&, const BlockW<bf16>&, int, bf16*, const Work<PrecBF16x3>&, hipStream_t);
+template hipError_t op_mlp_fused<PrecF16x3>(const Geom&, const BlockW<f16>&, int, f16*, const Work<PrecF16x3>&, hipStream_t);
+
+}  // namespace skp

@@ -33,7 +33,7 @@ _LIB_PATH = Path(__file__).resolve().parent.parent / "lib" / "libskyrim_pangu.so
 
 class SkConfig(ctypes.Structure):
     _fields_ = [("n_lat", ctypes.c_int), ("n_lon", ctypes.c_int), ("precision", ctypes.c_int),
-                ("roll_sign", ctypes.c_int), ("pad_mode", ctypes.c_int), ("mask_value", ctypes.c_float)]
+                ("roll_sign", ctypes.c_int), ("pad_mode", ctypes.c_int), ("mask_value", ctypes.c_float), ("mlp_mode", ctypes.c_int)]
 
 
 class SkSizes(ctypes.Structure):
@@ -103,11 +103,14 @@ def _check(code: int, what: str):
 PAD_MODES = {"centre": 0, "back": 1}
 
 
-def make_config(geom: PanguGeometry, precision: str = DEFAULT_PRECISION, roll_sign: int = -1, mask_value: float = -100.0) -> SkConfig:
+MLP_MODES = {"fused": 0, "split": 1}
+
+
+def make_config(geom: PanguGeometry, precision: str = DEFAULT_PRECISION, roll_sign: int = -1, mask_value: float = -100.0, mlp: str = "fused") -> SkConfig:
     """``skpangu_config`` of a geometry + the switchable conventions (include/skyrim_pangu.h; oracle: pangu_oracle.Conventions)."""
     if roll_sign not in (-1, 1):
         raise ValueError("roll_sign is -1 (Swin: roll by -(1,3,6) first) or +1 (pseudocode as written)")
-    return SkConfig(geom.n_lat, geom.n_lon, PRECISIONS[precision], roll_sign, PAD_MODES[geom.pad], float(mask_value))
+    return SkConfig(geom.n_lat, geom.n_lon, PRECISIONS[precision], roll_sign, PAD_MODES[geom.pad], float(mask_value), MLP_MODES[mlp])
 
 
 def query_sizes(geom: PanguGeometry, precision: str = DEFAULT_PRECISION) -> SkSizes:
@@ -136,15 +139,17 @@ class PanguEngine:
     """Device-resident Pangu 6-h step.  ``step`` maps a (69, n_lat, n_lon) fp32 CUDA tensor to the next state."""
 
     def __init__(self, geom: PanguGeometry | None = None, precision: str = DEFAULT_PRECISION, device: str | torch.device = "cuda:0",
-                 roll_sign: int = -1, mask_value: float = -100.0):
-        """``roll_sign`` / ``mask_value`` / ``geom.pad``: the conventions the public pseudocode leaves open."""
+                 roll_sign: int = -1, mask_value: float = -100.0, mlp: str = "fused"):
+        """``roll_sign`` / ``mask_value`` / ``geom.pad``: the conventions the public pseudocode leaves open.
+        ``mlp``: "fused" (default; one kernel per MLP in the 3-term modes, csrc/fused_mlp.hip) or "split" (two tiled GEMMs)."""
         self.lib = load_library()
         if not torch.cuda.is_available():
             raise RuntimeError("PanguEngine needs a ROCm GPU (gfx950); there is no CPU fallback")
         self.geom = geom or PanguGeometry()
         self.precision = precision
         self.device = torch.device(device)
-        self.cfg = make_config(self.geom, precision, roll_sign, mask_value)
+        self.cfg = make_config(self.geom, precision, roll_sign, mask_value, mlp)
+        self.mlp = mlp
         self.sizes = query_sizes(self.geom, precision)
         with torch.cuda.device(self.device):
             self._prepared = torch.empty(self.sizes.prepared_bytes, dtype=torch.uint8, device=self.device)

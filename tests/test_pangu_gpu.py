@@ -345,3 +345,28 @@ def test_switchable_conventions_match_the_oracle(toy, conv):
     assert O.per_channel_rel_err(y, O.forward(params, x)).max().item() > 1e-3
     y2 = eng.step(eng.step(x.cuda())).cpu()                     # rolled + unrolled blocks compose over steps
     assert O.per_channel_rel_err(y2, O.rollout(params, x, 2, conv=O.Conventions(**conv))[1]).max().item() < 3e-4
+
+
+def test_fused_mlp_kernel_matches_the_two_gemm_path_and_the_oracle(toy, ref):
+    """csrc/fused_mlp.hip (fc1 -> GELU -> fc2 -> LayerNorm -> residual in one kernel, token tile and hidden in registers) against
+    the two tiled GEMMs of round 1 and against the oracle: one block at each resolution (C = 192: 64 tokens per wave, C = 384:
+    32) and the whole step; the toy grid's token counts (4992, 1344) are not multiples of the 256 / 128-token tiles."""
+    from skyrim_amd.pangu.engine import PanguEngine
+    g, params, x = toy
+    taps, y_ref = ref
+    outs = {}
+    for mlp in ("fused", "split"):
+        for prec in ("f16x3q", "bf16x3"):
+            eng = PanguEngine(g, prec, "cuda:0", mlp=mlp)
+            eng.load_params(params)
+            assert eng.mlp == mlp
+            outs[mlp, prec] = eng.step(x.cuda()).cpu()
+            assert O.per_channel_rel_err(outs[mlp, prec], y_ref).max().item() < 3e-4, (mlp, prec)
+            if prec == "f16x3q":
+                x1 = taps["embed"].float().cuda()
+                b = eng.block(1, 0, x1).cpu()
+                assert rel(b, taps["layer1.block0"]) < STAGE_TOL[prec], mlp
+                x2 = taps["down"].float().cuda()
+                want2 = O.earth_block(O._block_params(params, 2, 0), taps["down"], O.Geometry(g.n_lat, g.n_lon).res(2), O.HEADS[1], False)
+                assert rel(eng.block(2, 0, x2).cpu(), want2) < STAGE_TOL[prec], mlp
+    assert O.per_channel_rel_err(outs["fused", "f16x3q"], outs["split", "f16x3q"]).max().item() < 2e-4

@@ -177,20 +177,34 @@ def test_full_size_step_vs_oracle_per_channel():
 
 
 @pytest.mark.timeout(1500)
-def test_ten_day_rollout_stays_inside_the_bar():
-    """configs[2] is a 10-day rollout = 40 autoregressive steps: engine and oracle each feed their own output back (97x192 grid,
-    scale factor 3, 4 layers); the per-channel error is asserted at every step, so fp16-split error growth would show."""
+def test_ten_day_rollout_error_growth_is_the_networks_own():
+    """configs[2] is a 10-day rollout = 40 autoregressive steps (97x192 grid, scale factor 3, 4 layers).  Two statements:
+    (a) STEP parity along the whole trajectory: fed the oracle's state k, the engine's step k + 1 is inside 1e-4 at every k;
+    (b) FREE-RUNNING: a random-weight SFNO amplifies any perturbation by ~1.6x per step (measured: the fp32 oracle itself drifts
+        from the fp64 oracle at that rate), so the free-running difference is held against that yardstick -- the engine's drift
+        from the fp64 trajectory grows no faster than the fp32 CPU oracle's own, and stays within 30x of it (its per-step rounding
+        is ~10x fp32's: three fp16-pair MFMA terms carry 22 bits against fp32's 24)."""
     from skyrim_amd.sfno.engine import SfnoEngine
     cfg = SfnoConfig(n_lat=97, n_lon=192, in_chans=11, out_chans=11, embed_dim=40, num_layers=4, scale_factor=3)
     params, x = init_synthetic(cfg, 0), synthetic_state(cfg, 0)
+    p64 = {k: v.double() for k, v in params.items()}
     eng = SfnoEngine(cfg, "cuda:0")
     eng.load_params(params)
     tr = O.Transforms(cfg)
-    xs, xr, worst = x.cuda().clone(), x, 0.0
+    xs, r32, r64 = x.cuda().clone(), x, x.double()
+    drift_eng, drift_f32, step_err = [], [], []
     for k in range(40):
-        eng.step(xs, xs)
-        xr = O.forward(params, xr, cfg, tr=tr)
-        e = O.per_channel_rel_err(xs.cpu(), xr).max().item()
-        worst = max(worst, e)
-        assert e < 1e-3, (k, e)
-    assert torch.isfinite(xs).all() and worst < 5e-4, worst
+        fed = eng.step(r32.cuda()).cpu()                          # (a) same input as the oracle's step k + 1
+        eng.step(xs, xs)                                          # (b) the engine's own trajectory, in place
+        r32_next = O.forward(params, r32, cfg, tr=tr)
+        r64 = O.forward(p64, r64, cfg, tr=tr)
+        step_err.append(O.per_channel_rel_err(fed, r32_next).max().item())
+        r32 = r32_next
+        drift_eng.append(O.per_channel_rel_err(xs.cpu(), r64).max().item())
+        drift_f32.append(O.per_channel_rel_err(r32, r64).max().item())
+    assert torch.isfinite(xs).all()
+    assert max(step_err) < 1e-4, step_err
+    for k in range(40):
+        assert drift_eng[k] < max(1e-4, 30.0 * drift_f32[k]), (k, drift_eng[k], drift_f32[k])
+    growth_eng, growth_f32 = drift_eng[20] / drift_eng[5], drift_f32[20] / drift_f32[5]
+    assert growth_eng < 3.0 * growth_f32, (growth_eng, growth_f32)
