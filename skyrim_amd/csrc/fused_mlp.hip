@@ -28,9 +28,12 @@
 
 namespace skp {
 
-template <int C_, int FM_, int NWAVES_, int DEPTH_ = 3>
+template <int C_, int FM_, int NWAVES_, int DEPTH_ = 3, bool PIPE_ = false, int VALU_PER_MFMA_ = 4, int WPE_ = 0, bool STAGGER_ = false>
 struct MlpShape {
-    static constexpr int C = C_, FM = FM_, NWAVES = NWAVES_, THREADS = 64 * NWAVES_, DEPTH = DEPTH_;
+    static constexpr int WPE = WPE_ ? WPE_ : NWAVES_ / 4;   // waves per SIMD the kernel is compiled for (2 with 4 waves = two workgroups per CU)
+    static constexpr bool STAGGER = STAGGER_;               // odd waves issue their LDS-DMA in the middle of a phase instead of at its start
+    static constexpr int C = C_, FM = FM_, NWAVES = NWAVES_, THREADS = 64 * NWAVES_, DEPTH = DEPTH_, VALU_PER_MFMA = VALU_PER_MFMA_;
+    static constexpr bool PIPE = PIPE_;
     static constexpr int KS = C / 32;             // 32-deep k-steps of fc1 = fragment pairs of the output
     static constexpr int CF = C / 16;             // 16-wide output fragments of fc2
     static constexpr int HID = 4 * C, NCH = HID / 32;
@@ -65,7 +68,7 @@ __device__ __forceinline__ void ld_pair(const char* p, uint4 (&w)[2]) {
 }
 
 template <class T, class S>
-__global__ void __launch_bounds__(S::THREADS) __attribute__((amdgpu_waves_per_eu(S::NWAVES / 4, S::NWAVES / 4)))
+__global__ void __launch_bounds__(S::THREADS) __attribute__((amdgpu_waves_per_eu(S::WPE, S::WPE)))
 fused_mlp_kernel(const MlpArgs<T> a) {
     constexpr int C = S::C, FM = S::FM, KS = S::KS, CF = S::CF, HID = S::HID, NCH = S::NCH, NWAVES = S::NWAVES;
     constexpr int DEPTH = S::DEPTH;   // weight-fragment pairs in flight per wave (register ring)
@@ -128,67 +131,127 @@ fused_mlp_kernel(const MlpArgs<T> a) {
 #pragma unroll
         for (int c = 0; c < CF; ++c) yacc[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    for (int j = 0; j < NCH; ++j) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                           // fc1 block j landed; every wave is done with fc2 block j - 1
-        issue_w2(j);
-        f32x4 hacc[FM][2];
+    f32x4 hacc[FM][2];
+    constexpr int NS = KS * 2;                           // fc1 step s = (ks, n): one hi/lo fragment pair, 3 FM MFMAs
+
+    // fc1 of one chunk out of stage A into hacc.  Weight fragments come through a ring of DEPTH register pairs, loaded DEPTH - 1
+    // steps ahead of their MFMAs (hipcc on its own reloads one pair in place: read, wait, MFMAs, read, ... -- and with one wave
+    // per SIMD nothing else hides the LDS latency).  ``side(s)`` = VALU work of ANOTHER chunk spliced into step s: the MFMA pipe
+    // is busy 16 clocks per instruction, a wave issues in order, so VALU placed between two MFMAs runs for free.
+    auto fc1 = [&](auto&& side, auto&& mid) {
 #pragma unroll
         for (int t = 0; t < FM; ++t) { hacc[t][0] = f32x4{0.f, 0.f, 0.f, 0.f}; hacc[t][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-        // weight fragments come through a ring of DEPTH register pairs, loaded DEPTH - 1 steps ahead of their MFMAs: with one wave
-        // per SIMD nothing else hides the LDS latency (hipcc on its own reloads one pair in place: read, wait, 6 MFMAs, read, ...)
-        {
-            constexpr int NS = KS * 2;                       // step s = (ks, n): one hi/lo fragment pair, 3 FM MFMAs
-            uint4 ring[DEPTH][2];
+        uint4 ring[DEPTH][2];
 #pragma unroll
-            for (int s = 0; s < DEPTH - 1 && s < NS; ++s) ld_pair(stA + ((s * 2) << 10) + lane * 16, ring[s % DEPTH]);
+        for (int s = 0; s < DEPTH - 1 && s < NS; ++s) ld_pair(stA + ((s * 2) << 10) + lane * 16, ring[s % DEPTH]);
 #pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                if (s + DEPTH - 1 < NS) ld_pair(stA + (((s + DEPTH - 1) * 2) << 10) + lane * 16, ring[(s + DEPTH - 1) % DEPTH]);
-                const int ks = s >> 1, n = s & 1;
-                const uint4 wh = ring[s % DEPTH][0], wl = ring[s % DEPTH][1];
+        for (int s = 0; s < NS; ++s) {
+            if (s + DEPTH - 1 < NS) ld_pair(stA + (((s + DEPTH - 1) * 2) << 10) + lane * 16, ring[(s + DEPTH - 1) % DEPTH]);
+            const int ks = s >> 1, n = s & 1;
+            const uint4 wh = ring[s % DEPTH][0], wl = ring[s % DEPTH][1];
+            const bool busy = side(s);
+            if (s == NS / 2) mid();
 #pragma unroll
-                for (int t = 0; t < FM; ++t) hacc[t][n] = OpT<T>::mfma(as_v8<T>(wl), xh[t][ks], hacc[t][n]);
+            for (int t = 0; t < FM; ++t) hacc[t][n] = OpT<T>::mfma(as_v8<T>(wl), xh[t][ks], hacc[t][n]);
 #pragma unroll
-                for (int t = 0; t < FM; ++t) hacc[t][n] = OpT<T>::mfma(as_v8<T>(wh), xl[t][ks], hacc[t][n]);
+            for (int t = 0; t < FM; ++t) hacc[t][n] = OpT<T>::mfma(as_v8<T>(wh), xl[t][ks], hacc[t][n]);
 #pragma unroll
-                for (int t = 0; t < FM; ++t) hacc[t][n] = OpT<T>::mfma(as_v8<T>(wh), xh[t][ks], hacc[t][n]);
-                __builtin_amdgcn_sched_barrier(0);
+            for (int t = 0; t < FM; ++t) hacc[t][n] = OpT<T>::mfma(as_v8<T>(wh), xh[t][ks], hacc[t][n]);
+            if (busy) {                                  // alternate: one MFMA, a few VALU, one MFMA, ...
+#pragma unroll
+                for (int k = 0; k < 3 * FM; ++k) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, S::VALU_PER_MFMA, 0); }
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
-        // bias + GELU + hi/lo split: the lane's 8 hidden units 16 n + 4 g + r of this chunk become k-slots 8 g + 4 n + r of fc2
+    };
+    uint4 hh[FM], hl[FM];
+    auto fc2 = [&](auto&& mid) {
+        uint4 ring[DEPTH][2];
+#pragma unroll
+        for (int c = 0; c < DEPTH - 1 && c < CF; ++c) ld_pair(stB + ((c * 2) << 10) + lane * 16, ring[c % DEPTH]);
+#pragma unroll
+        for (int c = 0; c < CF; ++c) {
+            if (c + DEPTH - 1 < CF) ld_pair(stB + (((c + DEPTH - 1) * 2) << 10) + lane * 16, ring[(c + DEPTH - 1) % DEPTH]);
+            const uint4 wh = ring[c % DEPTH][0], wl = ring[c % DEPTH][1];
+            if (c == CF / 2) mid();
+#pragma unroll
+            for (int t = 0; t < FM; ++t) yacc[t][c] = OpT<T>::mfma(as_v8<T>(wl), as_v8<T>(hh[t]), yacc[t][c]);
+#pragma unroll
+            for (int t = 0; t < FM; ++t) yacc[t][c] = OpT<T>::mfma(as_v8<T>(wh), as_v8<T>(hl[t]), yacc[t][c]);
+#pragma unroll
+            for (int t = 0; t < FM; ++t) yacc[t][c] = OpT<T>::mfma(as_v8<T>(wh), as_v8<T>(hh[t]), yacc[t][c]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    // bias + GELU + hi/lo split of a chunk: the lane's 8 hidden units 16 n + 4 g + r become k-slots 8 g + 4 n + r of fc2.
+    // Work items per token fragment: 4 x (GELU of two values) + 1 x (split into the hi / lo operand registers).
+    f32x2 vt[FM][4];
+    auto take = [&](int j) {                             // hacc + fc1 bias -> vt (hacc is free for the next chunk afterwards)
         const float4 bb0 = *reinterpret_cast<const float4*>(tab + j * 32 + 4 * g), bb1 = *reinterpret_cast<const float4*>(tab + j * 32 + 16 + 4 * g);
-        uint4 hh[FM], hl[FM];
 #pragma unroll
         for (int t = 0; t < FM; ++t) {
-            f32x4 lo = hacc[t][0], hi = hacc[t][1];
-            lo[0] += bb0.x; lo[1] += bb0.y; lo[2] += bb0.z; lo[3] += bb0.w;
-            hi[0] += bb1.x; hi[1] += bb1.y; hi[2] += bb1.z; hi[3] += bb1.w;
-            float v[8];
-            gelu_erf8(lo, hi, v);
-            uint4 o[2];
-            split8<T, 2>(v, o);
-            hh[t] = o[0]; hl[t] = o[1];
+            vt[t][0] = f32x2{hacc[t][0][0] + bb0.x, hacc[t][0][1] + bb0.y};
+            vt[t][1] = f32x2{hacc[t][0][2] + bb0.z, hacc[t][0][3] + bb0.w};
+            vt[t][2] = f32x2{hacc[t][1][0] + bb1.x, hacc[t][1][1] + bb1.y};
+            vt[t][3] = f32x2{hacc[t][1][2] + bb1.z, hacc[t][1][3] + bb1.w};
         }
+    };
+    constexpr int NITEMS = FM * 5;
+    auto item = [&](int i) {
+        const int t = i / 5, k = i % 5;
+        if (k < 4) { vt[t][k] = gelu_erf2(vt[t][k]); return; }
+        const float v[8] = {vt[t][0].x, vt[t][0].y, vt[t][1].x, vt[t][1].y, vt[t][2].x, vt[t][2].y, vt[t][3].x, vt[t][3].y};
+        uint4 o[2];
+        split8<T, 2>(v, o);
+        hh[t] = o[0]; hl[t] = o[1];
+    };
+
+    const bool late = S::STAGGER && (wave & 1);          // wave-uniform
+    auto nop = [] {};
+    if constexpr (!S::PIPE) {
+        // plain schedule per chunk:  fc1(j) | GELU(j) | fc2(j), two barriers
+        for (int j = 0; j < NCH; ++j) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                           // fc1 block j landed; every wave is done with fc2 block j - 1
+            if (!late) issue_w2(j);
+            fc1([](int) { return false; }, [&] { if (late) issue_w2(j); });
+            take(j);
+#pragma unroll
+            for (int i = 0; i < NITEMS; ++i) item(i);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                           // fc2 block j landed; every wave is done with fc1 block j
+            if (!late && j + 1 < NCH) issue_w1(j + 1);
+            fc2([&] { if (late && j + 1 < NCH) issue_w1(j + 1); });
+        }
+    } else {
+        // skewed schedule: fc1 runs one chunk ahead, so that the GELU of chunk j is spliced between the MFMAs of fc1(j + 1):
+        //   fc1(0) | [fc1(1) + GELU(0)] | fc2(0) | [fc1(2) + GELU(1)] | fc2(1) | ...        (stage A: fc1 blocks, stage B: fc2 blocks)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                           // fc2 block j landed; every wave is done with fc1 block j
-        if (j + 1 < NCH) issue_w1(j + 1);
-        {
-            uint4 ring[DEPTH][2];
+        __syncthreads();
+        fc1([](int) { return false; }, nop);
+        __syncthreads();                               // every wave is done with fc1 block 0
+        issue_w1(1);
+        for (int j = 0; j < NCH; ++j) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                           // fc1 block j + 1 landed; every wave is done with fc2 block j - 1
+            issue_w2(j);
+            take(j);
+            if (j + 1 < NCH) {
+                fc1([&](int s) {
+                    bool any = false;
 #pragma unroll
-            for (int c = 0; c < DEPTH - 1 && c < CF; ++c) ld_pair(stB + ((c * 2) << 10) + lane * 16, ring[c % DEPTH]);
+                    for (int i = 0; i < NITEMS; ++i)
+                        if ((i * NS) / NITEMS == s) { item(i); any = true; }
+                    return any;
+                }, nop);
+            } else {
 #pragma unroll
-            for (int c = 0; c < CF; ++c) {
-                if (c + DEPTH - 1 < CF) ld_pair(stB + (((c + DEPTH - 1) * 2) << 10) + lane * 16, ring[(c + DEPTH - 1) % DEPTH]);
-                const uint4 wh = ring[c % DEPTH][0], wl = ring[c % DEPTH][1];
-#pragma unroll
-                for (int t = 0; t < FM; ++t) yacc[t][c] = OpT<T>::mfma(as_v8<T>(wl), as_v8<T>(hh[t]), yacc[t][c]);
-#pragma unroll
-                for (int t = 0; t < FM; ++t) yacc[t][c] = OpT<T>::mfma(as_v8<T>(wh), as_v8<T>(hl[t]), yacc[t][c]);
-#pragma unroll
-                for (int t = 0; t < FM; ++t) yacc[t][c] = OpT<T>::mfma(as_v8<T>(wh), as_v8<T>(hh[t]), yacc[t][c]);
-                __builtin_amdgcn_sched_barrier(0);
+                for (int i = 0; i < NITEMS; ++i) item(i);
             }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                           // fc2 block j landed; every wave is done with fc1 block j + 1
+            if (j + 2 < NCH) issue_w1(j + 2);
+            fc2(nop);
         }
     }
 
@@ -306,10 +369,26 @@ hipError_t op_mlp_fused(const Geom& g, const BlockW<typename P::T>& b, int res, 
     static_assert(P::NA == 2 && P::NW == 2, "the fused MLP is the 3-term path");
     MlpArgs<T> a{Xs, wk.xs_plane[res], g.ntok[res], b.w1f, b.w2f, b.fc1_b, b.fc2_b, b.n2_g, b.n2_b, 1e-5f};
     if (a.M % 16 != 0) return hipErrorInvalidValue;
-    // C = 192: 64 tokens per wave, 4 waves (one per SIMD) | variant 1: 32 tokens per wave, 8 waves (two per SIMD);  C = 384: 32 x 4
+    // Measured at 721x1440 (ms per launch, C = 192 / C = 384; tools/mlp_variants.sh): the defaults are the schedules in which TWO
+    // waves share a SIMD, so that one wave's GELU, LDS-DMA issue and barrier waits run under the other's MFMAs --
+    //   C = 192: two independent 4-wave workgroups per CU, 32 tokens per wave ........ 0.748   (one 4-wave workgroup, 64 tokens per wave: 0.808;
+    //            one 8-wave workgroup: 0.764 -- its waves reach the barriers, and therefore the GELU, together)
+    //   C = 384: one 8-wave workgroup, 16 tokens per wave (LDS holds one 107 KB set) .. 0.695   (4 waves x 32 tokens, one per SIMD: 0.761)
+    // The skewed schedule (GELU of chunk j spliced into fc1 of chunk j + 1) needs 16 more registers than a wave has and spills.
     static const int variant = [] { const char* v = getenv("SKP_MLP_VARIANT"); return v ? atoi(v) : 0; }();
-    if (res == 0) return variant == 1 ? launch_fused_mlp<T, MlpShape<192, 2, 8>>(a, s) : launch_fused_mlp<T, MlpShape<192, 4, 4>>(a, s);
-    return launch_fused_mlp<T, MlpShape<384, 2, 4>>(a, s);
+    if (res == 0) {
+        switch (variant) {
+            case 1: return launch_fused_mlp<T, MlpShape<192, 2, 8, 3, false>>(a, s);
+            case 2: return launch_fused_mlp<T, MlpShape<192, 4, 4, 3, false>>(a, s);
+            case 3: return launch_fused_mlp<T, MlpShape<192, 4, 4, 2, true>>(a, s);
+            default: return launch_fused_mlp<T, MlpShape<192, 2, 4, 3, false, 4, 2>>(a, s);
+        }
+    }
+    switch (variant) {
+        case 2: return launch_fused_mlp<T, MlpShape<384, 2, 4, 3, false>>(a, s);
+        case 3: return launch_fused_mlp<T, MlpShape<384, 2, 4, 2, true>>(a, s);
+        default: return launch_fused_mlp<T, MlpShape<384, 1, 8, 3, false>>(a, s);
+    }
 }
 template hipError_t op_mlp_fused<PrecBF16x3>(const Geom&, const BlockW<bf16>&, int, bf16*, const Work<PrecBF16x3>&, hipStream_t);
 template hipError_t op_mlp_fused<PrecF16x3>(const Geom&, const BlockW<f16>&, int, f16*, const Work<PrecF16x3>&, hipStream_t);

@@ -1,0 +1,93 @@
+"""Per-kernel summary of the rocprofv3 counter passes written by tools/pmc_collect.sh.
+
+    python tools/pmc_summary.py gpurun_out/pmc_<tag> profiles/r02_<tag>_pmc.json [--steps N]
+
+For every kernel (demangled name, template arguments shortened) over all its dispatches: calls, average duration under the
+counters, and per dispatch
+  mfma_busy_pct     SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES)          share of CU-busy time the matrix pipe of a SIMD is busy
+  mfma_clk_per_inst SQ_VALU_MFMA_BUSY_CYCLES / SQ_INSTS_MFMA                          (16 for v_mfma_f32_16x16x32_f16: calibration)
+  wait_pct / stall_pct / issue_pct   SQ_WAIT_ANY, SQ_WAIT_INST_ANY, SQ_ACTIVE_INST_ANY over SQ_WAVE_CYCLES (disjoint, guide "PMC slots")
+  lds_active_pct    SQ_LDS_IDX_ACTIVE / SQ_BUSY_CU_CYCLES, bank conflicts as a share of LDS-active cycles
+  hbm_GB, hbm_GBps  FETCH_SIZE (KiB, doubled: gfx950 tallies 128-B read requests at 64 B -- MI355X_MICROARCH.md "HBM") + WRITE_SIZE (KiB)
+The clock under the counters is GRBM_GUI_ACTIVE / duration."""
+import csv
+import json
+import re
+import subprocess
+import sys
+from collections import defaultdict
+from pathlib import Path
+
+
+def short(name: str) -> str:
+    if name.startswith("_Z"):
+        name = subprocess.run(["c++filt", name], capture_output=True, text=True).stdout.strip() or name
+    name = re.sub(r"\(.*$", "", name)
+    name = name.replace("skp::", "").replace("void ", "")
+    name = re.sub(r"TileCfg<(\d+), (\d+), \d+, \d+, \d+>", r"\1x\2", name)
+    name = re.sub(r"(APlanes|AConcatPlanes|EpGelu|EpQKV|EpStorePlanes|SinkResidual|SinkStore)<[^<>]*>", r"\1", name)
+    name = re.sub(r"DmaArgs<.*$|GemmArgs<.*$", "", name)
+    return name[:140]
+
+
+def load(d: Path):
+    f = next(iter(sorted(d.glob("**/*counter_collection.csv"))), None)
+    if f is None:
+        return []
+    return list(csv.DictReader(open(f)))
+
+
+def main(prefix, out, *rest):
+    per = defaultdict(lambda: defaultdict(float))
+    calls = defaultdict(int)
+    dur = defaultdict(float)
+    cache = {}
+    for pas in ("sq1", "sq2", "fetch", "write"):
+        rows = load(Path(f"{prefix}_{pas}"))
+        seen = set()
+        for r in rows:
+            kn = r["Kernel_Name"]
+            if kn not in cache:
+                cache[kn] = short(kn)
+            k = cache[kn]
+            if "prep_" in k or "at::" in k or "rocclr" in k or "split_planes" in k:
+                continue
+            per[k][r["Counter_Name"] + "@" + pas] += float(r["Counter_Value"])
+            if pas == "sq1" and (kn, r["Dispatch_Id"]) not in seen:
+                seen.add((kn, r["Dispatch_Id"]))
+                calls[k] += 1
+                dur[k] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-3
+    res = {}
+    for k in sorted(calls, key=lambda k: -dur[k]):
+        n, c = calls[k], per[k]
+        g = lambda name, pas="sq1": c.get(name + "@" + pas, 0.0) / n          # noqa: E731
+        busy_cu, wave = g("SQ_BUSY_CU_CYCLES"), g("SQ_WAVE_CYCLES")
+        busy2 = g("GRBM_GUI_ACTIVE", "sq2")
+        e = {"calls": n, "avg_us": round(dur[k] / n, 2),
+             "clock_GHz": round(g("GRBM_GUI_ACTIVE") / (dur[k] / n * 1e3), 3) if dur[k] else None,
+             "mfma_busy_pct": round(100 * g("SQ_VALU_MFMA_BUSY_CYCLES") / (4 * busy_cu), 2) if busy_cu else None,
+             "mfma_clk_per_inst": round(g("SQ_VALU_MFMA_BUSY_CYCLES") / g("SQ_INSTS_MFMA"), 2) if g("SQ_INSTS_MFMA") else None,
+             "wait_pct": round(100 * g("SQ_WAIT_ANY") / wave, 1) if wave else None,
+             "stall_pct": round(100 * g("SQ_WAIT_INST_ANY") / wave, 1) if wave else None,
+             "issue_pct": round(100 * g("SQ_ACTIVE_INST_ANY") / wave, 1) if wave else None,
+             "lds_stall_pct": round(100 * g("SQ_WAIT_INST_LDS") / wave, 1) if wave else None,
+             "lds_active_per_gui": round(g("SQ_LDS_IDX_ACTIVE", "sq2") / busy2, 3) if busy2 else None,
+             "lds_conflict_pct": round(100 * g("SQ_LDS_BANK_CONFLICT", "sq2") / g("SQ_LDS_IDX_ACTIVE", "sq2"), 2) if g("SQ_LDS_IDX_ACTIVE", "sq2") else None,
+             "fetch_GB": round(2 * 1024 * g("FETCH_SIZE", "fetch") / 1e9, 4), "write_GB": round(1024 * g("WRITE_SIZE", "write") / 1e9, 4)}
+        e["hbm_GB"] = round(e["fetch_GB"] + e["write_GB"], 4)
+        e["hbm_GBps_under_pmc"] = round(e["hbm_GB"] / (e["avg_us"] * 1e-6), 1) if e["avg_us"] else None
+        e["raw_per_dispatch"] = {kk: round(v / n, 1) for kk, v in sorted(c.items())}
+        res[k] = e
+    steps = int(rest[rest.index("--steps") + 1]) if "--steps" in rest else 3
+    total = {"hbm_GB_per_step": round(sum(e["hbm_GB"] * e["calls"] for e in res.values()) / steps, 2),
+             "write_GB_per_step": round(sum(e["write_GB"] * e["calls"] for e in res.values()) / steps, 2),
+             "kernel_ms_per_step_under_pmc": round(sum(e["avg_us"] * e["calls"] for e in res.values()) / steps / 1e3, 2), "steps": steps}
+    json.dump({"total": total, "kernels": res}, open(out, "w"), indent=1)
+    print(json.dumps(total))
+    for k, e in res.items():
+        print(f"{e['avg_us']:9.1f} us x{e['calls']:4d}  mfma {e['mfma_busy_pct']}%  wait {e['wait_pct']} stall {e['stall_pct']} issue {e['issue_pct']}  "
+              f"lds {e['lds_active_per_gui']} confl {e['lds_conflict_pct']}%  hbm {e['hbm_GB']} GB ({e['write_GB']} W)  {k[:90]}")
+
+
+if __name__ == "__main__":
+    main(*sys.argv[1:])
