@@ -18,7 +18,7 @@
 extern "C" {
 #endif
 
-#define SKGC_ABI_VERSION 1
+#define SKGC_ABI_VERSION 2
 #define SKGC_E_ARG (-1)
 #define SKGC_E_HIP (-2)
 
@@ -60,6 +60,31 @@ int skgc_segment_sum(const float* e, const int* offsets, float* out, float* acc,
 int skgc_prepare_weight_perm8(const float* src, int N, int K, void* dst, long long plane, int ldw, void* stream);
 int skgc_linear_layer_norm(const float* a, long long lda, int K, const void* w, long long w_plane, int ldw, const float* bias, const float* gamma,
                            const float* beta, const float* res, float* out, long long rows, void* stream);
+
+/* Edge MLP with the first Linear taken apart by distributivity (512 columns only):
+ *   out[r][:] = (res ? res[r][:] : 0) + LayerNorm( act( sum_s src[s][ idx[s] ? idx[s][r] : r ][0..K) ) W^T + bias ) * gamma + beta
+ * i.e. the caller has computed the per-edge term e W_e^T (+ fc1 bias) and the per-NODE terms v_s W_s^T, v_r W_r^T; this kernel
+ * gathers and adds the three rows, applies the activation and runs the second Linear + LayerNorm (+ residual).  Replaces
+ * skgc_gather_gemm over concat(e, v_s[send], v_r[recv]) followed by skgc_linear_layer_norm: same result up to fp32 rounding.
+ * src rows are fp32 with leading dimension ld[s] >= K, 16-byte aligned; K % 8 == 0; W as for skgc_linear_layer_norm. */
+typedef struct skgc_sum_desc {
+    const float* src[3];
+    const int* idx[3];
+    long long ld[3];
+    int n_src;
+    int K;
+    int act;                 /* 0 = none, 2 = swish */
+    const void* w;
+    long long w_plane;
+    int ldw;
+    const float* bias;       /* second Linear's bias, [512] or NULL */
+    const float* gamma;
+    const float* beta;
+    const float* res;        /* NULL or [rows][512]; out may alias res */
+    float* out;              /* [rows][512] */
+    long long rows;
+} skgc_sum_desc;
+int skgc_sum_linear_layer_norm(const skgc_sum_desc* desc, void* stream);
 
 #ifdef __cplusplus
 }

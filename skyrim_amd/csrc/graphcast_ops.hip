@@ -56,6 +56,51 @@ struct ALGather {
     __device__ __forceinline__ uint4 direct(const Raw&) const { return make_uint4(0, 0, 0, 0); }
 };
 
+// A operand = swish( sum_s src[s][ idx[s] ? idx[s][m] : m ][k] ): the first Linear of an edge MLP by distributivity.
+//   fc1(concat(e, v_s[send], v_r[recv])) = e W_e^T + (v_s W_s^T)[send] + (v_r W_r^T)[recv] + b
+// The two node terms are computed once per NODE (8 edges share a mesh node, 3 a grid node), the edge term once per layer (or once
+// per model where the edge latent is input-independent), and this loader adds the gathered rows up on the fly and applies the
+// activation -- the hidden activation of the edge MLP is never materialised (12.8 GB of traffic per step for the mesh->grid edges),
+// and 44 % of the step's FLOPs are gone.
+struct ALSumGather {
+    static constexpr bool kDirect = false;
+    const float* src[3];
+    const int* idx[3];
+    long long ld[3];
+    int n_src, M, K, act;
+    struct Row { long long r[3]; int ok; };
+    struct Raw { float4 lo[3], hi[3]; int ok; };
+    __device__ __forceinline__ Row row(int m) const {
+        Row o;
+        o.ok = m < M;
+#pragma unroll
+        for (int s = 0; s < 3; ++s) o.r[s] = (o.ok && s < n_src) ? (long long)(idx[s] ? idx[s][m] : m) * ld[s] : 0;
+        return o;
+    }
+    __device__ __forceinline__ void issue(const Row& r, int k, Raw& o) const {
+        o.ok = r.ok && k < K;
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            o.lo[s] = make_float4(0.f, 0.f, 0.f, 0.f); o.hi[s] = o.lo[s];
+            if (o.ok && s < n_src) {                       // K % 8 == 0 and 16-byte aligned rows (checked by the launcher)
+                const float* p = src[s] + r.r[s] + k;
+                o.lo[s] = *reinterpret_cast<const float4*>(p);
+                o.hi[s] = *reinterpret_cast<const float4*>(p + 4);
+            }
+        }
+    }
+    __device__ __forceinline__ void finish(const Raw& r, float (&v)[8]) const {
+        const float4 a = r.lo[0], b = r.lo[1], c = r.lo[2], d = r.hi[0], e = r.hi[1], f = r.hi[2];
+        v[0] = (a.x + b.x) + c.x; v[1] = (a.y + b.y) + c.y; v[2] = (a.z + b.z) + c.z; v[3] = (a.w + b.w) + c.w;
+        v[4] = (d.x + e.x) + f.x; v[5] = (d.y + e.y) + f.y; v[6] = (d.z + e.z) + f.z; v[7] = (d.w + e.w) + f.w;
+        if (act == 2 && r.ok) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = swish(v[i]);
+        }
+    }
+    __device__ __forceinline__ uint4 direct(const Raw&) const { return make_uint4(0, 0, 0, 0); }
+};
+
 // second Linear of an MLP fused with its LayerNorm (+ residual): the tile spans the whole latent (N = 512 = LayerNorm width), so
 // the pre-norm activations never go to HBM (for the 3.1 M mesh->grid edges that is 12.8 GB of traffic per step).  The weight is
 // prepared in perm8 row order (common.h): a lane's accumulators of a fragment pair are 8 consecutive columns -> 32-byte row pieces.
@@ -88,6 +133,12 @@ template <bool RES>
 __global__ void __launch_bounds__(TLN::THREADS) linear_ln_kernel(const GemmArgs<PrecF16x3, ALStrided, EpLayerNorm<RowMapIndexed, SinkRowsF32<RES>>> g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     gemm_body<PrecF16x3, TLN, ALStrided, EpLayerNorm<RowMapIndexed, SinkRowsF32<RES>>, true>(g, smem);
+}
+
+template <bool RES>
+__global__ void __launch_bounds__(TLN::THREADS) sum_linear_ln_kernel(const GemmArgs<PrecF16x3, ALSumGather, EpLayerNorm<RowMapIndexed, SinkRowsF32<RES>>> g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    gemm_body<PrecF16x3, TLN, ALSumGather, EpLayerNorm<RowMapIndexed, SinkRowsF32<RES>>, true>(g, smem);
 }
 
 __global__ void __launch_bounds__(TG::THREADS) gather_gemm_kernel(const GemmArgs<PrecF16x3, ALGather, EpStrided> g) {
@@ -241,6 +292,43 @@ int skgc_linear_layer_norm(const float* a, long long lda, int K, const void* w, 
         return hipGetLastError();
     };
     const hipError_t e = res ? launch(std::true_type{}) : launch(std::false_type{});
+    return e == hipSuccess ? 0 : SKGC_E_HIP;
+}
+
+int skgc_sum_linear_layer_norm(const skgc_sum_desc* d, void* stream) {
+    constexpr int N = TLN::BN;
+    if (!d || !d->w || !d->gamma || !d->beta || !d->out || d->rows <= 0 || d->rows > 0x7fffffff || d->K <= 0 || (d->K & 7) || d->n_src < 1 || d->n_src > 3 ||
+        (d->ldw & 7) || d->ldw < d->K || (d->act != 0 && d->act != 2))
+        return SKGC_E_ARG;
+    ALSumGather al;
+    for (int s = 0; s < 3; ++s) {
+        al.src[s] = nullptr; al.idx[s] = nullptr; al.ld[s] = 0;
+        if (s < d->n_src) {
+            if (!d->src[s] || d->ld[s] < d->K || (d->ld[s] & 3) || (reinterpret_cast<size_t>(d->src[s]) & 15)) return SKGC_E_ARG;
+            al.src[s] = d->src[s]; al.idx[s] = d->idx[s]; al.ld[s] = d->ld[s];
+        }
+    }
+    al.n_src = d->n_src; al.M = (int)d->rows; al.K = d->K; al.act = d->act;
+    const dim3 grid(1, (unsigned)((d->rows + TLN::BM - 1) / TLN::BM));
+    constexpr int smem = gemm_smem_bytes<PrecF16x3, TLN>() + kEpiScratch;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    auto launch = [&](auto res_c) {
+        constexpr bool RES = decltype(res_c)::value;
+        typedef EpLayerNorm<RowMapIndexed, SinkRowsF32<RES>> EP;
+        GemmArgs<PrecF16x3, ALSumGather, EP> g;
+        g.al = al;
+        g.ep = EP{RowMapIndexed{nullptr}, SinkRowsF32<RES>{d->out, d->res}, d->bias, d->gamma, d->beta, 1e-5f};
+        g.W = static_cast<const f16*>(d->w);
+        g.w_plane = d->w_plane;
+        g.ldw = d->ldw;
+        g.M = (int)d->rows; g.N = N; g.K = d->K;
+        auto kern = sum_linear_ln_kernel<RES>;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, grid, dim3(TLN::THREADS), smem, st, g);
+        return hipGetLastError();
+    };
+    const hipError_t e = d->res ? launch(std::true_type{}) : launch(std::false_type{});
     return e == hipSuccess ? 0 : SKGC_E_HIP;
 }
 

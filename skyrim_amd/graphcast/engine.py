@@ -27,7 +27,7 @@ from .spec import N_FORCING, N_STATIC, GraphcastConfig, mlp_names, param_spec
 
 _LIB_PATH = Path(__file__).resolve().parent.parent / "lib" / "libskyrim_graphcast.so"
 EXPORTS = ["skgc_abi_version", "skgc_gather_gemm", "skgc_layer_norm", "skgc_segment_sum", "skgc_prepare_weight_perm8",
-           "skgc_linear_layer_norm"]
+           "skgc_linear_layer_norm", "skgc_sum_linear_layer_norm"]
 
 
 class GatherDesc(ctypes.Structure):
@@ -35,6 +35,12 @@ class GatherDesc(ctypes.Structure):
                 ("n_src", ctypes.c_int), ("kscale", ctypes.c_void_p), ("kshift", ctypes.c_void_p),
                 ("w", ctypes.c_void_p), ("w_plane", ctypes.c_longlong), ("ldw", ctypes.c_int), ("bias", ctypes.c_void_p),
                 ("out", ctypes.c_void_p), ("ldo", ctypes.c_longlong), ("M", ctypes.c_int), ("N", ctypes.c_int), ("act", ctypes.c_int)]
+
+
+class SumDesc(ctypes.Structure):
+    _fields_ = [("src", ctypes.c_void_p * 3), ("idx", ctypes.c_void_p * 3), ("ld", ctypes.c_longlong * 3), ("n_src", ctypes.c_int), ("K", ctypes.c_int),
+                ("act", ctypes.c_int), ("w", ctypes.c_void_p), ("w_plane", ctypes.c_longlong), ("ldw", ctypes.c_int), ("bias", ctypes.c_void_p),
+                ("gamma", ctypes.c_void_p), ("beta", ctypes.c_void_p), ("res", ctypes.c_void_p), ("out", ctypes.c_void_p), ("rows", ctypes.c_longlong)]
 
 
 _lib = None
@@ -54,6 +60,7 @@ def load_library():
     lib.skgc_prepare_weight_perm8.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_void_p]
     lib.skgc_linear_layer_norm.argtypes = [ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int] + \
         [ctypes.c_void_p] * 5 + [ctypes.c_longlong, ctypes.c_void_p]
+    lib.skgc_sum_linear_layer_norm.argtypes = [ctypes.POINTER(SumDesc), ctypes.c_void_p]
     for name in EXPORTS:
         getattr(lib, name).restype = ctypes.c_int
     _lib = lib
@@ -91,6 +98,10 @@ class GraphcastEngine:
         self.profiling = False
         self._events = []
         self.fused_ln = self.cfg.latent == 512 and not os.environ.get("SKGC_UNFUSED_LN")
+        # edge MLPs by distributivity (fc1 of concat(e, v_s[send], v_r[recv]) = e W_e^T + (v_s W_s^T)[send] + (v_r W_r^T)[recv]): the node
+        # terms once per node, the edge term once per layer (once per model for the encoder / decoder, whose edge latents are
+        # input-independent); needs the fused Linear + LayerNorm kernel (latent 512)
+        self.split_edges = self.fused_ln and not os.environ.get("SKGC_CONCAT_EDGES")
         self.state_shape = (self.cfg.n_vars, self.lat1 - self.lat0, self.cfg.n_lon)
 
     def _stream(self):
@@ -150,6 +161,39 @@ class GraphcastEngine:
         self._gemm(self.b_h, m["fc2"], self.b_t, rows, a_sm=L, a_sk=1, o_sm=L, o_sn=1, bias=m["b2"], label=label or name.split(".")[0])
         self._ln(self.b_t, m["g"], m["b"], res, out, rows)
 
+    def _sum_ln(self, name, sources, rows, out, res=None, label=None):
+        """out = (res +) LayerNorm(fc2(swish(sum of the gathered source rows))) -- sources: [(flat tensor, element offset, ld, index or None)]."""
+        m, L = self.m[name], self.cfg.latent
+        buf, plane, ldw = m["fc2p"]
+        self._mark(label or name.split(".")[0], 2.0 * rows * L * L)
+        ops.hip.gc_sum_linear_layer_norm([t for t, _, _, _ in sources], [o for _, o, _, _ in sources], [d for _, _, d, _ in sources], [i for _, _, _, i in sources],
+                                         L, 2, buf, plane, ldw, m["b2"], m["g"], m["b"], res, out, rows)
+
+    def _edge_mlp(self, name, edge_term, vs, idx_s, vr, idx_r, rows, out, res=None, label=None):
+        """Edge update by distributivity.  edge_term: a precomputed [rows][L] tensor (e W_e^T + b1, input-independent edge latents) or the
+        current edge latents (then e W_e^T + b1 is one GEMM); vs / vr: node latents whose W_s / W_r images are gathered (vr None: already
+        folded into edge_term)."""
+        m, L = self.m[name], self.cfg.latent
+        lab = label or name.split(".")[0]
+        if m.get("static_edge"):
+            E = edge_term
+        else:
+            self._gemm(edge_term, m["w_e"], self.b_h, rows, a_sm=L, a_sk=1, o_sm=L, o_sn=1, bias=m["b1"], label=lab)
+            E = self.b_h
+        srcs = [(E, 0, L, None)]
+        if vr is not None and vs is vr:                  # processor: one GEMM for both node terms, [n][2L] = v [W_s; W_r]^T
+            n = vs.shape[0]
+            self._gemm(vs, m["w_sr"], self.b_ps, n, a_sm=L, a_sk=1, o_sm=2 * L, o_sn=1, label=lab)
+            srcs += [(self.b_ps, 0, 2 * L, idx_s), (self.b_ps, L, 2 * L, idx_r)]
+        else:
+            ns = vs.shape[0]
+            self._gemm(vs, m["w_s"], self.b_ps, ns, a_sm=L, a_sk=1, o_sm=L, o_sn=1, label=lab)
+            srcs.append((self.b_ps, 0, L, idx_s))
+            if vr is not None:
+                self._gemm(vr, m["w_r"], self.b_pr, vr.shape[0], a_sm=L, a_sk=1, o_sm=L, o_sn=1, label=lab)
+                srcs.append((self.b_pr, 0, L, idx_r))
+        self._sum_ln(name, srcs, rows, out, res=res, label=lab)
+
     # ---- prepare ------------------------------------------------------------------------------------- #
     def load_params(self, params: dict):
         c, g, dev = self.cfg, self.graph, self.device
@@ -170,6 +214,14 @@ class GraphcastEngine:
                 self.m[name] = dict(fc1=_sf._Weight(weng, p[name + ".fc1.weight"]), b1=f32(p[name + ".fc1.bias"]),
                                     fc2=_sf._Weight(weng, w2), b2=f32(b2),
                                     g=f32(p[name + ".ln.weight"]) if ln else None, b=f32(p[name + ".ln.bias"]) if ln else None)
+                if self.split_edges and name.endswith(".edge") and not name.startswith("embed"):
+                    w1 = p[name + ".fc1.weight"]
+                    d = self.m[name]
+                    d["w_e"] = _sf._Weight(weng, w1[:, :L])
+                    if name.startswith("proc."):
+                        d["w_sr"] = _sf._Weight(weng, torch.cat([w1[:, L:2 * L], w1[:, 2 * L:]], dim=0))
+                    else:
+                        d["w_s"], d["w_r"] = _sf._Weight(weng, w1[:, L:2 * L]), _sf._Weight(weng, w1[:, 2 * L:])
                 if ln and self.fused_ln:                                 # perm8 copy of the second Linear for the fused Linear + LayerNorm kernel
                     src = f32(w2)
                     planes = torch.empty(2 * L * L, dtype=torch.float16, device=dev)
@@ -207,6 +259,24 @@ class GraphcastEngine:
                                     ("embed.mesh_edge", g.mesh_edge_feat, self.em_0), ("embed.m2g_edge", g.m2g_edge_feat, self.e2_0)):
                 ft = torch.from_numpy(np.ascontiguousarray(feat)).to(dev)
                 self._mlp(name, [(ft, None, ft.shape[1])], ft.shape[0], out)
+            if self.split_edges:
+                # input-independent parts of the encoder / decoder edge MLPs' first Linear, once per model:
+                #   grid->mesh: e1_0 W_e^T + b1 + (vm0 W_r^T)[receiver]   (edge latents AND the receiving mesh latents are structural)
+                #   mesh->grid: e2_0 W_e^T + b1
+                self.b_ps = buf(max(P, g.n_mesh), 2 * L)
+                self.b_pr = buf(max(P, g.n_mesh), L)
+                m1, m2 = self.m["g2m.edge"], self.m["m2g.edge"]
+                self._gemm(self.e1_0, m1["w_e"], self.b_h, E1, a_sm=L, a_sk=1, o_sm=L, o_sn=1, bias=m1["b1"])
+                self._gemm(self.vm0, m1["w_r"], self.b_pr, g.n_mesh, a_sm=L, a_sk=1, o_sm=L, o_sn=1)
+                torch.cuda.current_stream(dev).synchronize()
+                self.e1_0.copy_(self.b_h[:E1])
+                chunk = 1 << 20
+                for i0 in range(0, E1, chunk):
+                    self.e1_0[i0:i0 + chunk] += self.b_pr[self.g2m_r[i0:i0 + chunk].long()]
+                self._gemm(self.e2_0, m2["w_e"], self.b_h, E2, a_sm=L, a_sk=1, o_sm=L, o_sn=1, bias=m2["b1"])
+                torch.cuda.current_stream(dev).synchronize()
+                self.e2_0.copy_(self.b_h[:E2])
+                m1["static_edge"] = m2["static_edge"] = True
             torch.cuda.current_stream(dev).synchronize()
         self.prepared = True
 
@@ -235,7 +305,10 @@ class GraphcastEngine:
             self._gemm(self.b_h, m["fc2"], self.b_t, P, a_sm=L, a_sk=1, o_sm=L, o_sn=1, bias=m["b2"], label="embed")
             self._ln(self.b_t, m["g"], m["b"], None, self.vg, P)
             # encoder: grid -> mesh
-            self._mlp("g2m.edge", [(self.e1_0, None, L), (self.vg, self.g2m_s, L), (self.vm0, self.g2m_r, L)], self.E1, self.e1, label="encoder")
+            if self.split_edges:
+                self._edge_mlp("g2m.edge", self.e1_0, self.vg, self.g2m_s, None, None, self.E1, self.e1, label="encoder")
+            else:
+                self._mlp("g2m.edge", [(self.e1_0, None, L), (self.vg, self.g2m_s, L), (self.vm0, self.g2m_r, L)], self.E1, self.e1, label="encoder")
             self._segsum(self.e1, self.g2m_off, self.agg_m, self.graph.n_mesh)
             if self.world > 1:                       # the one exchange of a grid-sharded step: sum the partial aggregates over ranks
                 self._mark("exchange")
@@ -250,11 +323,17 @@ class GraphcastEngine:
             self.em.copy_(self.em_0)
             for i in range(c.steps):
                 de = self.de
-                self._mlp(f"proc.{i}.edge", [(self.em, None, L), (self.vm, self.me_s, L), (self.vm, self.me_r, L)], self.EM, de, label="processor")
+                if self.split_edges:
+                    self._edge_mlp(f"proc.{i}.edge", self.em, self.vm, self.me_s, self.vm, self.me_r, self.EM, de, label="processor")
+                else:
+                    self._mlp(f"proc.{i}.edge", [(self.em, None, L), (self.vm, self.me_s, L), (self.vm, self.me_r, L)], self.EM, de, label="processor")
                 self._segsum(de, self.me_off, self.agg_m, self.graph.n_mesh, acc=self.em)      # receiver sum; em += de rides along
                 self._mlp(f"proc.{i}.node", [(self.vm, None, L), (self.agg_m, None, L)], self.graph.n_mesh, self.vm, res=self.vm, label="processor")
             # decoder: mesh -> grid
-            self._mlp("m2g.edge", [(self.e2_0, None, L), (self.vm, self.m2g_s, L), (self.vg, self.m2g_r, L)], self.E2, self.e2, label="decoder")
+            if self.split_edges:
+                self._edge_mlp("m2g.edge", self.e2_0, self.vm, self.m2g_s, self.vg, self.m2g_r, self.E2, self.e2, label="decoder")
+            else:
+                self._mlp("m2g.edge", [(self.e2_0, None, L), (self.vm, self.m2g_s, L), (self.vg, self.m2g_r, L)], self.E2, self.e2, label="decoder")
             self._segsum(self.e2, self.m2g_off, self.agg_g, P)
             self._mlp("m2g.grid_node", [(self.vg, None, L), (self.agg_g, None, L)], P, self.vg, res=self.vg, label="decoder")
             # output layer: x(t+6h) = x(t) + diff_std * MLP(vg), written channel-major

@@ -8,7 +8,7 @@ are stream-ordered, allocation-free and capturable in a HIP graph.
 
     pangu_step / pangu_patch_embed / pangu_block / pangu_downsample / pangu_upsample / pangu_patch_recover     (ctx = skpangu_ctx*)
     sfno_gemm / sfno_instance_norm
-    gc_gather_gemm / gc_linear_layer_norm / gc_layer_norm / gc_segment_sum
+    gc_gather_gemm / gc_linear_layer_norm / gc_sum_linear_layer_norm / gc_layer_norm / gc_segment_sum
 """
 from __future__ import annotations
 
@@ -150,6 +150,28 @@ def _gc_linear_layer_norm(a, lda: int, K: int, w, w_plane: int, ldw: int, bias, 
                                        _f32(beta, "beta", dev), _opt(res), _f32(out, "out"), rows, _stream(out)), "skgc_linear_layer_norm")
 
 
+def _gc_sum_linear_layer_norm(src, src_off, ld, idx, K: int, act: int, w, w_plane: int, ldw: int, bias, gamma, beta, res, out, rows: int) -> None:
+    from .graphcast import engine
+    lib = engine.load_library()
+    dev = out.device
+    if not (1 <= len(src) <= 3) or not (len(src) == len(src_off) == len(ld) == len(idx)):
+        raise ValueError("gc_sum_linear_layer_norm: 1..3 sources with an element offset, a leading dimension and an (optional) index tensor each")
+    d = engine.SumDesc()
+    for s, (t, off, l, ix) in enumerate(zip(src, src_off, ld, idx)):
+        _f32(t, f"src[{s}]", dev)
+        if ix is not None and (ix.dtype != torch.int32 or ix.device != dev or not ix.is_contiguous()):
+            raise ValueError("gc_sum_linear_layer_norm: index tensors are contiguous int32 on the same device")
+        d.src[s], d.idx[s], d.ld[s] = t.data_ptr() + 4 * off, (ix.data_ptr() if ix is not None else None), l
+    d.n_src, d.K, d.act = len(src), K, act
+    d.w, d.w_plane, d.ldw = w.data_ptr(), w_plane, ldw
+    d.bias = bias.data_ptr() if bias is not None else None
+    d.gamma, d.beta = _f32(gamma, "gamma", dev).value, _f32(beta, "beta", dev).value
+    d.res = res.data_ptr() if res is not None else None
+    d.out, d.rows = _f32(out, "out").value, rows
+    with torch.cuda.device(dev):
+        _ok(lib.skgc_sum_linear_layer_norm(ctypes.byref(d), _stream(out)), "skgc_sum_linear_layer_norm")
+
+
 def _gc_layer_norm(x, gamma, beta, res, out, rows: int, N: int) -> None:
     from .graphcast import engine
     lib = engine.load_library()
@@ -182,6 +204,8 @@ _SCHEMAS = [
      "Tensor? kscale, Tensor? kshift) -> ()", _gc_gather_gemm),
     ("gc_linear_layer_norm(Tensor a, int lda, int K, Tensor w, int w_plane, int ldw, Tensor bias, Tensor gamma, Tensor beta, Tensor? res, Tensor(a!) out, int rows) -> ()",
      _gc_linear_layer_norm),
+    ("gc_sum_linear_layer_norm(Tensor[] src, int[] src_off, int[] ld, Tensor?[] idx, int K, int act, Tensor w, int w_plane, int ldw, Tensor? bias, Tensor gamma, "
+     "Tensor beta, Tensor? res, Tensor(a!) out, int rows) -> ()", _gc_sum_linear_layer_norm),
     ("gc_layer_norm(Tensor x, Tensor gamma, Tensor beta, Tensor? res, Tensor(a!) out, int rows, int N) -> ()", _gc_layer_norm),
     ("gc_segment_sum(Tensor e, Tensor offsets, Tensor(a!) out, Tensor(b!)? acc, int n_nodes, int N) -> ()", _gc_segment_sum),
 ]
