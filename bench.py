@@ -235,7 +235,19 @@ def run_graphcast(args, rank, local_rank, world, dist):
     cfg = GraphcastConfig(n_lat=args.n_lat, n_lon=args.n_lon)
     dev = torch.device("cuda", local_rank)
     sharded = args.shard and world > 1
-    eng = GraphcastEngine(cfg, dev, shard=(rank, world) if sharded else (0, 1))
+    comm = {}
+    if sharded and args.backend != "nccl":           # gloo moves host memory: stage the two collectives (control-flow runs on a 1-GPU box only)
+        def _reduce(t):
+            h = t.cpu()
+            dist.all_reduce(h)
+            t.copy_(h)
+
+        def _gather(out, mine):
+            h = torch.empty(out.shape, dtype=out.dtype)
+            dist.all_gather_into_tensor(h.view(-1, h.shape[-1]), mine.cpu())
+            out.copy_(h)
+        comm = dict(reduce_fn=_reduce, gather_fn=_gather)
+    eng = GraphcastEngine(cfg, dev, shard=(rank, world) if sharded else (0, 1), **comm)
     g = eng.graph
     params = init_synthetic(cfg, 0)
     eng.load_params(params)
@@ -289,8 +301,8 @@ def run_graphcast(args, rank, local_rank, world, dist):
                                f"{len(g.m2g_edges)} mesh->grid edges; latent {cfg.latent}, {cfg.steps} processor layers) 6-h autoregressive rollout, "
                                f"{cfg.n_lat}x{cfg.n_lon}x{cfg.n_vars} state, random-init weights (35.4 M), states resident in HBM, 1 member per GPU",
                    "precision": "every Linear as a GEMM with fp16 hi/lo operands, 3 MFMA terms, fp32 accumulate; fp32 latents",
-                   "parallelism": (f"one forecast over {world} GPUs: latitude bands of the grid, mesh replicated, one all-reduce of the "
-                                   f"({g.n_mesh} x {cfg.latent}) mesh aggregate per step") if sharded else
+                   "parallelism": (f"one forecast over {world} GPUs: latitude bands of the grid + mesh-node ranges (owner computes); per step one "
+                                   f"all-reduce of the ({g.n_mesh} x {cfg.latent}) grid->mesh aggregate and {cfg.steps} all-gathers of the node latents") if sharded else
                                   (f"member-parallel x{world}" if world > 1 else "single GPU"), "finite": finite},
         "roofline": {"bound": "mfma", "kernel": dom["name"] + " (gather_gemm_kernel + gemm_strided_kernel)", "achieved": achieved / 1e12,
                      "peak": PEAK_MFMA_BF16 / 1e12, "unit": "TFLOP/s", "frac": achieved / PEAK_MFMA_BF16, "traffic": None,
@@ -338,6 +350,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-alt-modes", action="store_true", help="skip the short runs of the other precision modes")
+    ap.add_argument("--members", type=int, default=0, help="pangu, --gpus > 1: ensemble members in total, sharded round-robin over the ranks "
+                    "(BASELINE configs[4]: --gpus 8 --members 50 --save-every 1 --gather); default: one member per rank")
+    ap.add_argument("--save-every", type=int, default=0, help="ensemble mean / spread (and --gather) every this many steps; default: once, after the last step")
+    ap.add_argument("--gather", action="store_true", help="also all-gather the member states at every saved step")
+    ap.add_argument("--reduce", default="allgather", choices=["allgather", "allreduce"], help="ensemble reduction: all-gather of per-rank partial "
+                    "sums + local reduce (direct xGMI exchange, default) or ring all-reduce")
     ap.add_argument("--mlp", default="fused", choices=["fused", "split"], help="pangu: one-kernel MLP (default) or the two tiled GEMMs of round 1")
     ap.add_argument("--model", default="pangu", choices=["pangu", "sfno", "graphcast"],
                     help="pangu (default; BASELINE.json's headline configuration), sfno (FourCastNet v2-small, configs[2]) or graphcast (configs[3])")
@@ -385,25 +403,38 @@ def main():
     dev = torch.device("cuda", local_rank)
     eng = PanguEngine(geom, args.precision, dev, mlp=args.mlp)
     eng.load_params(params)
-    x_host = synthetic_state(geom, 0, member=rank if world > 1 else None)
-    x = x_host.to(dev)
+    from skyrim_amd.pangu.ensemble import gather_members, member_shard
+    n_members = args.members or world
+    if n_members < world:
+        raise SystemExit("--members must be >= --gpus")
+    mine = member_shard(n_members, rank, world)              # round-robin: 50 members on 8 ranks -> 7,7,6,6,6,6,6,6
+    x_host = synthetic_state(geom, 0, member=mine[0] if world > 1 else None)
+    xs = [synthetic_state(geom, 0, member=m if world > 1 else None).to(dev) for m in mine]
+    x = xs[0]
+    save_every = args.save_every or args.steps
 
     def sync():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    def saved_step():
+        out = ensemble_mean_spread(xs, n_members, args.reduce)
+        return out + ((gather_members(xs, n_members),) if args.gather else ())
+
     for _ in range(args.warmup):
-        eng.step(x, x)
+        for xm in xs:
+            eng.step(xm, xm)
     if world > 1:   # warm the communicator outside the timed region
-        ensemble_mean_spread([x], world)
+        saved_step()
     eng.profile(True)
     sync()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        eng.step(x, x)
-    if world > 1:
-        mean, spread = ensemble_mean_spread([x], world)
+    for k in range(1, args.steps + 1):
+        for xm in xs:
+            eng.step(xm, xm)
+        if world > 1 and (k % save_every == 0 or k == args.steps):
+            saved = saved_step()
     sync()
     elapsed = time.perf_counter() - t0
     stats = eng.profile_read()
@@ -419,10 +450,10 @@ def main():
         dom = max(timed, key=lambda s: s["total_ms"])
         dom_ms = dom["total_ms"] / dom["launches"]
         achieved = dom["flops"] / (dom_ms * 1e-3)
-        gpu_ms = sum(s["total_ms"] for s in timed) / args.steps
+        gpu_ms = sum(s["total_ms"] for s in timed) / (args.steps * len(mine))
         out = {
             "metric": "6-h forecast steps/sec on 721x1440 state, 1/2/4/8 MI355X; per-channel max rel-err vs ref",
-            "value": world * args.steps / elapsed,
+            "value": n_members * args.steps / elapsed,          # 6-h steps of all members per second (whole job)
             "unit": "steps/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -438,8 +469,10 @@ def main():
                             "(13 levels x 5 vars + 4 surface), random-init weights (64 M params), "
                             "state resident in HBM, 1 ensemble member per GPU",
                 "precision": MODE_NOTES[args.precision][0],
-                "parallelism": f"member-parallel x{world}" if world > 1 else "single GPU",
-                "finite": finite,
+                "parallelism": (f"member-parallel: {n_members} members round-robin over {world} GPUs ({len(mine)} on rank 0), ensemble mean / spread "
+                                f"every {save_every} step(s) by {args.reduce}" + (", member states all-gathered at every saved step" if args.gather else ""))
+                               if world > 1 else "single GPU",
+                "members": n_members, "finite": finite,
             },
             "roofline": {
                 "bound": "mfma", "kernel": dom["name"], "achieved": achieved / 1e12, "peak": PEAK_MFMA_BF16 / 1e12,
@@ -449,7 +482,7 @@ def main():
                          "mfma_frac": F_ALG_STEP / (gpu_ms * 1e-3) / PEAK_MFMA_BF16,
                          "t_roof_ms": 1e3 * F_ALG_STEP / PEAK_MFMA_BF16},
                 "stages": {s["name"]: {"ms_per_launch": round(s["total_ms"] / s["launches"], 4),
-                                       "launches_per_step": s["launches"] // args.steps,
+                                       "launches_per_step": s["launches"] // (args.steps * len(mine)),
                                        "tflops": round(s["flops"] / (s["total_ms"] / s["launches"] * 1e-3) / 1e12, 1),
                                        "alg_GBps": round(s["bytes"] / (s["total_ms"] / s["launches"] * 1e-3) / 1e9, 1)}
                            for s in timed},

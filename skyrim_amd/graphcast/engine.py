@@ -74,9 +74,14 @@ def _check(code: int, what: str):
 
 class GraphcastEngine:
     def __init__(self, cfg: GraphcastConfig | None = None, device: str | torch.device = "cuda:0", graph: GraphStructure | None = None,
-                 shard: tuple[int, int] = (0, 1), reduce_fn=None):
-        """``shard = (rank, world)``: grid-sharded run over ``world`` GPUs (BASELINE configs[3]) -- this engine owns a latitude band
-        of the grid (states, forcings and outputs have ``lat1 - lat0`` rows), the mesh is replicated, and the only exchange of a step
+                 shard: tuple[int, int] = (0, 1), reduce_fn=None, gather_fn=None):
+        """``shard = (rank, world)``: one forecast over ``world`` GPUs (BASELINE configs[3]).  GRID side: this engine owns a latitude
+        band of the grid (states, forcings and outputs have ``lat1 - lat0`` rows), with the grid->mesh edges its points send and the
+        mesh->grid edges they receive.  MESH side ("all-gather of the small mesh latent"): it owns a contiguous range of mesh
+        nodes with the multi-mesh edges they RECEIVE (owner computes: edge update, receiver sum, node update), and after each of the 16
+        processor layers the ranks all-gather the updated node latents (n_mesh x latent fp32 = 84 MB at full size; 0.27 ms per layer
+        over one xGMI link at 2 GPUs) -- ``gather_fn(out [world, per, latent], mine [per, latent])``, default
+        ``torch.distributed.all_gather_into_tensor``.  The other exchange of a step
         is ``reduce_fn(agg)`` = the sum over ranks of the (n_mesh, latent) aggregate of the grid->mesh messages (default:
         ``torch.distributed.all_reduce`` = RCCL over xGMI; 84 MB at full size).  ``graph``: the FULL graph (built if omitted)."""
         self.cfg = cfg or GraphcastConfig()
@@ -84,6 +89,8 @@ class GraphcastEngine:
         if not (0 <= self.rank < self.world <= self.cfg.n_lat):
             raise ValueError("shard = (rank, world) with 0 <= rank < world <= n_lat")
         self.reduce_fn = reduce_fn
+        self.gather_fn = gather_fn
+        self.shard_mesh = self.world > 1 and not os.environ.get("SKGC_REPLICATED_MESH")
         if not torch.cuda.is_available():
             raise RuntimeError("GraphcastEngine needs an MI355X: the GraphCast path has no CPU fallback")
         if self.cfg.latent % 8 != 0:
@@ -243,6 +250,19 @@ class GraphcastEngine:
             self.me_s, self.me_r, self.me_off = i32(g.mesh_edges[:, 0]), i32(g.mesh_edges[:, 1]), csr(g.mesh_edges, g.n_mesh)
             self.m2g_s, self.m2g_r, self.m2g_off = i32(g.m2g_edges[:, 0]), i32(g.m2g_edges[:, 1]), csr(g.m2g_edges, g.n_grid)
             P, E1, EM, E2 = g.n_grid, len(g.g2m_edges), len(g.mesh_edges), len(g.m2g_edges)
+            # mesh-side ownership: nodes [mn0, mn1) and the multi-mesh edges they receive (edges are sorted by receiver: one slice)
+            self.mn_per = (g.n_mesh + self.world - 1) // self.world
+            self.mn0, self.mn1 = (min(self.rank * self.mn_per, g.n_mesh), min((self.rank + 1) * self.mn_per, g.n_mesh)) if self.shard_mesh else (0, g.n_mesh)
+            off = np.zeros(g.n_mesh + 1, dtype=np.int64)
+            np.add.at(off, g.mesh_edges[:, 1] + 1, 1)
+            off = np.cumsum(off)
+            self.me0, self.me1 = int(off[self.mn0]), int(off[self.mn1])
+            if self.shard_mesh:
+                self.me_s, self.me_r = self.me_s[self.me0:self.me1].contiguous(), self.me_r[self.me0:self.me1].contiguous()
+                self.me_off = i32(off[self.mn0:self.mn1 + 1] - self.me0)
+                EM = self.me1 - self.me0
+                self.xbuf = torch.zeros(self.world, self.mn_per, L, dtype=torch.float32, device=dev)
+                self.xmine = torch.zeros(self.mn_per, L, dtype=torch.float32, device=dev)
             self.P, self.E1, self.EM, self.E2 = P, E1, EM, E2
             buf = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)  # noqa: E731
             rows_max = max(P, E1, E2, EM, g.n_mesh)
@@ -256,7 +276,7 @@ class GraphcastEngine:
             # input-independent embeddings of the structural features
             self.vm0, self.e1_0, self.em_0, self.e2_0 = buf(g.n_mesh, L), buf(E1, L), buf(EM, L), buf(E2, L)
             for name, feat, out in (("embed.mesh", g.mesh_node_feat, self.vm0), ("embed.g2m_edge", g.g2m_edge_feat, self.e1_0),
-                                    ("embed.mesh_edge", g.mesh_edge_feat, self.em_0), ("embed.m2g_edge", g.m2g_edge_feat, self.e2_0)):
+                                    ("embed.mesh_edge", g.mesh_edge_feat[self.me0:self.me1], self.em_0), ("embed.m2g_edge", g.m2g_edge_feat, self.e2_0)):
                 ft = torch.from_numpy(np.ascontiguousarray(feat)).to(dev)
                 self._mlp(name, [(ft, None, ft.shape[1])], ft.shape[0], out)
             if self.split_edges:
@@ -319,7 +339,9 @@ class GraphcastEngine:
                     dist.all_reduce(self.agg_m, op=dist.ReduceOp.SUM)
             self._mlp("g2m.mesh_node", [(self.vm0, None, L), (self.agg_m, None, L)], self.graph.n_mesh, self.vm, res=self.vm0, label="encoder")
             self._mlp("g2m.grid_node", [(self.vg, None, L)], P, self.vg, res=self.vg, label="encoder")
-            # processor on the multi-mesh
+            # processor on the multi-mesh: this rank's node range and the edges it receives (everything, on one GPU)
+            nl = self.mn1 - self.mn0
+            vm_own, agg_own = self.vm[self.mn0:self.mn1], self.agg_m[self.mn0:self.mn1]
             self.em.copy_(self.em_0)
             for i in range(c.steps):
                 de = self.de
@@ -327,8 +349,20 @@ class GraphcastEngine:
                     self._edge_mlp(f"proc.{i}.edge", self.em, self.vm, self.me_s, self.vm, self.me_r, self.EM, de, label="processor")
                 else:
                     self._mlp(f"proc.{i}.edge", [(self.em, None, L), (self.vm, self.me_s, L), (self.vm, self.me_r, L)], self.EM, de, label="processor")
-                self._segsum(de, self.me_off, self.agg_m, self.graph.n_mesh, acc=self.em)      # receiver sum; em += de rides along
-                self._mlp(f"proc.{i}.node", [(self.vm, None, L), (self.agg_m, None, L)], self.graph.n_mesh, self.vm, res=self.vm, label="processor")
+                self._segsum(de, self.me_off, agg_own, nl, acc=self.em)                      # receiver sum; em += de rides along
+                self._mlp(f"proc.{i}.node", [(vm_own, None, L), (agg_own, None, L)], nl, vm_own, res=vm_own, label="processor")
+                if self.shard_mesh:                  # all-gather of the updated node latents (84 MB at full size)
+                    self._mark("exchange")
+                    self.xmine[:nl].copy_(vm_own)
+                    if self.gather_fn is not None:
+                        self.gather_fn(self.xbuf, self.xmine)
+                    else:
+                        import torch.distributed as dist
+                        dist.all_gather_into_tensor(self.xbuf.view(self.world * self.mn_per, L), self.xmine)
+                    for r in range(self.world):
+                        n0, n1 = min(r * self.mn_per, self.graph.n_mesh), min((r + 1) * self.mn_per, self.graph.n_mesh)
+                        if r != self.rank and n1 > n0:
+                            self.vm[n0:n1].copy_(self.xbuf[r, :n1 - n0])
             # decoder: mesh -> grid
             if self.split_edges:
                 self._edge_mlp("m2g.edge", self.e2_0, self.vm, self.m2g_s, self.vg, self.m2g_r, self.E2, self.e2, label="decoder")

@@ -5,8 +5,15 @@ GPU and averages them, /root/reference/skyrim/core/models/ensemble.py:51-67,73-1
 here are "mean over a new member dimension".  The rollout of a member needs no communication at all;
 the only exchange is the reduction that forms the ensemble mean / spread of a saved step:
 
-    mean   = all_reduce(sum_local(x)) / M
-    spread = sqrt(all_reduce(sum_local((x - mean)^2)) / M)          (two-pass: no cancellation)
+    mean   = sum_over_ranks(sum_local(x)) / M
+    spread = sqrt(sum_over_ranks(sum_local((x - mean)^2)) / M)          (two-pass: no cancellation -- the members of a perturbed-
+                                                                         IC ensemble differ by 1e-3 of a standard deviation)
+
+``sum_over_ranks`` is either a ring ``all_reduce`` or -- the default on the 8-GPU xGMI full mesh, SURVEY.md 5 -- an
+``all_gather`` of the per-rank partial sums followed by a local reduction: every rank sends its 286 MB partial to its 7 peers
+over 7 links at once (1.9 ms at 153 GB/s per link) instead of pushing 2 (N-1)/N of it around a ring (3.3 ms), and the result is
+bit-identical on every rank (same summation order).  BASELINE configs[4] (50 members on 8 GPUs, "all-gather of outputs"): members
+round-robin 7,7,6,6,6,6,6,6; per SAVED step one reduction for mean / spread and optionally one all-gather of the member states.
 
 ``torch.distributed`` with backend "nccl" is RCCL over xGMI on ROCm; "gloo" is used by the CPU tests.
 """
@@ -25,25 +32,55 @@ def _world():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
-def ensemble_mean_spread(local_states: list[torch.Tensor], n_members: int) -> tuple[torch.Tensor, torch.Tensor]:
+def sum_over_ranks(t: torch.Tensor, how: str = "allgather") -> torch.Tensor:
+    """Sum of one tensor per rank, on every rank, in place.  "allgather": all_gather of the partials + local sum in rank order
+    (direct exchange over the xGMI full mesh; identical bits on every rank); "allreduce": ring all-reduce."""
+    w = _world()
+    if w == 1:
+        return t
+    if how == "allreduce":
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return t
+    if how != "allgather":
+        raise ValueError("how is 'allgather' or 'allreduce'")
+    parts = torch.empty((w,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+    dist.all_gather_into_tensor(parts, t.contiguous()[None])          # concatenation form along dim 0 (the one every backend implements)
+    torch.sum(parts, dim=0, out=t)
+    return t
+
+
+def ensemble_mean_spread(local_states: list[torch.Tensor], n_members: int, how: str = "allgather") -> tuple[torch.Tensor, torch.Tensor]:
     """Ensemble mean and spread (population std) of states sharded over ranks.
 
-    ``local_states``: this rank's member states (same shape each; may be empty on a rank that owns
-    no member).  Every rank returns the full mean / spread.
+    ``local_states``: this rank's member states (same shape each).  Every rank returns the full mean / spread.
     """
-    if local_states:
-        s = torch.stack(local_states).sum(0)
-    else:
+    if not local_states:
         raise ValueError("every rank must own at least one member (use world_size <= n_members)")
-    if _world() > 1:
-        dist.all_reduce(s, op=dist.ReduceOp.SUM)
-    mean = s / n_members
+    s = torch.stack(local_states).sum(0) if len(local_states) > 1 else local_states[0].clone()
+    mean = sum_over_ranks(s, how) / n_members
     sq = torch.zeros_like(mean)
     for x in local_states:
         sq += (x - mean) ** 2
-    if _world() > 1:
-        dist.all_reduce(sq, op=dist.ReduceOp.SUM)
-    return mean, (sq / n_members).sqrt()
+    return mean, (sum_over_ranks(sq, how) / n_members).sqrt()
+
+
+def gather_members(local_states: list[torch.Tensor], n_members: int) -> torch.Tensor:
+    """All member states on every rank, ordered by member id: (n_members, ...).  One all-gather of ceil(M / world) slots per rank
+    (ranks owning one member less send a zero slot)."""
+    w = _world()
+    per = (n_members + w - 1) // w
+    local = torch.stack(local_states + [torch.zeros_like(local_states[0])] * (per - len(local_states)))
+    if w > 1:
+        buf = torch.empty((w * per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(buf, local)
+        buf = buf.view((w, per) + tuple(local.shape[1:]))
+    else:
+        buf = local[None]
+    states = [None] * n_members
+    for r in range(w):
+        for j, m in enumerate(member_shard(n_members, r, w)):
+            states[m] = buf[r, j]
+    return torch.stack(states)
 
 
 def rollout_members(step_fn, initial_states: list[torch.Tensor], n_steps: int) -> list[torch.Tensor]:
@@ -81,24 +118,24 @@ class MemberParallelEnsemble:
             raise ValueError("more ranks than ensemble members")
         self.members = member_shard(n_members, self.rank, self.world)
 
-    def run(self, x0: torch.Tensor, n_steps: int, gather: bool = False) -> dict:
+    def steps(self, x0: torch.Tensor, n_steps: int, save_every: int = 1, gather: bool = False, how: str = "allgather"):
+        """Generator over the SAVED steps of the ensemble rollout (BASELINE configs[4]): every local member advances ``save_every``
+        model steps without any communication, then one reduction forms the ensemble mean / spread of that lead time and, with
+        ``gather``, one all-gather collects the member states.  Yields dicts {"step", "mean", "spread", "local_states"[, "members"]}."""
+        states = [perturbed_member(x0, self.std, m, self.scale) for m in self.members]
+        for k in range(1, n_steps + 1):
+            states = [self.step_fn(x) for x in states]
+            if k % save_every == 0 or k == n_steps:
+                mean, spread = ensemble_mean_spread(states, self.n_members, how)
+                out = {"step": k, "mean": mean, "spread": spread, "local_members": self.members, "local_states": states}
+                if gather:
+                    out["members"] = gather_members(states, self.n_members)
+                yield out
+
+    def run(self, x0: torch.Tensor, n_steps: int, gather: bool = False, how: str = "allgather") -> dict:
         """Roll every local member ``n_steps`` forward.  Returns the ensemble mean and spread of the final states
         (identical on every rank) and, with ``gather``, all member states ordered by member id (all-gather)."""
-        ics = [perturbed_member(x0, self.std, m, self.scale) for m in self.members]
-        finals = rollout_members(self.step_fn, ics, n_steps)
-        mean, spread = ensemble_mean_spread(finals, self.n_members)
-        out = {"mean": mean, "spread": spread, "local_members": self.members, "local_states": finals}
-        if gather:
-            per = (self.n_members + self.world - 1) // self.world
-            local = torch.stack(finals + [torch.zeros_like(finals[0])] * (per - len(finals)))
-            if self.world > 1:
-                buf = [torch.empty_like(local) for _ in range(self.world)]
-                dist.all_gather(buf, local)
-            else:
-                buf = [local]
-            states = [None] * self.n_members
-            for r in range(self.world):
-                for j, m in enumerate(member_shard(self.n_members, r, self.world)):
-                    states[m] = buf[r][j]
-            out["members"] = torch.stack(states)
-        return out
+        last = None
+        for last in self.steps(x0, n_steps, save_every=n_steps, gather=gather, how=how):
+            pass
+        return last

@@ -88,6 +88,11 @@ def _ens_worker(rank, world, port, q):
         x0 = torch.arange(2 * 4 * 6, dtype=torch.float32).reshape(2, 4, 6)
         ens = MemberParallelEnsemble(lambda x: 0.5 * x + 1.0, 5, torch.tensor([1.0, 2.0]), perturb_scale=0.1)
         out = ens.run(x0, 2, gather=True)
+        # per saved step (BASELINE configs[4]): both reduction forms agree, the gathered members of step 1 are the rolled ICs
+        saved = list(ens.steps(x0, 2, save_every=1, gather=True, how="allreduce"))
+        assert [s_["step"] for s_ in saved] == [1, 2] and torch.allclose(saved[1]["mean"], out["mean"], rtol=1e-6)
+        assert torch.allclose(saved[1]["spread"], out["spread"], rtol=1e-4, atol=1e-6) and torch.equal(saved[1]["members"], out["members"])
+        assert saved[0]["members"].shape == (5, 2, 4, 6)
         q.put((rank, out["mean"].numpy(), out["spread"].numpy(), out["members"].numpy(), out["local_members"]))
     finally:
         dist.destroy_process_group()

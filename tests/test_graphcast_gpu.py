@@ -109,11 +109,26 @@ def test_grid_sharded_step_equals_the_single_gpu_step(world):
         torch.cuda.synchronize()
         barrier.wait()
 
+    slots, gathers = {}, []
+
+    def gather_fn(out, mine):                    # all-gather of the mesh latents after every processor layer
+        torch.cuda.synchronize()
+        me = threading.current_thread().name
+        with lock:
+            slots[me] = mine.clone()
+            gathers.append(mine.numel())
+        barrier.wait()
+        for r in range(world):
+            out[r].copy_(slots[f"rank{r}"])
+        torch.cuda.synchronize()
+        barrier.wait()
+
     outs, errs = [None] * world, []
 
     def run(r):
         try:
-            e = GraphcastEngine(cfg, "cuda:0", graph=full, shard=(r, world), reduce_fn=reduce_fn)
+            e = GraphcastEngine(cfg, "cuda:0", graph=full, shard=(r, world), reduce_fn=reduce_fn, gather_fn=gather_fn)
+            assert e.shard_mesh
             e.load_params(p)
             sl = slice(e.lat0, e.lat1)
             outs[r] = e.step(x0[:, sl].contiguous().cuda(), x1[:, sl].contiguous().cuda(), f[:, sl].contiguous().cuda()).cpu()
@@ -121,12 +136,14 @@ def test_grid_sharded_step_equals_the_single_gpu_step(world):
             errs.append(ex)
             barrier.abort()
 
-    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    threads = [threading.Thread(target=run, args=(r,), name=f"rank{r}") for r in range(world)]
     [t.start() for t in threads]
     [t.join() for t in threads]
     assert not errs, errs
     got = torch.cat(outs, dim=1)
     assert got.shape == want.shape and exchanged == [full.n_mesh * cfg.latent] * world
+    per = (full.n_mesh + world - 1) // world
+    assert gathers == [per * cfg.latent] * (world * cfg.steps)               # one all-gather of the node latents per processor layer
     assert O.increment_rel_err(got, want, x1).max().item() < 1e-4          # summation order of the aggregate differs, nothing else
 
 
@@ -249,3 +266,69 @@ def test_ten_day_rollout_stays_inside_the_bar():
         worst = max(worst, e)
         assert e < 1e-3, (k, e)
     assert torch.isfinite(b).all() and worst < 1e-4, worst
+
+
+def _sharded_worker(rank, world, port, q):
+    """One process per rank, BOTH on GPU 0 (a 1-GPU box), gloo as the transport: the collectives are staged through the host."""
+    import os
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from skyrim_amd.graphcast.engine import GraphcastEngine
+
+        def reduce_fn(t):                            # gloo moves host memory
+            h = t.cpu()
+            dist.all_reduce(h)
+            t.copy_(h)
+
+        def gather_fn(out, mine):
+            h = torch.empty(out.shape, dtype=out.dtype)
+            dist.all_gather_into_tensor(h.view(-1, h.shape[-1]), mine.cpu())
+            out.copy_(h)
+
+        cfg = CONFIGS["tiny"]
+        p = init_synthetic(cfg, 0)
+        x0, x1 = synthetic_states(cfg, 0)
+        f = forcings(cfg, 1000.0)
+        e = GraphcastEngine(cfg, "cuda:0", shard=(rank, world), reduce_fn=reduce_fn, gather_fn=gather_fn)
+        e.load_params(p)
+        sl = slice(e.lat0, e.lat1)
+        a, b = x0[:, sl].contiguous().cuda(), x1[:, sl].contiguous().cuda()
+        for k in range(2):                           # two autoregressive steps: each rank keeps feeding its own band back
+            a, b = b, e.step(a, b, forcings(cfg, 1000.0 + 6.0 * k)[:, sl].contiguous().cuda())
+        q.put((rank, e.lat0, e.lat1, b.cpu().numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_process_sharded_rollout_matches_the_single_gpu_rollout():
+    """BASELINE configs[3] control flow with real processes and a real process group: 2 ranks (on this box both on GPU 0, gloo),
+    latitude bands + mesh-node ranges, one all-reduce and 16 all-gathers per step, two steps; against one unsharded engine."""
+    import socket
+    import torch.multiprocessing as mp
+    from skyrim_amd.graphcast.engine import GraphcastEngine
+    world = 2
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sharded_worker, args=(r, world, port, q)) for r in range(world)]
+    [p_.start() for p_ in procs]
+    got = sorted([q.get(timeout=500) for _ in range(world)], key=lambda t: t[0])
+    for p_ in procs:
+        p_.join(60)
+        assert p_.exitcode == 0
+    cfg = CONFIGS["tiny"]
+    p = init_synthetic(cfg, 0)
+    x0, x1 = synthetic_states(cfg, 0)
+    single = GraphcastEngine(cfg, "cuda:0")
+    single.load_params(p)
+    a, b = x0.cuda(), x1.cuda()
+    for k in range(2):
+        a, b = b, single.step(a, b, forcings(cfg, 1000.0 + 6.0 * k).cuda())
+    out = torch.cat([torch.from_numpy(g[3]) for g in got], dim=1)
+    assert got[0][1] == 0 and got[0][2] == got[1][1] and got[1][2] == cfg.n_lat
+    assert O.increment_rel_err(out, b.cpu(), x1).max().item() < 1e-4
