@@ -250,13 +250,51 @@ def auto_map(model: Model, geom: PanguGeometry, window: int = 16) -> tuple[dict,
     return mapping, [s for (s, _), tk in zip(slots, taken) if not tk]
 
 
-def convert(path, geom: PanguGeometry, mapping: dict | None = None, extra: dict | None = None) -> dict:
-    """-> {slot: float32 ndarray} for every slot of ``param_spec(geom)``.  ``mapping`` as produced by ``auto_map`` (the
-    default) or written by hand; ``extra`` supplies arrays for slots that are not in the file (e.g. normalisation stats).
+def validate(arrays: dict) -> list[str]:
+    """Plausibility of a converted parameter set, slot class by slot class -- what a WRONG slot assignment (several slots of a block
+    share a shape: proj.bias, norm1.weight, norm1.bias, fc2.bias, norm2.* are all (C,)) or a wrong layout would break:
+    LayerNorm gains centred near 1 and positive, LayerNorm / linear biases centred near 0, weight matrices with a small non-zero
+    spread, finite bias tables, positive normalisation stds.  Returns the list of complaints (empty = plausible).  It cannot prove a
+    mapping right: the qkv split order and the bias_table index layout have only been checked against a synthetic Pangu-shaped file."""
+    bad = []
+    for name, a in arrays.items():
+        a = np.asarray(a, dtype=np.float64)
+        if not np.isfinite(a).all():
+            bad.append(f"{name}: non-finite values")
+            continue
+        if name.endswith(("norm.weight", "norm1.weight", "norm2.weight")):
+            if not (0.2 < a.mean() < 5.0) or (a <= 0).mean() > 0.1:
+                bad.append(f"{name}: LayerNorm gain with mean {a.mean():.3g}, {100 * (a <= 0).mean():.0f}% non-positive (a bias in a gain slot?)")
+        elif name.endswith(("norm.bias", "norm1.bias", "norm2.bias")) or (name.endswith(".bias") and a.ndim == 1 and not name.startswith("norm.")):
+            if abs(a.mean()) > 0.5 and abs(a.mean()) > 3 * a.std():
+                bad.append(f"{name}: bias centred at {a.mean():.3g} (a LayerNorm gain in a bias slot?)")
+        elif name.endswith(".weight") and a.ndim >= 2:
+            if not (1e-5 < a.std() < 2.0):
+                bad.append(f"{name}: weight spread {a.std():.3g}")
+        elif name.endswith("bias_table") and np.abs(a).max() > 100.0:
+            bad.append(f"{name}: |entry| up to {np.abs(a).max():.3g}")
+        elif name == "norm.std" and (a <= 0).any():
+            bad.append("norm.std: non-positive entries")
+    return bad
+
+
+def convert(path, geom: PanguGeometry, mapping: dict | None = None, extra: dict | None = None, allow_auto: bool | None = None) -> dict:
+    """-> {slot: float32 ndarray} for every slot of ``param_spec(geom)``.  ``mapping``: {slot: onnx name | [name, transform]}, written
+    by hand or produced by ``auto_map`` and REVIEWED (``python -m skyrim_amd.pangu.onnx_weights automap FILE > FILE.map.json``);
+    ``extra`` supplies arrays for slots that are not in the file (e.g. normalisation stats).  Without a mapping the automatic one is
+    used only when ``allow_auto`` (or SKYRIM_ONNX_AUTOMAP=1) says so: it assigns by shape and order of use, and a block has many
+    slots of identical shape, so a fully resolved mapping can still be wrong.  Every result is checked by ``validate``.
     Raises if any slot stays empty: a partially loaded network must not run."""
+    import os
     model = read_model(path)
     unresolved = []
     if mapping is None:
+        if allow_auto is None:
+            allow_auto = os.environ.get("SKYRIM_ONNX_AUTOMAP") == "1"
+        if not allow_auto:
+            raise ValueError(f"{path}: no slot mapping given.  Write one with `python -m skyrim_amd.pangu.onnx_weights automap {path} > {path}.map.json`, "
+                             "review it against `... inspect`, and load again (PanguTimeLoop reads <file>.map.json); or opt into the unreviewed "
+                             "automatic mapping with SKYRIM_ONNX_AUTOMAP=1 / allow_auto=True")
         mapping, unresolved = auto_map(model, geom)
     out = {}
     for slot, shape in param_spec(geom):
@@ -272,6 +310,9 @@ def convert(path, geom: PanguGeometry, mapping: dict | None = None, extra: dict 
     if missing:
         raise ValueError(f"{len(missing)} parameter slots unresolved (first: {missing[:6]}); "
                          f"inspect the file and pass an explicit mapping / extra arrays")
+    bad = validate(out)
+    if bad:
+        raise ValueError(f"{path}: the converted parameters look wrong in {len(bad)} slot(s) -- a mis-assigned mapping? " + "; ".join(bad[:6]))
     return out
 
 

@@ -37,12 +37,20 @@ class SfnoTimeLoop:
         self.cfg = cfg or SfnoConfig()
         self.engine = SfnoEngine(self.cfg, device)
         if params is None:
-            params = weights.resolve("SKYRIM_SFNO_WEIGHTS", lambda p: torch.load(p, map_location="cpu"), lambda: init_synthetic(self.cfg, seed), "fourcastnet_v2")
+            params = weights.resolve("SKYRIM_SFNO_WEIGHTS", self._load, lambda: init_synthetic(self.cfg, seed), "fourcastnet_v2")
         self.engine.load_params(params)
         names = CHANNELS if self.cfg.in_chans == len(CHANNELS) else [f"c{i}" for i in range(self.cfg.in_chans)]
         self.in_channel_names = list(names)
         self.out_channel_names = list(names[: self.cfg.out_chans])
         self.grid = Grid(list(np.linspace(90.0, -90.0, self.cfg.n_lat)), list(np.arange(self.cfg.n_lon) * (360.0 / self.cfg.n_lon)))
+
+    def _load(self, path: str) -> dict:
+        """A torch file of the slot dict (``spec.param_spec``), or the reference's own package: a directory holding ``weights.tar``,
+        ``global_means.npy`` and ``global_stds.npy`` (earth2mip's fcnv2_sm layout), mapped by ``checkpoint.convert``."""
+        if os.path.isdir(path):
+            from . import checkpoint
+            return checkpoint.load(os.path.join(path, "weights.tar"), self.cfg, os.path.join(path, "global_means.npy"), os.path.join(path, "global_stds.npy"))
+        return torch.load(path, map_location="cpu")
 
     @property
     def device(self):

@@ -132,7 +132,9 @@ def test_auto_map_and_convert_reproduce_the_parameters(toy_onnx):
     assert unresolved == []
     assert {s: v[0] for s, v in mapping.items()} == truth
     assert mapping["layer1.block0.attn.proj.weight"][1] == "T"          # square weight: decided by the consuming MatMul
-    got = OW.convert(path, g)
+    with pytest.raises(ValueError, match="no slot mapping given"):
+        OW.convert(path, g)                                                # the shape-and-order mapping is never applied silently
+    got = OW.convert(path, g, allow_auto=True)
     assert list(got) == [s for s, _ in param_spec(g)]
     for slot, _ in param_spec(g):
         assert np.array_equal(got[slot], params[slot].numpy()), slot
@@ -164,3 +166,19 @@ def test_cli_inspect_and_automap(toy_onnx, capsys):
     OW.main(["automap", str(path)])       # maps the toy file against the full-size geometry: shapes with lat/lon do not fit
     rep = json.loads(capsys.readouterr().out)
     assert "const_masks" in rep["unresolved"] and "layer1.block0.attn.qkv.weight" in rep["mapping"]
+
+
+def test_validation_catches_a_swapped_gain_and_bias(toy_onnx):
+    """A fully resolved mapping can still be wrong: norm1.weight and norm1.bias (and proj.bias, fc2.bias, norm2.*) share the shape
+    (C,).  Swapping two of them passes every shape check; ``validate`` refuses the result (onnx_weights.py:230)."""
+    g, params, path, truth = toy_onnx
+    mapping = {s: [n, "T" if n.startswith("onnx::MatMul") else "id"] for s, n in truth.items()}
+    ok = OW.convert(path, g, mapping)
+    assert OW.validate(ok) == []
+    swapped = dict(mapping)
+    swapped["layer1.block0.norm1.weight"], swapped["layer1.block0.norm1.bias"] = mapping["layer1.block0.norm1.bias"], mapping["layer1.block0.norm1.weight"]
+    with pytest.raises(ValueError, match="look wrong"):
+        OW.convert(path, g, swapped)
+    bad = dict(ok)
+    bad["layer2.block1.attn.bias_table"] = ok["layer2.block1.attn.bias_table"] * np.float32(np.inf)
+    assert any("non-finite" in b for b in OW.validate(bad))
