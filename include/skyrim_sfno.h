@@ -14,7 +14,7 @@
 extern "C" {
 #endif
 
-#define SKSFNO_ABI_VERSION 2
+#define SKSFNO_ABI_VERSION 1
 #define SKSFNO_E_ARG (-1) /* bad argument */
 #define SKSFNO_E_HIP (-2) /* a HIP call failed */
 
@@ -66,11 +66,6 @@ int sksfno_gemm_run(const sksfno_gemm* desc, void* stream);
 
 /* out[c][i] = (x[c][i] - mean_c) * rsqrt(var_c + eps) * gamma[c] + beta[c] over i < HW (biased variance), c < C */
 int sksfno_instance_norm(const float* x, const float* gamma, const float* beta, float* out, int C, long long HW, float eps, void* stream);
-
-/* The same statistics without the apply pass: scale[c] = gamma[c] * rsqrt(var_c + eps), shift[c] = beta[c] - mean_c * scale[c], so that
- * a consumer whose contraction index is the channel (a 1x1 convolution) normalises in its loader (sksfno_gemm.a_kscale / a_kshift)
- * and the normalised tensor is never written: one read instead of two reads + one write. */
-int sksfno_instance_norm_stats(const float* x, const float* gamma, const float* beta, float* scale, float* shift, int C, long long HW, float eps, void* stream);
 
 #ifdef __cplusplus
 }

@@ -57,11 +57,10 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 }
 
 __global__ void __launch_bounds__(1024) instance_norm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
-                                                             const float* __restrict__ beta, float* __restrict__ out, long long HW, float eps,
-                                                             float* __restrict__ scale_out, float* __restrict__ shift_out) {
+                                                             const float* __restrict__ beta, float* __restrict__ out, long long HW, float eps) {
     __shared__ float red[16];
     const float* xc = x + (long long)blockIdx.x * HW;
-    float* oc = out ? out + (long long)blockIdx.x * HW : nullptr;
+    float* oc = out + (long long)blockIdx.x * HW;
     const bool v4 = (HW & 3) == 0;
     // one pass for both moments, shifted by the channel's first value (var = E[(x-p)^2] - E[x-p]^2 keeps its digits as long as
     // |mean - p| is a few standard deviations): 2 reads + 1 write of the tensor instead of 3 + 1
@@ -82,10 +81,6 @@ __global__ void __launch_bounds__(1024) instance_norm_kernel(const float* __rest
     const float mean = pv + m1;
     const float rstd = rsqrtf(fmaxf(m2 - m1 * m1, 0.f) + eps);
     const float g = gamma[blockIdx.x] * rstd, b = beta[blockIdx.x] - mean * g;
-    if (out == nullptr) {                       // statistics only: the consumer applies x * scale[c] + shift[c] in its loader
-        if (threadIdx.x == 0) { scale_out[blockIdx.x] = g; shift_out[blockIdx.x] = b; }
-        return;
-    }
     if (v4) {
         for (long long i = threadIdx.x; i < HW / 4; i += blockDim.x) {
             const float4 v = reinterpret_cast<const float4*>(xc)[i];
@@ -143,13 +138,7 @@ int sksfno_gemm_run(const sksfno_gemm* d, void* stream) {
 
 int sksfno_instance_norm(const float* x, const float* gamma, const float* beta, float* out, int C, long long HW, float eps, void* stream) {
     if (!x || !gamma || !beta || !out || C <= 0 || HW <= 0) return SKSFNO_E_ARG;
-    hipLaunchKernelGGL(instance_norm_kernel, dim3(C), dim3(1024), 0, static_cast<hipStream_t>(stream), x, gamma, beta, out, HW, eps, (float*)nullptr, (float*)nullptr);
-    return hipGetLastError() == hipSuccess ? 0 : SKSFNO_E_HIP;
-}
-
-int sksfno_instance_norm_stats(const float* x, const float* gamma, const float* beta, float* scale, float* shift, int C, long long HW, float eps, void* stream) {
-    if (!x || !gamma || !beta || !scale || !shift || C <= 0 || HW <= 0) return SKSFNO_E_ARG;
-    hipLaunchKernelGGL(instance_norm_kernel, dim3(C), dim3(1024), 0, static_cast<hipStream_t>(stream), x, gamma, beta, (float*)nullptr, HW, eps, scale, shift);
+    hipLaunchKernelGGL(instance_norm_kernel, dim3(C), dim3(1024), 0, static_cast<hipStream_t>(stream), x, gamma, beta, out, HW, eps);
     return hipGetLastError() == hipSuccess ? 0 : SKSFNO_E_HIP;
 }
 

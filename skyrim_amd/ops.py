@@ -7,7 +7,7 @@ dispatcher -- there is no CPU fallback.  Outputs are written in place into calle
 are stream-ordered, allocation-free and capturable in a HIP graph.
 
     pangu_step / pangu_patch_embed / pangu_block / pangu_downsample / pangu_upsample / pangu_patch_recover     (ctx = skpangu_ctx*)
-    sfno_gemm / sfno_instance_norm / sfno_instance_norm_stats
+    sfno_gemm / sfno_instance_norm
     gc_gather_gemm / gc_linear_layer_norm / gc_sum_linear_layer_norm / gc_layer_norm / gc_segment_sum
 """
 from __future__ import annotations
@@ -117,14 +117,6 @@ def _sfno_instance_norm(x, gamma, beta, out, C: int, HW: int, eps: float) -> Non
             "sksfno_instance_norm")
 
 
-def _sfno_instance_norm_stats(x, gamma, beta, scale, shift, C: int, HW: int, eps: float) -> None:
-    from .sfno import engine
-    lib = engine.load_library()
-    with torch.cuda.device(x.device):
-        _ok(lib.sksfno_instance_norm_stats(_f32(x, "x"), _f32(gamma, "gamma", x.device), _f32(beta, "beta", x.device), _f32(scale, "scale", x.device),
-                                           _f32(shift, "shift", x.device), C, HW, eps, _stream(x)), "sksfno_instance_norm_stats")
-
-
 # ---- GraphCast -------------------------------------------------------------------------------------------------------------- #
 def _gc_gather_gemm(src, idx, width, w, w_plane: int, ldw: int, bias, out, M: int, N: int, act: int, kscale, kshift) -> None:
     from .graphcast import engine
@@ -208,7 +200,6 @@ _SCHEMAS = [
     ("sfno_gemm(Tensor a, Tensor w, Tensor(a!) out, Tensor? bias, Tensor? res_pre, Tensor? res_post, Tensor? a_kscale, Tensor? a_kshift, Tensor? a2, int[] geom) -> ()",
      _sfno_gemm),
     ("sfno_instance_norm(Tensor x, Tensor gamma, Tensor beta, Tensor(a!) out, int C, int HW, float eps) -> ()", _sfno_instance_norm),
-    ("sfno_instance_norm_stats(Tensor x, Tensor gamma, Tensor beta, Tensor(a!) scale, Tensor(b!) shift, int C, int HW, float eps) -> ()", _sfno_instance_norm_stats),
     ("gc_gather_gemm(Tensor[] src, Tensor?[] idx, int[] width, Tensor w, int w_plane, int ldw, Tensor bias, Tensor(a!) out, int M, int N, int act, "
      "Tensor? kscale, Tensor? kshift) -> ()", _gc_gather_gemm),
     ("gc_linear_layer_norm(Tensor a, int lda, int K, Tensor w, int w_plane, int ldw, Tensor bias, Tensor gamma, Tensor beta, Tensor? res, Tensor(a!) out, int rows) -> ()",

@@ -27,7 +27,7 @@ from .sht import ShtMatrices
 from .spec import SfnoConfig, param_spec
 
 _LIB_PATH = Path(__file__).resolve().parent.parent / "lib" / "libskyrim_sfno.so"
-EXPORTS = ["sksfno_abi_version", "sksfno_prepare_weight", "sksfno_gemm_run", "sksfno_instance_norm", "sksfno_instance_norm_stats"]
+EXPORTS = ["sksfno_abi_version", "sksfno_prepare_weight", "sksfno_gemm_run", "sksfno_instance_norm"]
 
 
 class GemmDesc(ctypes.Structure):
@@ -60,7 +60,6 @@ def load_library():
     lib.sksfno_gemm_run.argtypes = [ctypes.POINTER(GemmDesc), ctypes.c_void_p]
     lib.sksfno_instance_norm.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
                                          ctypes.c_longlong, ctypes.c_float, ctypes.c_void_p]
-    lib.sksfno_instance_norm_stats.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_int, ctypes.c_longlong, ctypes.c_float, ctypes.c_void_p]
     for name in EXPORTS:
         getattr(lib, name).restype = ctypes.c_int
     _lib = lib
@@ -190,7 +189,6 @@ class SfnoEngine:
             self.b_coef = buf(c.lmax * c.mmax * 2 * e)
             self.b_mixed = torch.zeros(c.lmax * c.mmax * 2 * e, dtype=torch.float32, device=dev)     # rows m > l are never written
             self.b_out = buf(c.out_chans * hw_o)
-            self.n_scale, self.n_shift = buf(e), buf(e)
             torch.cuda.current_stream(dev).synchronize()
         self.prepared = True
 
@@ -228,11 +226,6 @@ class SfnoEngine:
     def _norm(self, x, g, b, out, C, HW):
         self._mark("norm", 8.0 * C * HW, 16.0 * C * HW)
         ops.hip.sfno_instance_norm(x, g, b, out, C, HW, self.cfg.eps)
-
-    def _norm_stats(self, x, g, b, C, HW):
-        """Instance-norm statistics only -> (scale, shift) per channel for the consuming 1x1 convolution's loader."""
-        self._mark("norm", 2.0 * C * HW, 4.0 * C * HW)
-        ops.hip.sfno_instance_norm_stats(x, g, b, self.n_scale, self.n_shift, C, HW, self.cfg.eps)
 
     def _pointwise(self, a, W, out, hw, cin, cout, label="conv1x1", **kw):
         """1x1 convolution on [C][hw] activations: rows = pixels (contiguous), k = channel (stride hw)."""
@@ -297,11 +290,9 @@ class SfnoEngine:
                 # GELU(filter output + inner skip(residual))
                 outer = "_outer" if tout is self.tr["outer"] else ""
                 self._pointwise(res, blk["skip"], self.b_y, hw_out, e, e, label="inner_skip" + outer, bias=blk["skip_b"], res_pre=self.b_sp, act=1)
-                # norm1 feeds only the MLP's first 1x1 convolution (k = channel): statistics here, the apply in that GEMM's loader
-                self._norm_stats(self.b_y, blk["n1_g"], blk["n1_b"], e, hw_out)
+                self._norm(self.b_y, blk["n1_g"], blk["n1_b"], self.b_sp, e, hw_out)
                 hbuf = self.b_hid_outer if tout is self.tr["outer"] else self.b_hid
-                self._pointwise(self.b_y, blk["fc1"], hbuf, hw_out, e, hid, label="mlp" + outer, bias=blk["fc1_b"], act=1,
-                                a_kscale=self.n_scale, a_kshift=self.n_shift)
+                self._pointwise(self.b_sp, blk["fc1"], hbuf, hw_out, e, hid, label="mlp" + outer, bias=blk["fc1_b"], act=1)
                 self._pointwise(hbuf, blk["fc2"], self.b_y, hw_out, hid, e, label="mlp" + outer, bias=blk["fc2_b"], res_post=res)
                 cur = self.b_y
             # decoder on concat(cur, normalised input): W_a cur + b' , then GELU(W_b' x + .), then W2' . + mean

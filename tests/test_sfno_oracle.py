@@ -101,7 +101,7 @@ def test_sfno_library_exports_declared_symbols_and_rejects_bad_arguments():
     syms = sorted(set(re.findall(r"\b(sksfno_[a-z_]+)\s*\(", header)))
     lib = E.load_library()
     assert set(syms) == set(E.EXPORTS) and all(hasattr(lib, s) for s in syms)
-    assert lib.sksfno_abi_version() == 2
+    assert lib.sksfno_abi_version() == 1
     assert lib.sksfno_gemm_run(None, None) == -1
     d = E.GemmDesc()
     assert lib.sksfno_gemm_run(ctypes.byref(d), None) == -1                       # null pointers / zero sizes
