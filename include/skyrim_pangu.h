@@ -57,8 +57,9 @@ typedef struct skpangu_config {
                       (roll3D(x, shift=[wz/2, wh/2, ww/2]) as the pseudocode's call is written).  The masked window follows. */
     int pad_mode;  /* SKPANGU_PAD_* for every zero padding on the path (input latitude, window latitude, 2x2 merge) */
     float mask_value; /* additive shifted-window mask; 0 = default -100 (Swin); the pseudocode's comment suggests -1000 */
-    int mlp_mode;  /* 0 (default): fc1 -> GELU -> fc2 -> LayerNorm -> residual as ONE kernel in the 3-term modes (the hidden activation
-                      never reaches HBM); 1: two tiled GEMMs with the hidden as hi/lo planes in HBM (the round-1 path) */
+    int mlp_mode;  /* 0 (default): the row-tile kernels -- fc1 -> GELU -> fc2 -> LayerNorm -> residual as ONE kernel in the 3-term modes (the
+                      hidden activation never reaches HBM), proj + LayerNorm + residual and the 2-term QKV with the token rows in
+                      registers; 1: every linear as a tiled LDS-DMA GEMM (the round-1 path) */
 } skpangu_config;
 
 typedef struct skpangu_sizes {

@@ -124,6 +124,7 @@ struct Engine : IEngine {
     size_t q_elems = 0, ao_elems = 0, hid_elems = 0;
     int hid16 = 0;            // fp16-hidden mode (bf16x3 engines only)
     bool fused_mlp = false;   // one-kernel MLP (fused_mlp.hip): 3-term modes with the hidden as hi/lo pair
+    bool rt_proj = false, rt_qkv = false;   // row-tile proj / QKV kernels (rowtile.hip)
     T* zrow = nullptr;
 
     // ---- per-stage timing with HIP events on the launch stream (bench.py roofline leg) ---- //
@@ -220,6 +221,8 @@ struct Engine : IEngine {
                 if (hid16 && !std::is_same<T, f16>::value) { bw.fc2h.plane = (long long)c * 4 * c; bw.fc2h.w = a.take<f16>((size_t)bw.fc2h.plane * 2); }
                 bw.w1f = fused_mlp ? a.take<T>((size_t)8 * c * c) : nullptr;      // 4c x c elements, hi + lo
                 bw.w2f = fused_mlp ? a.take<T>((size_t)8 * c * c) : nullptr;
+                bw.projf = rt_proj ? a.take<T>((size_t)2 * c * c) : nullptr;
+                bw.qkvf = rt_qkv ? a.take<T>((size_t)6 * c * c) : nullptr;
                 bw.qkv_b = a.take<float>(3 * c); bw.proj_b = a.take<float>(c);
                 bw.fc1_b = a.take<float>(4 * c); bw.fc2_b = a.take<float>(c);
                 bw.n1_g = a.take<float>(c); bw.n1_b = a.take<float>(c);
@@ -264,6 +267,8 @@ struct Engine : IEngine {
 
     explicit Engine(const Geom& geom, int hid16_ = 0, int qkv_a1 = 0, int mlp_mode = 0) : g(geom), hid16(hid16_) {
         fused_mlp = (P::NA == 2 && P::NW == 2 && !hid16_ && mlp_mode == 0);
+        rt_proj = (P::NA == 2 && P::NW == 2 && mlp_mode == 0);
+        rt_qkv = (std::is_same<P, PrecF16x3>::value && qkv_a1 && mlp_mode == 0);
         wk.hid16 = hid16_;
         wk.qkv_a1 = qkv_a1;
         params = build_params(g, nullptr);
@@ -313,6 +318,8 @@ struct Engine : IEngine {
                 CK(lin(bw.fc2, P_(m, p + "mlp.fc2.weight"), c, 4 * c, 4 * c, 1, s));
                 if (hid16 && !std::is_same<T, f16>::value) CK((prep_weight<f16, 2>(P_(m, p + "mlp.fc2.weight"), const_cast<f16*>(bw.fc2h.w), bw.fc2h.plane, c, 4 * c, 4 * c, 4 * c, 1, 1, 1, s)));
                 if constexpr (P::NA == 2 && P::NW == 2) {
+                    if (rt_proj) CK(prep_rowtile_weights<T>(P_(m, p + "attn.proj.weight"), const_cast<T*>(bw.projf), c, c, s));
+                    if (rt_qkv) CK(prep_rowtile_weights<T>(P_(m, p + "attn.qkv.weight"), const_cast<T*>(bw.qkvf), 3 * c, c, s));
                     if (fused_mlp) CK(prep_mlp_weights<T>(P_(m, p + "mlp.fc1.weight"), P_(m, p + "mlp.fc2.weight"), const_cast<T*>(bw.w1f), const_cast<T*>(bw.w2f), c, s));
                 }
                 CK(copyf(bw.qkv_b, P_(m, p + "attn.qkv.bias"), 3 * c, s));
@@ -358,12 +365,22 @@ struct Engine : IEngine {
         const int* widx = w.widx[res][i & 1];
         const int o = res == 0 ? 0 : 5;
         mark(C_QKV0 + o, s);
-        CK((op_qkv<P>(g, bw, widx, res, xs, wk, s)));
+        if constexpr (std::is_same<P, PrecF16x3>::value) {
+            if (rt_qkv) CK(op_qkv_rowtile(g, bw, widx, res, xs, wk, s));
+            else CK((op_qkv<P>(g, bw, widx, res, xs, wk, s)));
+        } else {
+            CK((op_qkv<P>(g, bw, widx, res, xs, wk, s)));
+        }
         mark(C_ATTN0 + o, s);
         AttnArgs<P> a{wk.q, wk.k, wk.vt, wk.qkv_plane, bw.bias_exp, wk.ao, wk.ao_plane, C, g.nwin[res], g.nW[res], heads};
         CK(launch_attention<P>(a, s));
         mark(C_PROJ0 + o, s);
-        CK((op_proj<P>(g, bw, widx, res, xs, wk, s)));
+        if constexpr (P::NA == 2 && P::NW == 2) {
+            if (rt_proj) CK((op_proj_rowtile<P>(g, bw, widx, res, xs, wk, s)));
+            else CK((op_proj<P>(g, bw, widx, res, xs, wk, s)));
+        } else {
+            CK((op_proj<P>(g, bw, widx, res, xs, wk, s)));
+        }
         if constexpr (P::NA == 2 && P::NW == 2) {
             if (fused_mlp) {                      // timed under the fc1 category ("mlp" when fused); fc2 has no launch of its own
                 mark(C_FC1_0 + o, s);
