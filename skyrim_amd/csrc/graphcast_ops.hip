@@ -4,6 +4,8 @@
 // concat(edge latent, sender latent, receiver latent) from the three row-major sources through the edge's index arrays
 // (k-contiguous 32-byte reads), so a 3.1 M-edge x 1536-wide matrix (19 GB) stays virtual.  Same 3-term fp16 MFMA pipeline as
 // the SFNO GEMMs (strided_gemm.h / gemm.h); LayerNorm and the receiver sum are small HBM-bound kernels.
+#include <cstdlib>
+#include <type_traits>
 #include "../../include/skyrim_graphcast.h"
 #include "strided_gemm.h"
 
@@ -127,15 +129,19 @@ struct SinkRowsF32 {
     }
 };
 
-typedef TileCfg<64, 512, 32, 1, 8> TLN;
+// the tile spans the latent (N = 512): 128 rows x 512 columns, 8 waves as 2 x 4 with 64 x 128 wave tiles (96 MFMAs per wave and
+// k-step against one 64 KB weight k-tile; the 64-row tile TLN64 re-stages that weight tile twice as often)
+typedef TileCfg<64, 512, 32, 1, 8> TLN64;
+typedef TileCfg<128, 512, 32, 2, 4> TLN128;
+static int ln_tile_rows() { static const int v = [] { const char* e = getenv("SKGC_LN_TILE"); return e ? atoi(e) : 128; }(); return v; }
 
-template <bool RES>
+template <class TLN, bool RES>
 __global__ void __launch_bounds__(TLN::THREADS) linear_ln_kernel(const GemmArgs<PrecF16x3, ALStrided, EpLayerNorm<RowMapIndexed, SinkRowsF32<RES>>> g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     gemm_body<PrecF16x3, TLN, ALStrided, EpLayerNorm<RowMapIndexed, SinkRowsF32<RES>>, true>(g, smem);
 }
 
-template <bool RES>
+template <class TLN, bool RES>
 __global__ void __launch_bounds__(TLN::THREADS) sum_linear_ln_kernel(const GemmArgs<PrecF16x3, ALSumGather, EpLayerNorm<RowMapIndexed, SinkRowsF32<RES>>> g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     gemm_body<PrecF16x3, TLN, ALSumGather, EpLayerNorm<RowMapIndexed, SinkRowsF32<RES>>, true>(g, smem);
@@ -211,6 +217,61 @@ __global__ void __launch_bounds__(256) segment_sum_kernel(const float* __restric
 
 using namespace skp;
 
+template <class TLN>
+static int linear_layer_norm_t(const float* a, long long lda, int K, const void* w, long long w_plane, int ldw, const float* bias, const float* gamma,
+                               const float* beta, const float* res, float* out, long long rows, void* stream) {
+    constexpr int N = TLN::BN;
+    const dim3 grid(1, (unsigned)((rows + TLN::BM - 1) / TLN::BM));
+    if (grid.y > 65535 * 16) return SKGC_E_ARG;
+    constexpr int smem = gemm_smem_bytes<PrecF16x3, TLN>() + kEpiScratch;
+    const ALStrided al{a, (int)rows, K, 1 << 30, lda, 0, 1, nullptr, nullptr, nullptr, 0, 0};
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    auto launch = [&](auto res_c) {
+        constexpr bool RES = decltype(res_c)::value;
+        typedef EpLayerNorm<RowMapIndexed, SinkRowsF32<RES>> EP;
+        GemmArgs<PrecF16x3, ALStrided, EP> g;
+        g.al = al;
+        g.ep = EP{RowMapIndexed{nullptr}, SinkRowsF32<RES>{out, res}, bias, gamma, beta, 1e-5f};
+        g.W = static_cast<const f16*>(w);
+        g.w_plane = w_plane;
+        g.ldw = ldw;
+        g.M = (int)rows; g.N = N; g.K = K;
+        auto kern = linear_ln_kernel<TLN, RES>;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, grid, dim3(TLN::THREADS), smem, st, g);
+        return hipGetLastError();
+    };
+    const hipError_t e = res ? launch(std::true_type{}) : launch(std::false_type{});
+    return e == hipSuccess ? 0 : SKGC_E_HIP;
+}
+
+template <class TLN>
+static int sum_linear_layer_norm_t(const skgc_sum_desc* d, const ALSumGather& al, void* stream) {
+    constexpr int N = TLN::BN;
+    const dim3 grid(1, (unsigned)((d->rows + TLN::BM - 1) / TLN::BM));
+    constexpr int smem = gemm_smem_bytes<PrecF16x3, TLN>() + kEpiScratch;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    auto launch = [&](auto res_c) {
+        constexpr bool RES = decltype(res_c)::value;
+        typedef EpLayerNorm<RowMapIndexed, SinkRowsF32<RES>> EP;
+        GemmArgs<PrecF16x3, ALSumGather, EP> g;
+        g.al = al;
+        g.ep = EP{RowMapIndexed{nullptr}, SinkRowsF32<RES>{d->out, d->res}, d->bias, d->gamma, d->beta, 1e-5f};
+        g.W = static_cast<const f16*>(d->w);
+        g.w_plane = d->w_plane;
+        g.ldw = d->ldw;
+        g.M = (int)d->rows; g.N = N; g.K = d->K;
+        auto kern = sum_linear_ln_kernel<TLN, RES>;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, grid, dim3(TLN::THREADS), smem, st, g);
+        return hipGetLastError();
+    };
+    const hipError_t e = d->res ? launch(std::true_type{}) : launch(std::false_type{});
+    return e == hipSuccess ? 0 : SKGC_E_HIP;
+}
+
 extern "C" {
 
 int skgc_abi_version(void) { return SKGC_ABI_VERSION; }
@@ -268,35 +329,12 @@ int skgc_prepare_weight_perm8(const float* src, int N, int K, void* dst, long lo
 
 int skgc_linear_layer_norm(const float* a, long long lda, int K, const void* w, long long w_plane, int ldw, const float* bias, const float* gamma,
                            const float* beta, const float* res, float* out, long long rows, void* stream) {
-    constexpr int N = TLN::BN;
     if (!a || !w || !gamma || !beta || !out || rows <= 0 || rows > 0x7fffffff || K <= 0 || lda < K || (ldw & 7) || ldw < K) return SKGC_E_ARG;
-    const dim3 grid(1, (unsigned)((rows + TLN::BM - 1) / TLN::BM));
-    if (grid.y > 65535 * 16) return SKGC_E_ARG;
-    constexpr int smem = gemm_smem_bytes<PrecF16x3, TLN>() + kEpiScratch;
-    const ALStrided al{a, (int)rows, K, 1 << 30, lda, 0, 1, nullptr, nullptr, nullptr, 0, 0};
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    auto launch = [&](auto res_c) {
-        constexpr bool RES = decltype(res_c)::value;
-        typedef EpLayerNorm<RowMapIndexed, SinkRowsF32<RES>> EP;
-        GemmArgs<PrecF16x3, ALStrided, EP> g;
-        g.al = al;
-        g.ep = EP{RowMapIndexed{nullptr}, SinkRowsF32<RES>{out, res}, bias, gamma, beta, 1e-5f};
-        g.W = static_cast<const f16*>(w);
-        g.w_plane = w_plane;
-        g.ldw = ldw;
-        g.M = (int)rows; g.N = N; g.K = K;
-        auto kern = linear_ln_kernel<RES>;
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(kern, grid, dim3(TLN::THREADS), smem, st, g);
-        return hipGetLastError();
-    };
-    const hipError_t e = res ? launch(std::true_type{}) : launch(std::false_type{});
-    return e == hipSuccess ? 0 : SKGC_E_HIP;
+    if (ln_tile_rows() == 64) return linear_layer_norm_t<TLN64>(a, lda, K, w, w_plane, ldw, bias, gamma, beta, res, out, rows, stream);
+    return linear_layer_norm_t<TLN128>(a, lda, K, w, w_plane, ldw, bias, gamma, beta, res, out, rows, stream);
 }
 
 int skgc_sum_linear_layer_norm(const skgc_sum_desc* d, void* stream) {
-    constexpr int N = TLN::BN;
     if (!d || !d->w || !d->gamma || !d->beta || !d->out || d->rows <= 0 || d->rows > 0x7fffffff || d->K <= 0 || (d->K & 7) || d->n_src < 1 || d->n_src > 3 ||
         (d->ldw & 7) || d->ldw < d->K || (d->act != 0 && d->act != 2))
         return SKGC_E_ARG;
@@ -309,27 +347,8 @@ int skgc_sum_linear_layer_norm(const skgc_sum_desc* d, void* stream) {
         }
     }
     al.n_src = d->n_src; al.M = (int)d->rows; al.K = d->K; al.act = d->act;
-    const dim3 grid(1, (unsigned)((d->rows + TLN::BM - 1) / TLN::BM));
-    constexpr int smem = gemm_smem_bytes<PrecF16x3, TLN>() + kEpiScratch;
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    auto launch = [&](auto res_c) {
-        constexpr bool RES = decltype(res_c)::value;
-        typedef EpLayerNorm<RowMapIndexed, SinkRowsF32<RES>> EP;
-        GemmArgs<PrecF16x3, ALSumGather, EP> g;
-        g.al = al;
-        g.ep = EP{RowMapIndexed{nullptr}, SinkRowsF32<RES>{d->out, d->res}, d->bias, d->gamma, d->beta, 1e-5f};
-        g.W = static_cast<const f16*>(d->w);
-        g.w_plane = d->w_plane;
-        g.ldw = d->ldw;
-        g.M = (int)d->rows; g.N = N; g.K = d->K;
-        auto kern = sum_linear_ln_kernel<RES>;
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(kern, grid, dim3(TLN::THREADS), smem, st, g);
-        return hipGetLastError();
-    };
-    const hipError_t e = d->res ? launch(std::true_type{}) : launch(std::false_type{});
-    return e == hipSuccess ? 0 : SKGC_E_HIP;
+    if (ln_tile_rows() == 64) return sum_linear_layer_norm_t<TLN64>(d, al, stream);
+    return sum_linear_layer_norm_t<TLN128>(d, al, stream);
 }
 
 }  // extern "C"
