@@ -356,6 +356,7 @@ def main():
     ap.add_argument("--gather", action="store_true", help="also all-gather the member states at every saved step")
     ap.add_argument("--reduce", default="allgather", choices=["allgather", "allreduce"], help="ensemble reduction: all-gather of per-rank partial "
                     "sums + local reduce (direct xGMI exchange, default) or ring all-reduce")
+    ap.add_argument("--graph", action="store_true", help="pangu: replay one captured HIP graph per step instead of 72 eager launches (per-stage timing off)")
     ap.add_argument("--mlp", default="fused", choices=["fused", "split"], help="pangu: one-kernel MLP (default) or the two tiled GEMMs of round 1")
     ap.add_argument("--model", default="pangu", choices=["pangu", "sfno", "graphcast"],
                     help="pangu (default; BASELINE.json's headline configuration), sfno (FourCastNet v2-small, configs[2]) or graphcast (configs[3])")
@@ -425,20 +426,37 @@ def main():
     for _ in range(args.warmup):
         for xm in xs:
             eng.step(xm, xm)
+    graphs = [eng.capture(xm) for xm in xs] if args.graph else None
+
+    def advance(i):
+        if graphs is not None:
+            graphs[i].replay()
+        else:
+            eng.step(xs[i], xs[i])
+
     if world > 1:   # warm the communicator outside the timed region
         saved_step()
-    eng.profile(True)
+    eng.profile(not args.graph)
     sync()
     t0 = time.perf_counter()
     for k in range(1, args.steps + 1):
-        for xm in xs:
-            eng.step(xm, xm)
+        for i in range(len(xs)):
+            advance(i)
         if world > 1 and (k % save_every == 0 or k == args.steps):
             saved = saved_step()
     sync()
     elapsed = time.perf_counter() - t0
     stats = eng.profile_read()
     eng.profile(False)
+    if args.graph:        # per-stage events are not recorded inside a captured graph: time the stages in one eager step afterwards
+        eng.profile(True)
+        scratch = xs[0].clone()
+        eng.step(scratch, scratch)
+        stats = eng.profile_read()
+        eng.profile(False)
+        for s_ in stats:
+            s_["total_ms"] *= args.steps * len(mine)
+            s_["launches"] *= args.steps * len(mine)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

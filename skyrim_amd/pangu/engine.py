@@ -198,6 +198,26 @@ class PanguEngine:
         ops.hip.pangu_step(self._ctx.value, x, out)
         return out
 
+    def capture(self, x: torch.Tensor) -> "torch.cuda.CUDAGraph":
+        """Capture one in-place step ``x <- Pangu6(x)`` (its 72 kernel launches) as a HIP graph on ``x``'s storage; ``graph.replay()``
+        then advances ``x`` by 6 h with ONE launch from the host.  The library allocates nothing and records no events outside
+        profiling, so the step is capturable as is.  A step is GPU-bound at 721x1440 (the launches are queued ahead of
+        the GPU either way); the graph matters on small grids and when the host is busy (ensemble drivers, I/O threads)."""
+        self._chk_dev(x, self.state_shape)
+        with torch.cuda.device(self.device):
+            side = torch.cuda.Stream(self.device)
+            side.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(side):                  # warm-up outside the capture: hipFuncSetAttribute etc. happen here
+                keep = x.clone()
+                ops.hip.pangu_step(self._ctx.value, x, x)
+                x.copy_(keep)
+            torch.cuda.current_stream(self.device).wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                ops.hip.pangu_step(self._ctx.value, x, x)
+            x.copy_(keep)                                  # the capture itself does not run the step; leave x as handed in
+        return g
+
     def profile(self, on: bool):
         """Record HIP events between the launches of ``step`` (per-stage kernel time, bench.py)."""
         _check(self.lib.skpangu_profile(self._ctx, 1 if on else 0), "skpangu_profile")

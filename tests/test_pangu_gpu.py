@@ -372,3 +372,22 @@ def test_fused_mlp_kernel_matches_the_two_gemm_path_and_the_oracle(toy, ref):
                 want2 = O.earth_block(O._block_params(params, 2, 0), taps["down"], O.Geometry(g.n_lat, g.n_lon).res(2), O.HEADS[1], False)
                 assert rel(eng.block(2, 0, x2).cpu(), want2) < STAGE_TOL[prec], mlp
     assert O.per_channel_rel_err(outs["fused", "f16x3q"], outs["split", "f16x3q"]).max().item() < 2e-4
+
+
+def test_step_as_a_captured_hip_graph(toy):
+    """One in-place step captured as a HIP graph (72 launches -> one replay): same bits as the eager step, replayable."""
+    from skyrim_amd.pangu.engine import PanguEngine
+    g, params, x = toy
+    eng = PanguEngine(g, device="cuda:0")
+    eng.load_params(params)
+    want1 = eng.step(x.cuda())
+    want2 = eng.step(want1)
+    xs = x.cuda().clone()
+    graph = eng.capture(xs)
+    assert torch.equal(xs, x.cuda())
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(xs, want1)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(xs, want2)
