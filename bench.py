@@ -85,17 +85,39 @@ def toy_parity(precision):
     return {"grid": "49x192", "max_rel_err": O.per_channel_rel_err(y, O.forward(p, x)).max().item(), "bar": 1e-3}
 
 
-def pmc_traffic(kernel: str):
-    """HBM bytes per launch of ``kernel`` from the committed rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE collected in
-    separate runs, FETCH doubled per MI355X_MICROARCH.md 'HBM'); profiles/r01_pmc_traffic.json is produced by
-    tools/pmc_traffic.py.  None when no PMC summary exists for this kernel."""
-    f = ROOT / "profiles" / "r01_pmc_traffic.json"
-    if not f.exists():
-        return None
+def pmc_summary(model: str):
+    """profiles/r02_<model>_pmc.json (tools/pmc_collect.sh + tools/pmc_summary.py: rocprofv3 --pmc passes, FETCH_SIZE doubled per
+    MI355X_MICROARCH.md 'HBM'), or None."""
+    f = ROOT / "profiles" / f"r02_{model}_pmc.json"
     try:
-        return json.loads(f.read_text()).get(kernel, {}).get("hbm_bytes_per_launch")
+        return json.loads(f.read_text())
     except Exception:
         return None
+
+
+def pmc_kernels(model: str, *needles: str):
+    """Counters of the kernels whose (demangled) name contains every needle, summed per STEP: HBM bytes, kernel time under the
+    counters, MFMA-busy share (time-weighted).  None without a committed summary."""
+    d = pmc_summary(model)
+    if not d:
+        return None
+    steps = d["total"]["steps"]
+    rows = [e for k, e in d["kernels"].items() if all(n in k for n in needles)]
+    if not rows:
+        return None
+    t = sum(e["avg_us"] * e["calls"] for e in rows)
+    return {"hbm_bytes_per_step": 1e9 * sum(e["hbm_GB"] * e["calls"] for e in rows) / steps,
+            "hbm_bytes_per_launch": 1e9 * sum(e["hbm_GB"] * e["calls"] for e in rows) / sum(e["calls"] for e in rows),
+            "ms_per_step_under_pmc": t / steps / 1e3,
+            "mfma_busy_pct": sum((e["mfma_busy_pct"] or 0.0) * e["avg_us"] * e["calls"] for e in rows) / t if t else None,
+            "source": f"profiles/r02_{model}_pmc.json"}
+
+
+# bench stage -> what identifies its kernel in the counter summary
+PANGU_STAGE_KERNEL = {"mlp_r0": ("fused_mlp_kernel", "MlpShape<192"), "mlp_r1": ("fused_mlp_kernel", "MlpShape<384"),
+                      "qkv_r0": ("rt_qkv_kernel", "QkvShape<192"), "qkv_r1": ("rt_qkv_kernel", "QkvShape<384"),
+                      "attn_r0": ("earth_attention_kernel",), "attn_r1": ("earth_attention_kernel",),
+                      "proj_r0": ("gemm_dma_kernel", "256x192", "EpLayerNorm", "RowMapIndexed"), "proj_r1": ("gemm_dma_kernel", "128x384", "EpLayerNorm")}
 
 
 def quick_mode(precision, geom, params, x_host, dev, steps=3, mlp="fused"):
@@ -195,26 +217,32 @@ def run_sfno(args, rank, local_rank, world, dist):
                    "precision": "every linear map (1x1 convs, DFT, Legendre, dhconv) as a GEMM with fp16 hi/lo operands, 3 MFMA terms, fp32 "
                                 "accumulate; fp32 activations",
                    "parallelism": f"member-parallel x{world}" if world > 1 else "single GPU", "finite": finite},
-        "roofline": {"bound": "mfma", "kernel": dom["name"] + " (gemm_strided_kernel)", "achieved": achieved / 1e12, "peak": PEAK_MFMA_BF16 / 1e12,
-                     "unit": "TFLOP/s", "frac": achieved / PEAK_MFMA_BF16, "traffic": None, "avg_launch_ms": dom_ms,
-                     "alg_flops_per_launch": dom["flops"] / dom["launches"],
-                     "note": "dense GEMM FLOPs of the launch (the Legendre / dhconv GEMMs also multiply the l < m zeros)",
-                     "step": {"alg_tflop": f_step / 1e12, "gpu_ms": gpu_ms, "mfma_frac": f_step / (gpu_ms * 1e-3) / PEAK_MFMA_BF16},
+        # SFNO is a bandwidth-bound network (1.9 TFLOP against ~30 GB of fp32 activations per step): the roofline is the HBM one.
+        # achieved = algorithmic bytes (A operand read once + output written once + residuals, fp32) of the dominant stage / its time
+        "roofline": {"bound": "hbm", "kernel": dom["name"] + " (gemm_strided_kernel)", "achieved": dom["bytes"] / (dom["total_ms"] * 1e-3) / 1e9,
+                     "peak": PEAK_HBM / 1e9, "unit": "GB/s", "frac": dom["bytes"] / (dom["total_ms"] * 1e-3) / PEAK_HBM,
+                     "traffic": (pmc_kernels("sfno", "gemm_strided_kernel") or {}).get("hbm_bytes_per_launch"),
+                     "counters_all_gemm_launches": pmc_kernels("sfno", "gemm_strided_kernel"),
+                     "avg_launch_ms": dom_ms, "alg_bytes_per_launch": dom["bytes"] / dom["launches"],
+                     "mfma": {"achieved_tflops": achieved / 1e12, "frac": achieved / PEAK_MFMA_BF16,
+                              "note": "dense GEMM FLOPs of the dominant stage (the Legendre / dhconv GEMMs also multiply the l < m zeros)"},
+                     "step": {"alg_tflop": f_step / 1e12, "alg_GB": sum(s["bytes"] for s in stats) / args.steps / 1e9, "gpu_ms": gpu_ms,
+                              "hbm_frac": sum(s["bytes"] for s in stats) / args.steps / (gpu_ms * 1e-3) / PEAK_HBM,
+                              "mfma_frac": f_step / (gpu_ms * 1e-3) / PEAK_MFMA_BF16,
+                              "hbm_GB_measured": ((pmc_summary("sfno") or {}).get("total") or {}).get("hbm_GB_per_step")},
                      "stages": {s["name"]: {"ms_per_step": round(s["total_ms"] / args.steps, 4), "launches_per_step": s["launches"] // args.steps,
-                                            "dense_tflops": round(s["flops"] / (s["total_ms"] * 1e-3) / 1e12, 1)} for s in stats}},
+                                            "dense_tflops": round(s["flops"] / (s["total_ms"] * 1e-3) / 1e12, 1),
+                                            "alg_GBps": round(s["bytes"] / (s["total_ms"] * 1e-3) / 1e9, 1)} for s in stats}},
     }
     if world == 1 and not args.no_cpu_baseline:
         from oracle import sfno_oracle as O
+        tr = O.Transforms(cfg)                           # quadrature / Legendre tables: setup, not timed (the engine prepares its own once, too)
         t0 = time.time()
         with torch.no_grad():
-            mean, std = params["norm.mean"][:, None, None], params["norm.std"][:, None, None]
-            y = torch.nn.functional.gelu(O._conv1x1((x_host - mean) / std, params["encoder.fc1.weight"], params["encoder.fc1.bias"]))
-            y = O._conv1x1(y, params["encoder.fc2.weight"]) + params["pos_embed"]
+            O.forward(params, x_host, cfg, tr=tr)
         dt = time.time() - t0
-        f_sample = 2.0 * cfg.n_lat * cfg.n_lon * (cfg.in_chans * cfg.embed_dim + cfg.embed_dim ** 2)
-        out["cpu_baseline"] = {"value": 1.0 / (dt * f_step / f_sample), "unit": "steps/s", "cores": torch.get_num_threads(), "kind": "port",
-                               "sample": f"encoder (two 1x1 convolutions + GELU + position embedding) of one {cfg.n_lat}x{cfg.n_lon} step "
-                                         f"({100 * f_sample / f_step:.1f}% of its FLOPs) in {dt:.1f} s, scaled by FLOPs; PyTorch-CPU fp32 restatement"}
+        out["cpu_baseline"] = {"value": 1.0 / dt, "unit": "steps/s", "cores": torch.get_num_threads(), "kind": "port",
+                               "sample": f"ONE full {cfg.n_lat}x{cfg.n_lon} step of the PyTorch-CPU restatement (fp32 network, fp64 transforms) in {dt:.1f} s; no scaling"}
     if world == 1 and not args.no_parity:
         from oracle import sfno_oracle as O
         tiny = SfnoConfig(n_lat=97, n_lon=192, in_chans=11, out_chans=11, embed_dim=40, num_layers=4, scale_factor=3)
@@ -305,24 +333,54 @@ def run_graphcast(args, rank, local_rank, world, dist):
                                    f"all-reduce of the ({g.n_mesh} x {cfg.latent}) grid->mesh aggregate and {cfg.steps} all-gathers of the node latents") if sharded else
                                   (f"member-parallel x{world}" if world > 1 else "single GPU"), "finite": finite},
         "roofline": {"bound": "mfma", "kernel": dom["name"] + " (gather_gemm_kernel + gemm_strided_kernel)", "achieved": achieved / 1e12,
-                     "peak": PEAK_MFMA_BF16 / 1e12, "unit": "TFLOP/s", "frac": achieved / PEAK_MFMA_BF16, "traffic": None,
+                     "peak": PEAK_MFMA_BF16 / 1e12, "unit": "TFLOP/s", "frac": achieved / PEAK_MFMA_BF16,
+                     "traffic": (pmc_kernels("graphcast", "ln_kernel") or {}).get("hbm_bytes_per_launch"),
+                     "counters_linear_layer_norm_kernels": pmc_kernels("graphcast", "ln_kernel"),
+                     "hbm_GB_per_step_all_kernels": ((pmc_summary("graphcast") or {}).get("total") or {}).get("hbm_GB_per_step"),
                      "avg_launch_ms": dom["total_ms"] / dom["launches"],
                      "step": {"alg_tflop": f_step / 1e12, "gpu_ms": gpu_ms, "mfma_frac": f_step / (gpu_ms * 1e-3) / PEAK_MFMA_BF16},
                      "stages": {s["name"]: {"ms_per_step": round(s["total_ms"] / args.steps, 3), "launches_per_step": s["launches"] // args.steps,
                                             "dense_tflops": round(s["flops"] / (s["total_ms"] * 1e-3) / 1e12, 1)} for s in stats}},
     }
     if world == 1 and not args.no_cpu_baseline:
+        # bounded sample with one piece per cost class, each timed on the host cores and scaled by its own count (not by FLOPs alone:
+        # the edge updates are gather / scatter-bound on a CPU): (1) the grid-node embedder on 1/8 of the grid (dense, per grid node);
+        # (2) ONE full processor layer on the multi-mesh (gathers over 327 660 edges + receiver sum + node update) x 16;
+        # (3) the mesh->grid edge update + receiver sum on 1/16 of the grid's edges x 16; the remaining stages are priced from these
+        from oracle import graphcast_graph as OG
         from oracle import graphcast_oracle as O
-        t0 = time.time()
-        with torch.no_grad():                        # bounded sample: the grid-node embedder of one full-size step
+        og = OG.build(cfg.n_lat, cfg.n_lon, cfg.splits)
+        L, gen = cfg.latent, torch.Generator().manual_seed(0)
+        with torch.no_grad():
             mean, std = params["norm.mean"][:, None, None], params["norm.std"][:, None, None]
-            feats = torch.cat([(x0h - mean) / std, (x1h - mean) / std, fcs[0].cpu(), params["static"]], dim=0).flatten(1).T
-            O.mlp(params, "embed.grid", torch.cat([feats, torch.from_numpy(g.grid_node_feat)], dim=1))
-        dt = time.time() - t0
-        f_sample = 2.0 * g.n_grid * (cfg.grid_in * cfg.latent + cfg.latent * cfg.latent)
-        out["cpu_baseline"] = {"value": 1.0 / (dt * f_step / f_sample), "unit": "steps/s", "cores": torch.get_num_threads(), "kind": "port",
-                               "sample": f"grid-node embedder (186 -> 512 -> 512 + LayerNorm on {g.n_grid} nodes) of one step "
-                                         f"({100 * f_sample / f_step:.1f}% of its FLOPs) in {dt:.1f} s, scaled by FLOPs; PyTorch-CPU fp32 restatement"}
+            n8 = og.n_grid // 8
+            feats = torch.cat([(x0h - mean) / std, (x1h - mean) / std, fcs[0].cpu(), params["static"]], dim=0).flatten(1).T[:n8]
+            t0 = time.time()
+            O.mlp(params, "embed.grid", torch.cat([feats, torch.from_numpy(og.grid_node_feat[:n8])], dim=1))
+            t_embed = (time.time() - t0) * 8
+            vm, em = torch.randn(og.n_mesh, L, generator=gen), torch.randn(len(og.mesh_edges), L, generator=gen)
+            me = torch.from_numpy(og.mesh_edges)
+            t0 = time.time()
+            de = O.edge_update(params, "proc.0.edge", em, vm, vm, me)
+            vm2 = vm + O.mlp(params, "proc.0.node", torch.cat([vm, O.aggregate(de, me[:, 1], og.n_mesh)], dim=1))
+            t_proc = (time.time() - t0) * cfg.steps
+            n16 = og.n_grid // 16
+            m2g = torch.from_numpy(og.m2g_edges[:3 * n16])
+            e2, vg = torch.randn(3 * n16, L, generator=gen), torch.randn(n16, L, generator=gen)
+            t0 = time.time()
+            ee = O.edge_update(params, "m2g.edge", e2, vm2, vg, m2g)
+            O.aggregate(ee, m2g[:, 1], n16)
+            t_m2g = (time.time() - t0) * 16
+        # priced from the samples: grid->mesh edges like mesh->grid edges per edge; the three other grid-node MLPs like the embedder per FLOP
+        t_g2m = t_m2g * len(og.g2m_edges) / len(og.m2g_edges)
+        f_embed = cfg.grid_in * L + L * L
+        t_grid_mlps = t_embed * ((L * L + L * L) + (2 * L * L + L * L) + (L * L + L * cfg.n_vars)) / f_embed
+        t_step = t_embed + t_proc + t_m2g + t_g2m + t_grid_mlps
+        out["cpu_baseline"] = {"value": 1.0 / t_step, "unit": "steps/s", "cores": torch.get_num_threads(), "kind": "port",
+                               "sample": f"grid-node embedder on 1/8 of the grid ({t_embed / 8:.1f} s) + one full processor layer ({t_proc / cfg.steps:.1f} s) + mesh->grid "
+                                         f"edge update and receiver sum on 1/16 of the grid ({t_m2g / 16:.1f} s); each scaled by its own count, the grid->mesh edges and the "
+                                         "other grid-node MLPs priced from these; PyTorch-CPU fp32 restatement on the oracle's own graph",
+                               "s_per_step_est": t_step}
     if world == 1 and not args.no_parity:
         from oracle import graphcast_oracle as O
         small = GraphcastConfig(n_lat=61, n_lon=120, splits=3, latent=64, steps=4)
@@ -494,7 +552,11 @@ def main():
             },
             "roofline": {
                 "bound": "mfma", "kernel": dom["name"], "achieved": achieved / 1e12, "peak": PEAK_MFMA_BF16 / 1e12,
-                "unit": "TFLOP/s", "frac": achieved / PEAK_MFMA_BF16, "traffic": pmc_traffic(dom["name"]),
+                "unit": "TFLOP/s", "frac": achieved / PEAK_MFMA_BF16,
+                "traffic": (pmc_kernels("pangu", *PANGU_STAGE_KERNEL.get(dom["name"], ("?",))) or {}).get("hbm_bytes_per_launch"),
+                "counters": pmc_kernels("pangu", *PANGU_STAGE_KERNEL.get(dom["name"], ("?",))),
+                "hbm_bytes_per_step_all_kernels": ((pmc_summary("pangu") or {}).get("total") or {}).get("hbm_GB_per_step"),
+                "alg_bytes_per_launch": dom["bytes"],
                 "avg_launch_ms": dom_ms, "alg_flops_per_launch": dom["flops"],
                 "step": {"alg_tflop": F_ALG_STEP / 1e12, "gpu_ms": gpu_ms,
                          "mfma_frac": F_ALG_STEP / (gpu_ms * 1e-3) / PEAK_MFMA_BF16,

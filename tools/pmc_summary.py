@@ -21,13 +21,18 @@ from pathlib import Path
 
 def short(name: str) -> str:
     if name.startswith("_Z"):
-        name = subprocess.run(["c++filt", name], capture_output=True, text=True).stdout.strip() or name
+        # GNU c++filt does not know the _Float16 / __bf16 manglings (DF16_, DF16b): demangle with "half" (Dh) standing in for both
+        tagged = name.replace("DF16b", "Dh").replace("DF16_", "Dh")
+        out = subprocess.run(["c++filt", tagged], capture_output=True, text=True).stdout.strip()
+        if out and not out.startswith("_Z"):
+            name = out.replace("__fp16", "f16" if "DF16_" in name else "bf16").replace("half", "f16" if "DF16_" in name else "bf16")
     name = re.sub(r"\(.*$", "", name)
     name = name.replace("skp::", "").replace("void ", "")
     name = re.sub(r"TileCfg<(\d+), (\d+), \d+, \d+, \d+>", r"\1x\2", name)
     name = re.sub(r"(APlanes|AConcatPlanes|EpGelu|EpQKV|EpStorePlanes|SinkResidual|SinkStore)<[^<>]*>", r"\1", name)
-    name = re.sub(r"DmaArgs<.*$|GemmArgs<.*$", "", name)
-    return name[:140]
+    name = re.sub(r"DmaArgs<.*$|GemmArgs<.*$|MlpArgs<.*$|ProjArgs<.*$", "", name)
+    name = re.sub(r"\s+", " ", name).strip()
+    return name[:160]
 
 
 def load(d: Path):
