@@ -129,3 +129,18 @@ def flops_per_step(cfg: GraphcastConfig, n_grid: int, n_mesh: int, e_mesh: int, 
     f += cfg.steps * (mlp(e_mesh, 3 * L, L) + mlp(n_mesh, 2 * L, L))
     f += mlp(e_m2g, 3 * L, L) + mlp(n_grid, 2 * L, L) + mlp(n_grid, L, cfg.n_vars)
     return f
+
+
+def flops_per_step_executed(cfg: GraphcastConfig, n_grid: int, n_mesh: int, e_mesh: int, e_g2m: int, e_m2g: int) -> float:
+    """FLOPs the engine actually executes for the same result: the first Linear of every edge MLP taken apart by distributivity
+    (engine.py: node terms once per node, input-independent edge terms once per model), everything else as in ``flops_per_step``."""
+    L = cfg.latent
+    lin = lambda rows, d_in, d_out: 2.0 * rows * d_in * d_out  # noqa: E731
+    mlp = lambda rows, d_in, d_out: 2.0 * rows * (d_in * L + L * d_out)  # noqa: E731
+    f = mlp(n_grid, cfg.grid_in, L)                                                   # grid embedder
+    f += lin(n_grid, L, L) + lin(e_g2m, L, L)                                         # grid->mesh edges: sender term per grid node + second Linear
+    f += mlp(n_mesh, 2 * L, L) + mlp(n_grid, L, L)                                    # encoder node updates
+    f += cfg.steps * (lin(e_mesh, L, L) + lin(n_mesh, L, 2 * L) + lin(e_mesh, L, L) + mlp(n_mesh, 2 * L, L))
+    f += lin(n_mesh, L, L) + lin(n_grid, L, L) + lin(e_m2g, L, L)                     # mesh->grid edges
+    f += mlp(n_grid, 2 * L, L) + mlp(n_grid, L, cfg.n_vars)
+    return f
