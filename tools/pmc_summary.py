@@ -9,7 +9,7 @@ counters, and per dispatch
   wait_pct / stall_pct / issue_pct   SQ_WAIT_ANY, SQ_WAIT_INST_ANY, SQ_ACTIVE_INST_ANY over SQ_WAVE_CYCLES (disjoint, guide "PMC slots")
   lds_active_pct    SQ_LDS_IDX_ACTIVE / SQ_BUSY_CU_CYCLES, bank conflicts as a share of LDS-active cycles
   hbm_GB, hbm_GBps  FETCH_SIZE (KiB, doubled: gfx950 tallies 128-B read requests at 64 B -- MI355X_MICROARCH.md "HBM") + WRITE_SIZE (KiB)
-The clock under the counters is GRBM_GUI_ACTIVE / duration."""
+The clock under the counters is GRBM_GUI_ACTIVE / 8 XCDs / duration."""
 import csv
 import json
 import re
@@ -69,7 +69,7 @@ def main(prefix, out, *rest):
         busy_cu, wave = g("SQ_BUSY_CU_CYCLES"), g("SQ_WAVE_CYCLES")
         busy2 = g("GRBM_GUI_ACTIVE", "sq2")
         e = {"calls": n, "avg_us": round(dur[k] / n, 2),
-             "clock_GHz": round(g("GRBM_GUI_ACTIVE") / (dur[k] / n * 1e3), 3) if dur[k] else None,
+             "clock_GHz": round(g("GRBM_GUI_ACTIVE") / 8 / (dur[k] / n * 1e3), 3) if dur[k] else None,      # the counter sums the 8 XCDs
              "mfma_busy_pct": round(100 * g("SQ_VALU_MFMA_BUSY_CYCLES") / (4 * busy_cu), 2) if busy_cu else None,
              "mfma_clk_per_inst": round(g("SQ_VALU_MFMA_BUSY_CYCLES") / g("SQ_INSTS_MFMA"), 2) if g("SQ_INSTS_MFMA") else None,
              "wait_pct": round(100 * g("SQ_WAIT_ANY") / wave, 1) if wave else None,
