@@ -206,6 +206,7 @@ def run_sfno(args, rank, local_rank, world, dist):
     dom_ms = dom["total_ms"] / dom["launches"]
     achieved = dom["flops"] / dom["launches"] / (dom_ms * 1e-3)
     gpu_ms = sum(s["total_ms"] for s in stats) / args.steps
+    dom_kernel = "sfno_chain_kernel" if eng.chain is not None and dom["name"] in ("encoder", "mlp", "mlp_outer", "mlp_decoder") else "gemm_strided_kernel"
     out = {
         "metric": "6-h forecast steps/sec on 721x1440 state, 1/2/4/8 MI355X; per-channel max rel-err vs ref",
         "value": world * args.steps / elapsed, "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -215,13 +216,14 @@ def run_sfno(args, rank, local_rank, world, dist):
                                f"autoregressive rollout, {cfg.n_lat}x{cfg.n_lon}x{cfg.in_chans} state, random-init weights, state resident in "
                                "HBM, 1 ensemble member per GPU",
                    "precision": "every linear map (1x1 convs, DFT, Legendre, dhconv) as a GEMM with fp16 hi/lo operands, 3 MFMA terms, fp32 "
-                                "accumulate; fp32 activations",
+                                "accumulate; fp32 activations" + ("; encoder, block MLPs (+ norm1) and MLP + decoder of the last block as one "
+                                                                  "pixel-wise chain kernel each" if eng.chain is not None else ""),
                    "parallelism": f"member-parallel x{world}" if world > 1 else "single GPU", "finite": finite},
         # SFNO is a bandwidth-bound network (1.9 TFLOP against ~30 GB of fp32 activations per step): the roofline is the HBM one.
         # achieved = algorithmic bytes (A operand read once + output written once + residuals, fp32) of the dominant stage / its time
-        "roofline": {"bound": "hbm", "kernel": dom["name"] + " (gemm_strided_kernel)", "achieved": dom["bytes"] / (dom["total_ms"] * 1e-3) / 1e9,
+        "roofline": {"bound": "hbm", "kernel": dom["name"] + f" ({dom_kernel})", "achieved": dom["bytes"] / (dom["total_ms"] * 1e-3) / 1e9,
                      "peak": PEAK_HBM / 1e9, "unit": "GB/s", "frac": dom["bytes"] / (dom["total_ms"] * 1e-3) / PEAK_HBM,
-                     "traffic": (pmc_kernels("sfno", "gemm_strided_kernel") or {}).get("hbm_bytes_per_launch"),
+                     "traffic": (pmc_kernels("sfno", dom_kernel) or {}).get("hbm_bytes_per_launch"),
                      "counters_all_gemm_launches": pmc_kernels("sfno", "gemm_strided_kernel"),
                      "avg_launch_ms": dom_ms, "alg_bytes_per_launch": dom["bytes"] / dom["launches"],
                      "mfma": {"achieved_tflops": achieved / 1e12, "frac": achieved / PEAK_MFMA_BF16,

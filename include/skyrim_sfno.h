@@ -4,8 +4,10 @@
  * earth2mip.networks.fcnv2_sm.load(...) (/root/reference/skyrim/core/models/fourcastnet_v2.py:36-37): the forward of
  * modulus' SphericalFourierNeuralOperatorNet on torch / torch-harmonics.  Every linear map of that network (1x1
  * convolutions, truncated real DFT, Legendre analysis / synthesis, per-degree complex channel mixing) is one call of
- * sksfno_gemm_run against a constant matrix prepared by sksfno_prepare_weight; sksfno_instance_norm is the only other
- * kernel.  The host side (skyrim_amd/sfno/engine.py) owns the buffers and the order of the calls.
+ * sksfno_gemm_run against a constant matrix prepared by sksfno_prepare_weight; sksfno_instance_norm normalises a field.
+ * ABI v2 adds the fused pixel-wise chains (sksfno_chain_run: encoder, block MLP, last MLP + decoder as one kernel each, the
+ * instance norm in front of an MLP as a per-channel affine from sksfno_instance_stats).
+ * The host side (skyrim_amd/sfno/engine.py) owns the buffers and the order of the calls.
  * All pointers are device pointers; calls are asynchronous on `stream` (a hipStream_t); nothing is allocated inside. */
 #ifndef SKYRIM_SFNO_H
 #define SKYRIM_SFNO_H
@@ -14,7 +16,7 @@
 extern "C" {
 #endif
 
-#define SKSFNO_ABI_VERSION 1
+#define SKSFNO_ABI_VERSION 2
 #define SKSFNO_E_ARG (-1) /* bad argument */
 #define SKSFNO_E_HIP (-2) /* a HIP call failed */
 
@@ -66,6 +68,45 @@ int sksfno_gemm_run(const sksfno_gemm* desc, void* stream);
 
 /* out[c][i] = (x[c][i] - mean_c) * rsqrt(var_c + eps) * gamma[c] + beta[c] over i < HW (biased variance), c < C */
 int sksfno_instance_norm(const float* x, const float* gamma, const float* beta, float* out, int C, long long HW, float eps, void* stream);
+
+/* ---- fused pixel-wise chains (ABI v2) -------------------------------------------------------------------------------------
+ * Activations are [channels][HW] fp32, HW a multiple of 16.  One launch walks the pixels once:
+ *   ENC   out = W2 GELU(W1 (x * scale + shift) + b1) + res                 x: [KX][HW] raw state, res: position embedding [C][HW]
+ *   MLP   out = W2 GELU(W1 (y * scale + shift) + b1) + b2 + res            y, res, out: [C][HW]   (scale / shift: sksfno_instance_stats)
+ *   TAIL  z = MLP(y);  out = V2 GELU(V1 concat(z, x * xscale + xshift) + d1) + d2       out: [OUT][HW]
+ * replacing, in /root/reference's network (fourcastnet_v2.py:36-37 -> modulus SphericalFourierNeuralOperatorNet), encoder,
+ * block MLP (+ norm1) and decoder (+ big skip).  Weights are prepared by sksfno_prepare_chain_weights from matrices zero-padded to
+ * the widths of the shape class (sksfno_chain_dims); `tab` is one fp32 array in the order
+ *   scale[K0] shift[K0] b1[H0] b2[CP]  (TAIL: + xscale[KXP] xshift[KXP] d1[CP] d2[OP])      K0 = KXP, H0 = CP for ENC; K0 = CP, H0 = HP else,
+ * zero beyond the real widths. */
+#define SKSFNO_CHAIN_ENC 0
+#define SKSFNO_CHAIN_MLP 1
+#define SKSFNO_CHAIN_TAIL 2
+
+typedef struct sksfno_chain {
+    int mode;              /* SKSFNO_CHAIN_* */
+    int shape;             /* shape class: 0 = (CP 256, HP 512, KXP 96, OP 96), 1 = (64, 96, 32, 32) */
+    const float* y;        /* input of the first pair (ENC: the raw state) */
+    const float* x;        /* TAIL: the raw state */
+    const float* res;
+    float* out;            /* may alias y (MLP) or x (TAIL): a workgroup reads its own pixels before it writes them */
+    long long HW;
+    int C, KX, OUT;        /* real widths: embed, state channels, output channels */
+    const void *w1f, *w2f; /* first pair */
+    const void *v1f, *v2f; /* TAIL: decoder pair */
+    const float* tab;
+} sksfno_chain;
+
+/* padded widths of a shape class */
+int sksfno_chain_dims(int shape, int* cp, int* hp, int* kxp, int* op);
+
+/* w1: [H][K], w2: [N][H] fp32, zero-padded (K, H, N multiples of 32) -> fragment-order fp16 hi/lo planes; w1f: 2 H K, w2f: 2 N H elements */
+int sksfno_prepare_chain_weights(const float* w1, const float* w2, int K, int H, int N, void* w1f, void* w2f, void* stream);
+
+/* scale[c] = gamma[c] rstd_c, shift[c] = beta[c] - mean_c scale[c]: the instance norm of x[c][HW] as an affine of its consumer */
+int sksfno_instance_stats(const float* x, const float* gamma, const float* beta, float* scale, float* shift, int C, long long HW, float eps, void* stream);
+
+int sksfno_chain_run(const sksfno_chain* desc, void* stream);
 
 #ifdef __cplusplus
 }

@@ -7,7 +7,7 @@ dispatcher -- there is no CPU fallback.  Outputs are written in place into calle
 are stream-ordered, allocation-free and capturable in a HIP graph.
 
     pangu_step / pangu_patch_embed / pangu_block / pangu_downsample / pangu_upsample / pangu_patch_recover     (ctx = skpangu_ctx*)
-    sfno_gemm / sfno_instance_norm
+    sfno_gemm / sfno_instance_norm / sfno_chain / sfno_instance_stats
     gc_gather_gemm / gc_linear_layer_norm / gc_sum_linear_layer_norm / gc_layer_norm / gc_segment_sum
 """
 from __future__ import annotations
@@ -117,6 +117,37 @@ def _sfno_instance_norm(x, gamma, beta, out, C: int, HW: int, eps: float) -> Non
             "sksfno_instance_norm")
 
 
+def _sfno_chain(mode: int, shape: int, y, x, res, out, HW: int, C: int, KX: int, OUT: int, w1f, w2f, v1f, v2f, tab) -> None:
+    from .sfno import engine
+    lib = engine.load_library()
+    dev = y.device
+    for t, what in ((y, "y"), (x, "x"), (res, "res"), (out, "out"), (tab, "tab")):
+        if t is not None:
+            _f32(t, what, dev)
+    for t, what in ((w1f, "w1f"), (w2f, "w2f"), (v1f, "v1f"), (v2f, "v2f")):
+        if t is not None and (t.dtype != torch.float16 or t.device != dev or not t.is_contiguous()):
+            raise ValueError(f"sfno_chain: {what} must be the fp16 planes of sksfno_prepare_chain_weights on the same device")
+    nin = KX if mode == engine.CHAIN_ENC else C
+    nout = OUT if mode == engine.CHAIN_TAIL else C
+    if y.numel() < nin * HW or res.numel() < C * HW or out.numel() < nout * HW or (x is not None and x.numel() < KX * HW):
+        raise ValueError("sfno_chain: an activation tensor is smaller than channels x HW")
+    d = engine.ChainDesc(mode, shape, y.data_ptr(), _opt(x), res.data_ptr(), out.data_ptr(), HW, C, KX, OUT, w1f.data_ptr(), w2f.data_ptr(),
+                         _opt(v1f), _opt(v2f), tab.data_ptr())
+    with torch.cuda.device(dev):
+        _ok(lib.sksfno_chain_run(ctypes.byref(d), _stream(y)), "sksfno_chain_run")
+
+
+def _sfno_instance_stats(x, gamma, beta, tab, shift_off: int, C: int, HW: int, eps: float) -> None:
+    from .sfno import engine
+    lib = engine.load_library()
+    dev = x.device
+    if tab.numel() < shift_off + C or x.numel() < C * HW:
+        raise ValueError("sfno_instance_stats: tab or x too small")
+    with torch.cuda.device(dev):
+        _ok(lib.sksfno_instance_stats(_f32(x, "x"), _f32(gamma, "gamma", dev), _f32(beta, "beta", dev), _f32(tab, "tab", dev),
+                                      ctypes.c_void_p(tab.data_ptr() + 4 * shift_off), C, HW, eps, _stream(x)), "sksfno_instance_stats")
+
+
 # ---- GraphCast -------------------------------------------------------------------------------------------------------------- #
 def _gc_gather_gemm(src, idx, width, w, w_plane: int, ldw: int, bias, out, M: int, N: int, act: int, kscale, kshift) -> None:
     from .graphcast import engine
@@ -200,6 +231,9 @@ _SCHEMAS = [
     ("sfno_gemm(Tensor a, Tensor w, Tensor(a!) out, Tensor? bias, Tensor? res_pre, Tensor? res_post, Tensor? a_kscale, Tensor? a_kshift, Tensor? a2, int[] geom) -> ()",
      _sfno_gemm),
     ("sfno_instance_norm(Tensor x, Tensor gamma, Tensor beta, Tensor(a!) out, int C, int HW, float eps) -> ()", _sfno_instance_norm),
+    ("sfno_chain(int mode, int shape, Tensor y, Tensor? x, Tensor res, Tensor(a!) out, int HW, int C, int KX, int OUT, Tensor w1f, Tensor w2f, "
+     "Tensor? v1f, Tensor? v2f, Tensor tab) -> ()", _sfno_chain),
+    ("sfno_instance_stats(Tensor x, Tensor gamma, Tensor beta, Tensor(a!) tab, int shift_off, int C, int HW, float eps) -> ()", _sfno_instance_stats),
     ("gc_gather_gemm(Tensor[] src, Tensor?[] idx, int[] width, Tensor w, int w_plane, int ldw, Tensor bias, Tensor(a!) out, int M, int N, int act, "
      "Tensor? kscale, Tensor? kshift) -> ()", _gc_gather_gemm),
     ("gc_linear_layer_norm(Tensor a, int lda, int K, Tensor w, int w_plane, int ldw, Tensor bias, Tensor gamma, Tensor beta, Tensor? res, Tensor(a!) out, int rows) -> ()",

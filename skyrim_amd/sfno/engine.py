@@ -27,7 +27,9 @@ from .sht import ShtMatrices
 from .spec import SfnoConfig, param_spec
 
 _LIB_PATH = Path(__file__).resolve().parent.parent / "lib" / "libskyrim_sfno.so"
-EXPORTS = ["sksfno_abi_version", "sksfno_prepare_weight", "sksfno_gemm_run", "sksfno_instance_norm"]
+EXPORTS = ["sksfno_abi_version", "sksfno_prepare_weight", "sksfno_gemm_run", "sksfno_instance_norm",
+           "sksfno_chain_dims", "sksfno_prepare_chain_weights", "sksfno_instance_stats", "sksfno_chain_run"]
+CHAIN_ENC, CHAIN_MLP, CHAIN_TAIL = 0, 1, 2
 
 
 class GemmDesc(ctypes.Structure):
@@ -41,6 +43,12 @@ class GemmDesc(ctypes.Structure):
                 ("k_lo_step", ctypes.c_int), ("m_cap0", ctypes.c_int), ("m_cap_step", ctypes.c_int),
                 ("a_kscale", ctypes.c_void_p), ("a_kshift", ctypes.c_void_p),
                 ("a2", ctypes.c_void_p), ("a2_sk", ctypes.c_longlong), ("a2_k_split", ctypes.c_int), ("terms", ctypes.c_int)]
+
+
+class ChainDesc(ctypes.Structure):                      # sksfno_chain
+    _fields_ = [("mode", ctypes.c_int), ("shape", ctypes.c_int), ("y", ctypes.c_void_p), ("x", ctypes.c_void_p), ("res", ctypes.c_void_p),
+                ("out", ctypes.c_void_p), ("HW", ctypes.c_longlong), ("C", ctypes.c_int), ("KX", ctypes.c_int), ("OUT", ctypes.c_int),
+                ("w1f", ctypes.c_void_p), ("w2f", ctypes.c_void_p), ("v1f", ctypes.c_void_p), ("v2f", ctypes.c_void_p), ("tab", ctypes.c_void_p)]
 
 
 _lib = None
@@ -60,6 +68,11 @@ def load_library():
     lib.sksfno_gemm_run.argtypes = [ctypes.POINTER(GemmDesc), ctypes.c_void_p]
     lib.sksfno_instance_norm.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
                                          ctypes.c_longlong, ctypes.c_float, ctypes.c_void_p]
+    lib.sksfno_chain_dims.argtypes = [ctypes.c_int] + [ctypes.POINTER(ctypes.c_int)] * 4
+    lib.sksfno_prepare_chain_weights.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                                                 ctypes.c_void_p, ctypes.c_void_p]
+    lib.sksfno_instance_stats.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_int, ctypes.c_longlong, ctypes.c_float, ctypes.c_void_p]
+    lib.sksfno_chain_run.argtypes = [ctypes.POINTER(ChainDesc), ctypes.c_void_p]
     for name in EXPORTS:
         getattr(lib, name).restype = ctypes.c_int
     _lib = lib
@@ -97,14 +110,56 @@ class _Weight:
             torch.cuda.current_stream(eng.device).synchronize()
 
 
+def chain_shapes(lib) -> list[tuple[int, int, int, int]]:
+    """(CP, HP, KXP, OP) of the shape classes the fused pixel-wise chains are compiled for, smallest last."""
+    out = []
+    for k in range(2):
+        v = [ctypes.c_int() for _ in range(4)]
+        _check(lib.sksfno_chain_dims(k, *[ctypes.byref(t) for t in v]), "sksfno_chain_dims")
+        out.append(tuple(t.value for t in v))
+    return out
+
+
+class _Pair:
+    """An expand / contract pair W1 [H][K], W2 [N][H] (zero-padded fp32) as fragment-order fp16 hi/lo planes (sfno_chain.hip)."""
+
+    def __init__(self, eng, w1: torch.Tensor, w2: torch.Tensor):
+        H, K = w1.shape
+        N = w2.shape[0]
+        assert w2.shape[1] == H and K % 32 == 0 and H % 32 == 0 and N % 32 == 0
+        a, b = w1.float().contiguous().to(eng.device), w2.float().contiguous().to(eng.device)
+        self.w1f = torch.empty(2 * H * K, dtype=torch.float16, device=eng.device)
+        self.w2f = torch.empty(2 * N * H, dtype=torch.float16, device=eng.device)
+        _check(eng.lib.sksfno_prepare_chain_weights(a.data_ptr(), b.data_ptr(), K, H, N, self.w1f.data_ptr(), self.w2f.data_ptr(), eng._stream()),
+               "sksfno_prepare_chain_weights")
+        torch.cuda.current_stream(eng.device).synchronize()
+
+
+def _pad2(m: torch.Tensor, rows: int, cols: int) -> torch.Tensor:
+    out = torch.zeros(rows, cols, dtype=torch.float64)
+    out[: m.shape[0], : m.shape[1]] = m
+    return out
+
+
+def _pad1(v: torch.Tensor, n: int) -> torch.Tensor:
+    out = torch.zeros(n, dtype=torch.float64)
+    out[: v.shape[0]] = v
+    return out
+
+
 class SfnoEngine:
-    def __init__(self, cfg: SfnoConfig | None = None, device: str | torch.device = "cuda:0", terms: int = 3):
+    def __init__(self, cfg: SfnoConfig | None = None, device: str | torch.device = "cuda:0", terms: int = 3, fused: bool | None = None):
         """``terms``: MFMA terms per GEMM -- 3: activations and constants as fp16 hi/lo pairs (fp32-class, ~1e-6 vs the oracle);
-        2: activations rounded to one fp16 plane (faster; error measured in tests/test_sfno_gpu.py)."""
+        2: activations rounded to one fp16 plane (faster; error measured in tests/test_sfno_gpu.py).
+        ``fused``: encoder, block MLPs (+ norm1) and decoder as one pixel-wise chain kernel each (sfno_chain.hip) instead of GEMM by
+        GEMM; default on (``SKYRIM_SFNO_UNFUSED=1`` switches it off) wherever the widths fit a compiled shape class and the pixel count
+        of the grid is a multiple of 16 -- otherwise that stage runs GEMM by GEMM."""
         self.cfg = cfg or SfnoConfig()
         if terms not in (2, 3):
             raise ValueError("terms must be 2 or 3")
         self.terms = terms
+        self.fused = (os.environ.get("SKYRIM_SFNO_UNFUSED", "0") != "1") if fused is None else bool(fused)
+        self.chain = None                 # shape class of the fused chains, set by load_params
         if not torch.cuda.is_available():
             raise RuntimeError("SfnoEngine needs an MI355X: the SFNO path has no CPU fallback")
         self.lib = load_library()
@@ -170,6 +225,7 @@ class SfnoEngine:
             self.dec1_b = f32(p["decoder.fc1.bias"])
             self.dec2 = _Weight(self, p["decoder.fc2.weight"] * std[: c.out_chans, None])
             self.dec2_b = f32(mean[: c.out_chans])
+            self._prepare_chains(p, mean, std)
             # transforms: outer (equiangular 721 x 1440) and inner (Legendre-Gauss h x w)
             self.tr = {}
             for key, (nlat, nlon, grid) in {"outer": (c.n_lat, c.n_lon, "equiangular"), "inner": (c.h, c.w, "legendre-gauss")}.items():
@@ -191,6 +247,38 @@ class SfnoEngine:
             self.b_out = buf(c.out_chans * hw_o)
             torch.cuda.current_stream(dev).synchronize()
         self.prepared = True
+
+    def _prepare_chains(self, p: dict, mean: torch.Tensor, std: torch.Tensor):
+        """Fragment-order weights and tables of the fused pixel-wise chains (include/skyrim_sfno.h, ABI v2)."""
+        c = self.cfg
+        e, hid = c.embed_dim, c.embed_dim * c.mlp_ratio
+        self.chain = None
+        if not self.fused or self.terms != 3:
+            return
+        for k, (CP, HP, KXP, OP) in reversed(list(enumerate(chain_shapes(self.lib)))):       # smallest class that fits
+            if e <= CP and hid <= HP and c.in_chans <= KXP and c.out_chans <= OP:
+                self.chain, self.chain_dims = k, (CP, HP, KXP, OP)
+                break
+        if self.chain is None:
+            return
+        CP, HP, KXP, OP = self.chain_dims
+        dev = self.device
+        tab = lambda *parts: torch.cat(parts).float().contiguous().to(dev)  # noqa: E731
+        # encoder: K0 = KXP, H0 = CP
+        self.ch_enc = _Pair(self, _pad2(p["encoder.fc1.weight"], CP, KXP), _pad2(p["encoder.fc2.weight"], CP, CP))
+        self.ch_enc_tab = tab(_pad1(1.0 / std, KXP), _pad1(-mean / std, KXP), _pad1(p["encoder.fc1.bias"], CP), torch.zeros(CP, dtype=torch.float64))
+        for i, blk in enumerate(self.blocks):
+            g = lambda n: p[f"blocks.{i}.{n}"]  # noqa: E731,B023
+            blk["ch_mlp"] = _Pair(self, _pad2(g("mlp.fc1.weight"), HP, CP), _pad2(g("mlp.fc2.weight"), CP, HP))
+            parts = [torch.zeros(2 * CP, dtype=torch.float64), _pad1(g("mlp.fc1.bias"), HP), _pad1(g("mlp.fc2.bias"), CP)]    # scale / shift: per step
+            if i == c.num_layers - 1:
+                wd = p["decoder.fc1.weight"]
+                v1 = torch.zeros(CP, CP + KXP, dtype=torch.float64)
+                v1[:e, :e] = wd[:, :e]
+                v1[:e, CP:CP + c.in_chans] = wd[:, e:]
+                blk["ch_dec"] = _Pair(self, v1, _pad2(p["decoder.fc2.weight"] * std[: c.out_chans, None], OP, CP))
+                parts += [_pad1(1.0 / std, KXP), _pad1(-mean / std, KXP), _pad1(p["decoder.fc1.bias"], CP), _pad1(mean[: c.out_chans], OP)]
+            blk["ch_tab"] = tab(*parts)
 
     # ---- launches ---------------------------------------------------------------------------------- #
     def _mark(self, label: str, flops: float = 0.0, nbytes: float = 0.0):
@@ -226,6 +314,21 @@ class SfnoEngine:
     def _norm(self, x, g, b, out, C, HW):
         self._mark("norm", 8.0 * C * HW, 16.0 * C * HW)
         ops.hip.sfno_instance_norm(x, g, b, out, C, HW, self.cfg.eps)
+
+    def _chain(self, mode, label, y, res, out, hw, pair, tab, x=None, dec=None):
+        """One fused pixel-wise chain over hw pixels (sksfno_chain_run)."""
+        c = self.cfg
+        e, hid = c.embed_dim, c.embed_dim * c.mlp_ratio
+        macs = {CHAIN_ENC: c.in_chans * e + e * e, CHAIN_MLP: 2 * e * hid, CHAIN_TAIL: 2 * e * hid + (e + c.in_chans) * e + e * c.out_chans}[mode]
+        chans = {CHAIN_ENC: c.in_chans + 2 * e, CHAIN_MLP: 3 * e, CHAIN_TAIL: 2 * e + c.in_chans + c.out_chans}[mode]
+        self._mark(label, 2.0 * hw * macs, 4.0 * hw * chans)
+        ops.hip.sfno_chain(mode, self.chain, y, x, res, out, hw, e, c.in_chans, c.out_chans, pair.w1f, pair.w2f,
+                           None if dec is None else dec.w1f, None if dec is None else dec.w2f, tab)
+
+    def _stats(self, x, g, b, tab, C, HW):
+        """Instance-norm statistics of x as the consumer's per-channel affine: scale -> tab[0:C], shift -> tab[CP:CP + C]."""
+        self._mark("norm", 4.0 * C * HW, 4.0 * C * HW)
+        ops.hip.sfno_instance_stats(x, g, b, tab, self.chain_dims[0], C, HW, self.cfg.eps)
 
     def _pointwise(self, a, W, out, hw, cin, cout, label="conv1x1", **kw):
         """1x1 convolution on [C][hw] activations: rows = pixels (contiguous), k = channel (stride hw)."""
@@ -266,11 +369,19 @@ class SfnoEngine:
         e, hid = c.embed_dim, c.embed_dim * c.mlp_ratio
         hw_o = c.n_lat * c.n_lon
         with torch.cuda.device(self.device):
+            y = out if out is not None else torch.empty((c.out_chans, c.n_lat, c.n_lon), dtype=torch.float32, device=self.device)
+            if y.device != self.device or y.dtype != torch.float32 or tuple(y.shape) != (c.out_chans, c.n_lat, c.n_lon) or not y.is_contiguous():
+                raise ValueError("bad output tensor")
+            fuse_o = self.chain is not None and hw_o % 16 == 0          # outer-grid chains
             # encoder: GELU(W1' x + b1') -> W2 . + position embedding
-            self._pointwise(x, self.enc1, self.b_sp, hw_o, c.in_chans, e, label="encoder", bias=self.enc1_b, act=1,
-                            a_kscale=self.in_scale, a_kshift=self.in_shift)
-            self._pointwise(self.b_sp, self.enc2, self.b_y, hw_o, e, e, label="encoder", res_post=self.pos)
+            if fuse_o:
+                self._chain(CHAIN_ENC, "encoder", x, self.pos, self.b_y, hw_o, self.ch_enc, self.ch_enc_tab)
+            else:
+                self._pointwise(x, self.enc1, self.b_sp, hw_o, c.in_chans, e, label="encoder", bias=self.enc1_b, act=1,
+                                a_kscale=self.in_scale, a_kshift=self.in_shift)
+                self._pointwise(self.b_sp, self.enc2, self.b_y, hw_o, e, e, label="encoder", res_post=self.pos)
             cur = self.b_y
+            done = False
             for i, blk in enumerate(self.blocks):
                 tin = self.tr["outer"] if i == 0 else self.tr["inner"]
                 tout = self.tr["outer"] if i == c.num_layers - 1 else self.tr["inner"]
@@ -290,11 +401,23 @@ class SfnoEngine:
                 # GELU(filter output + inner skip(residual))
                 outer = "_outer" if tout is self.tr["outer"] else ""
                 self._pointwise(res, blk["skip"], self.b_y, hw_out, e, e, label="inner_skip" + outer, bias=blk["skip_b"], res_pre=self.b_sp, act=1)
-                self._norm(self.b_y, blk["n1_g"], blk["n1_b"], self.b_sp, e, hw_out)
-                hbuf = self.b_hid_outer if tout is self.tr["outer"] else self.b_hid
-                self._pointwise(self.b_sp, blk["fc1"], hbuf, hw_out, e, hid, label="mlp" + outer, bias=blk["fc1_b"], act=1)
-                self._pointwise(hbuf, blk["fc2"], self.b_y, hw_out, hid, e, label="mlp" + outer, bias=blk["fc2_b"], res_post=res)
+                if self.chain is not None and hw_out % 16 == 0:
+                    # norm1 as the chain's input affine; the last block's chain runs on into the decoder and writes the next state
+                    self._stats(self.b_y, blk["n1_g"], blk["n1_b"], blk["ch_tab"], e, hw_out)
+                    if i == c.num_layers - 1:
+                        self._chain(CHAIN_TAIL, "mlp_decoder", self.b_y, res, y, hw_out, blk["ch_mlp"], blk["ch_tab"], x=x, dec=blk["ch_dec"])
+                        done = True
+                    else:
+                        self._chain(CHAIN_MLP, "mlp" + outer, self.b_y, res, self.b_y, hw_out, blk["ch_mlp"], blk["ch_tab"])
+                else:
+                    self._norm(self.b_y, blk["n1_g"], blk["n1_b"], self.b_sp, e, hw_out)
+                    hbuf = self.b_hid_outer if tout is self.tr["outer"] else self.b_hid
+                    self._pointwise(self.b_sp, blk["fc1"], hbuf, hw_out, e, hid, label="mlp" + outer, bias=blk["fc1_b"], act=1)
+                    self._pointwise(hbuf, blk["fc2"], self.b_y, hw_out, hid, e, label="mlp" + outer, bias=blk["fc2_b"], res_post=res)
                 cur = self.b_y
+            if done:
+                self._mark("end")
+                return y
             # decoder on concat(cur, normalised input): W_a cur + b' , then GELU(W_b' x + .), then W2' . + mean
             if self.dec_fused:
                 self._pointwise(cur, self.dec1, self.b_xn, hw_o, e + c.in_chans, e, label="decoder", bias=self.dec1_b, act=1,
@@ -303,9 +426,6 @@ class SfnoEngine:
                 self._pointwise(cur, self.dec1a, self.b_sp, hw_o, e, e, label="decoder", bias=self.dec1_b)
                 self._pointwise(x, self.dec1b, self.b_xn, hw_o, c.in_chans, e, label="decoder", res_pre=self.b_sp, act=1,
                                 a_kscale=self.in_scale, a_kshift=self.in_shift)
-            y = out if out is not None else torch.empty((c.out_chans, c.n_lat, c.n_lon), dtype=torch.float32, device=self.device)
-            if y.device != self.device or y.dtype != torch.float32 or tuple(y.shape) != (c.out_chans, c.n_lat, c.n_lon) or not y.is_contiguous():
-                raise ValueError("bad output tensor")
             target = self.b_out if y.data_ptr() == x.data_ptr() else y
             self._pointwise(self.b_xn, self.dec2, target, hw_o, e, c.out_chans, label="decoder", bias=self.dec2_b)
             if target is self.b_out:
@@ -314,7 +434,14 @@ class SfnoEngine:
         return y
 
     def launches_per_step(self) -> int:
-        n = 2 + (2 if self.dec_fused else 3)
-        for i in range(self.cfg.num_layers):
-            n += 2 + 2 + 1 + 2 + 3 + (2 if i in (0, self.cfg.num_layers - 1) else 0)     # norms, analysis, dhconv, synthesis, skip + MLP
+        c = self.cfg
+        fo = self.chain is not None and (c.n_lat * c.n_lon) % 16 == 0
+        fi = self.chain is not None and (c.h * c.w) % 16 == 0
+        n = 1 if fo else 2                                    # encoder
+        for i in range(c.num_layers):
+            last = i == c.num_layers - 1
+            n += 1 + 2 + 1 + 2 + 1 + (2 if i in (0, c.num_layers - 1) else 0)       # norm0, analysis, dhconv, synthesis, skip (+ residual synthesis)
+            n += 2 if (fo if last else fi) else 3             # statistics + chain  |  norm1 + fc1 + fc2
+        if not fo:
+            n += 2 if self.cfg.embed_dim % 8 == 0 else 3      # decoder (part of the last chain otherwise)
         return n

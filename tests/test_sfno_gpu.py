@@ -124,6 +124,101 @@ def test_gemm_building_block_against_float64():
     assert ((out.cpu().double() - ref).abs().max() / ref.abs().max()).item() < 2e-6
 
 
+def _chain_case(shape, C, HID, KX, OUT, HW, seed):
+    """Random weights / activations of one pixel-wise chain + everything prepared the way SfnoEngine._prepare_chains does."""
+    from skyrim_amd.sfno import engine as E
+    eng = E.SfnoEngine(CONFIGS["tiny"], "cuda:0")
+    CP, HP, KXP, OP = E.chain_shapes(eng.lib)[shape]
+    gen = torch.Generator().manual_seed(seed)
+    r = lambda *s: torch.randn(*s, generator=gen, dtype=torch.float64)  # noqa: E731
+    t = dict(y=r(C, HW) * 2 + 0.5, res=r(C, HW), x=r(KX, HW) * 300 + 1e4,                    # raw fields far outside the fp16 range
+             W1=r(HID, C) / C ** 0.5, b1=r(HID) * 0.1, W2=r(C, HID) / HID ** 0.5, b2=r(C) * 0.1, sc=1 + 0.2 * r(C), sh=0.3 * r(C),
+             xs=torch.full((KX,), 1 / 300.0, dtype=torch.float64), xh=torch.full((KX,), -1e4 / 300.0, dtype=torch.float64),
+             E1=r(C, KX) / KX ** 0.5, e1=r(C) * 0.1, E2=r(C, C) / C ** 0.5,
+             V1=r(C, C + KX) / (C + KX) ** 0.5, d1=r(C) * 0.1, V2=r(OUT, C) / C ** 0.5, d2=r(OUT))
+    dev = lambda v: v.float().contiguous().cuda()  # noqa: E731
+    tab = lambda *parts: dev(torch.cat(parts))  # noqa: E731
+    z = torch.zeros
+    p = dict(eng=eng, E=E, shape=shape, dims=(CP, HP, KXP, OP), t=t, dev=dev,
+             mlp=E._Pair(eng, E._pad2(t["W1"], HP, CP), E._pad2(t["W2"], CP, HP)),
+             enc=E._Pair(eng, E._pad2(t["E1"], CP, KXP), E._pad2(t["E2"], CP, CP)))
+    v1 = z(CP, CP + KXP, dtype=torch.float64)
+    v1[:C, :C], v1[:C, CP:CP + KX] = t["V1"][:, :C], t["V1"][:, C:]
+    p["dec"] = E._Pair(eng, v1, E._pad2(t["V2"], OP, CP))
+    p["tab_mlp"] = tab(E._pad1(t["sc"], CP), E._pad1(t["sh"], CP), E._pad1(t["b1"], HP), E._pad1(t["b2"], CP),
+                       E._pad1(t["xs"], KXP), E._pad1(t["xh"], KXP), E._pad1(t["d1"], CP), E._pad1(t["d2"], OP))
+    p["tab_enc"] = tab(E._pad1(t["xs"], KXP), E._pad1(t["xh"], KXP), E._pad1(t["e1"], CP), z(CP, dtype=torch.float64))
+    return p
+
+
+@pytest.mark.parametrize("shape,C,HID,KX,OUT,HW", [(1, 40, 80, 11, 9, 16 * 37), (1, 64, 96, 32, 32, 256), (0, 256, 512, 73, 73, 128 * 5 + 48),
+                                                   (0, 200, 400, 50, 60, 16 * 21)])
+def test_pixelwise_chains_against_float64(shape, C, HID, KX, OUT, HW):
+    """sksfno_chain_run, all three modes, through torch.ops.skyrim_hip.sfno_chain: padded and exact widths of both shape classes,
+    a ragged last workgroup, raw inputs outside the fp16 range (normalised by the loader), outputs aliasing inputs."""
+    G = torch.nn.functional.gelu
+    p = _chain_case(shape, C, HID, KX, OUT, HW, 5)
+    t, dev, E = p["t"], p["dev"], p["E"]
+    hip = torch.ops.skyrim_hip
+    rel = lambda got, ref: ((got.cpu().double() - ref).abs().max() / ref.abs().max()).item()  # noqa: E731
+    # MLP
+    zref = t["W2"] @ G(t["W1"] @ (t["y"] * t["sc"][:, None] + t["sh"][:, None]) + t["b1"][:, None]) + t["b2"][:, None] + t["res"]
+    y, res, x = dev(t["y"]), dev(t["res"]), dev(t["x"])
+    out = torch.full((C, HW), float("nan"), device="cuda")
+    hip.sfno_chain(E.CHAIN_MLP, shape, y, None, res, out, HW, C, KX, OUT, p["mlp"].w1f, p["mlp"].w2f, None, None, p["tab_mlp"])
+    assert rel(out, zref) < 3e-6
+    yy = y.clone()
+    hip.sfno_chain(E.CHAIN_MLP, shape, yy, None, res, yy, HW, C, KX, OUT, p["mlp"].w1f, p["mlp"].w2f, None, None, p["tab_mlp"])     # in place
+    assert torch.equal(yy, out)
+    # TAIL = MLP + decoder on concat(block output, normalised state)
+    xn = t["x"] * t["xs"][:, None] + t["xh"][:, None]
+    oref = t["V2"] @ G(t["V1"] @ torch.cat([zref, xn]) + t["d1"][:, None]) + t["d2"][:, None]
+    o = torch.full((OUT, HW), float("nan"), device="cuda")
+    hip.sfno_chain(E.CHAIN_TAIL, shape, y, x, res, o, HW, C, KX, OUT, p["mlp"].w1f, p["mlp"].w2f, p["dec"].w1f, p["dec"].w2f, p["tab_mlp"])
+    assert rel(o, oref) < 3e-6
+    if OUT == KX:                                                 # next state written over the current one (bench.py: eng.step(x, x))
+        xx = x.clone()
+        hip.sfno_chain(E.CHAIN_TAIL, shape, y, xx, res, xx, HW, C, KX, OUT, p["mlp"].w1f, p["mlp"].w2f, p["dec"].w1f, p["dec"].w2f, p["tab_mlp"])
+        assert torch.equal(xx, o)
+    # ENC
+    eref = t["E2"] @ G(t["E1"] @ xn + t["e1"][:, None]) + t["res"]
+    eo = torch.full((C, HW), float("nan"), device="cuda")
+    hip.sfno_chain(E.CHAIN_ENC, shape, x, None, res, eo, HW, C, KX, OUT, p["enc"].w1f, p["enc"].w2f, None, None, p["tab_enc"])
+    assert rel(eo, eref) < 3e-6
+    with pytest.raises(RuntimeError):                             # HW must be a multiple of 16
+        hip.sfno_chain(E.CHAIN_MLP, shape, y, None, res, out, HW - 8, C, KX, OUT, p["mlp"].w1f, p["mlp"].w2f, None, None, p["tab_mlp"])
+
+
+def test_instance_stats_are_the_norms_affine():
+    """sksfno_instance_stats: x * scale + shift == instance norm of x (vs float64), including a large common offset."""
+    gen = torch.Generator().manual_seed(2)
+    C, HW, CP = 40, 97 * 192, 64
+    x = torch.randn(C, HW, generator=gen, dtype=torch.float64) * torch.linspace(0.1, 30, C, dtype=torch.float64)[:, None] + torch.linspace(-200, 200, C, dtype=torch.float64)[:, None]
+    g, b = torch.randn(C, generator=gen, dtype=torch.float64), torch.randn(C, generator=gen, dtype=torch.float64)
+    tab = torch.zeros(2 * CP + 7, device="cuda")
+    torch.ops.skyrim_hip.sfno_instance_stats(x.float().cuda(), g.float().cuda(), b.float().cuda(), tab, CP, C, HW, 1e-6)
+    mean, var = x.mean(1, keepdim=True), x.var(1, unbiased=False, keepdim=True)
+    ref = (x - mean) / torch.sqrt(var + 1e-6) * g[:, None] + b[:, None]
+    got = x * tab[:C].cpu().double()[:, None] + tab[CP:CP + C].cpu().double()[:, None]
+    assert ((got - ref).abs().max() / ref.abs().max()).item() < 2e-5
+    assert (tab[C:CP] == 0).all() and (tab[CP + C:] == 0).all()
+
+
+def test_fused_and_gemm_by_gemm_paths_agree(case):
+    """The default engine runs encoder / block MLPs / decoder as fused chains; fused=False runs them GEMM by GEMM.  Both meet the
+    per-step bar against the oracle and agree with each other to round-off."""
+    from skyrim_amd.sfno.engine import SfnoEngine
+    cfg, params, x, eng = case
+    assert eng.chain == 1 and eng.launches_per_step() < SfnoEngine(cfg, "cuda:0", fused=False).launches_per_step()
+    plain = SfnoEngine(cfg, "cuda:0", fused=False)
+    plain.load_params(params)
+    assert plain.chain is None
+    ref = O.forward(params, x, cfg)
+    a, b = eng.step(x.cuda()).cpu(), plain.step(x.cuda()).cpu()
+    assert O.per_channel_rel_err(a, ref).max().item() < 1e-4 and O.per_channel_rel_err(b, ref).max().item() < 1e-4
+    assert O.per_channel_rel_err(a, b).max().item() < 2e-5
+
+
 def test_errors_are_loud():
     from skyrim_amd.sfno.engine import SfnoEngine
     cfg = CONFIGS["tiny"]

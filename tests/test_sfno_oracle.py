@@ -101,12 +101,24 @@ def test_sfno_library_exports_declared_symbols_and_rejects_bad_arguments():
     syms = sorted(set(re.findall(r"\b(sksfno_[a-z_]+)\s*\(", header)))
     lib = E.load_library()
     assert set(syms) == set(E.EXPORTS) and all(hasattr(lib, s) for s in syms)
-    assert lib.sksfno_abi_version() == 1
+    assert lib.sksfno_abi_version() == 2
     assert lib.sksfno_gemm_run(None, None) == -1
     d = E.GemmDesc()
     assert lib.sksfno_gemm_run(ctypes.byref(d), None) == -1                       # null pointers / zero sizes
     assert lib.sksfno_instance_norm(None, None, None, None, 4, 16, 1e-6, None) == -1
     assert lib.sksfno_prepare_weight(None, 1, 1, 4, 4, None, 0, 8, None) == -1
+    # ABI v2: fused pixel-wise chains
+    assert E.chain_shapes(lib) == [(256, 512, 96, 96), (64, 96, 32, 32)]
+    assert lib.sksfno_chain_run(None, None) == -1
+    assert lib.sksfno_chain_run(ctypes.byref(E.ChainDesc()), None) == -1
+    one = ctypes.c_void_p(16)                                                     # non-null, never dereferenced: argument checks come first
+    bad_hw = E.ChainDesc(E.CHAIN_MLP, 1, one, None, one, one, 24, 40, 11, 9, one, one, None, None, one)      # HW not a multiple of 16
+    too_wide = E.ChainDesc(E.CHAIN_MLP, 1, one, None, one, one, 32, 65, 11, 9, one, one, None, None, one)    # embed wider than the class
+    no_dec = E.ChainDesc(E.CHAIN_TAIL, 1, one, one, one, one, 32, 40, 11, 9, one, one, None, None, one)      # TAIL without decoder weights
+    for d in (bad_hw, too_wide, no_dec):
+        assert lib.sksfno_chain_run(ctypes.byref(d), None) == -1
+    assert lib.sksfno_instance_stats(None, None, None, None, None, 4, 16, 1e-6, None) == -1
+    assert lib.sksfno_prepare_chain_weights(one, one, 40, 64, 64, one, one, None) == -1                      # K not a multiple of 32
 
 
 @pytest.mark.parametrize("grid,n_lat,n_lon,lmax", [("equiangular", 33, 64, 16), ("legendre-gauss", 24, 48, 24), ("equiangular", 97, 192, 32)])
