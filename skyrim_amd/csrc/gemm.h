@@ -44,6 +44,11 @@ struct GemmArgs {
     int M, N, K;              // K: loop bound (multiple of 8; loader and W both zero-fill beyond their own extent)
 };
 
+// loaders that take the k-tile (wave-uniform) and the thread's slot separately declare  static constexpr bool kUniformK = true
+template <class AL, class = void> struct al_uniform_k_t { static constexpr bool value = false; };
+template <class AL> struct al_uniform_k_t<AL, decltype((void)AL::kUniformK)> { static constexpr bool value = AL::kUniformK; };
+template <class AL> constexpr bool al_uniform_k_v = al_uniform_k_t<AL>::value;
+
 template <class P, class TC>
 constexpr int gemm_smem_bytes() { return (P::NA * TC::BM + P::NW * TC::BN) * TC::BK * 2; }
 
@@ -92,7 +97,10 @@ __device__ __forceinline__ void gemm_body(const GemmArgs<P, AL, EP>& g, char* sm
         const int k = kt * BK + st_slot * 8;
 #pragma unroll
         for (int i = 0; i < TC::A_CHUNKS; ++i) {
-            if (TC::A_CHUNKS * ROWS_PER_PASS == BM || st_row + i * ROWS_PER_PASS < BM) g.al.issue(arow[i], k, araw[i]);
+            if (TC::A_CHUNKS * ROWS_PER_PASS == BM || st_row + i * ROWS_PER_PASS < BM) {
+                if constexpr (al_uniform_k_v<AL>) g.al.issue2(arow[i], kt * BK, st_slot * 8, BK, araw[i]);     // uniform base + per-thread offset
+                else g.al.issue(arow[i], k, araw[i]);
+            }
         }
 #pragma unroll
         for (int j = 0; j < TC::W_CHUNKS; ++j) {
@@ -131,12 +139,21 @@ __device__ __forceinline__ void gemm_body(const GemmArgs<P, AL, EP>& g, char* sm
 
     const int nk = (g.K + BK - 1) / BK;
     const int fr_row = lane & 15, fr_grp = lane >> 4;
+#ifdef SKP_PROBE_NO_LOAD      // timing probe (tools/sfno_probe.sh): the operands are fetched once, every k-tile reuses them
     load_tile(0);
+#define SKP_PROBE_LOAD(kt) ((void)0)
+#else
+#define SKP_PROBE_LOAD(kt) load_tile(kt)
+    load_tile(0);
+#endif
     g.ep.template init<TC>(smem + gemm_smem_bytes<P, TC>() + kEpiReduceBytes, tid, n0);   // ordered by the loop's first barrier
     for (int kt = 0; kt < nk; ++kt) {
         stage_tile();
         __syncthreads();
-        if (kt + 1 < nk) load_tile(kt + 1);
+        if (kt + 1 < nk) SKP_PROBE_LOAD(kt + 1);
+#ifdef SKP_PROBE_NO_MFMA
+        if (kt >= 0) { __syncthreads(); continue; }
+#endif
 #pragma unroll
         for (int ks = 0; ks < BK / 32; ++ks) {
             const int slot = ks * 4 + fr_grp;
@@ -174,6 +191,9 @@ __device__ __forceinline__ void gemm_body(const GemmArgs<P, AL, EP>& g, char* sm
         }
         __syncthreads();
     }
+#ifdef SKP_PROBE_NO_EPILOGUE
+    if (g.M > 0) { if (acc[0][0][0] == 12345.678f) g.ep.template run<TC, SWAP>(acc, m0 + wm * TC::WTM, n0 + wn * TC::WTN, lane, wm, wn, smem + gemm_smem_bytes<P, TC>(), g.M, g.N, (int)blockIdx.x); return; }
+#endif
     g.ep.template run<TC, SWAP>(acc, m0 + wm * TC::WTM, n0 + wn * TC::WTN, lane, wm, wn, smem + gemm_smem_bytes<P, TC>(), g.M, g.N, (int)blockIdx.x);
 }
 

@@ -11,6 +11,8 @@
 // loader issues scalar loads when k is not the contiguous index; layout-specialised loaders are the next step.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "../../include/skyrim_sfno.h"
 #include "strided_gemm.h"
 
@@ -18,8 +20,8 @@ namespace skp {
 
 
 
-template <class PX, bool SWAP>
-__global__ void __launch_bounds__(TG::THREADS) gemm_strided_kernel(GemmArgs<PX, ALStrided, EpStrided> g, BatchStrides bs) {
+template <class PX, class AL, bool SWAP>
+__global__ void __launch_bounds__(TG::THREADS) gemm_strided_kernel(GemmArgs<PX, AL, EpStrided> g, BatchStrides bs) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const long long z = blockIdx.z;
     g.al.a += z * bs.a;
@@ -40,7 +42,7 @@ __global__ void __launch_bounds__(TG::THREADS) gemm_strided_kernel(GemmArgs<PX, 
         if (cap < g.M) { g.M = cap; g.al.M = cap; }
         if ((int)blockIdx.y * TG::BM >= g.M) return;
     }
-    gemm_body<PX, TG, ALStrided, EpStrided, SWAP>(g, smem);
+    gemm_body<PX, TG, AL, EpStrided, SWAP>(g, smem);
 }
 
 // ---- instance norm over (H, W) per channel: two passes for the statistics, one to apply ---- //
@@ -119,20 +121,32 @@ int sksfno_gemm_run(const sksfno_gemm* d, void* stream) {
     // rows contiguous in the output (NCHW activations): un-swapped order gives 4 consecutive rows per lane
     const bool swap = !(d->o_sm == 1 && d->o_sn != 1);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    auto launch = [&](auto px) {
+    auto launch = [&](auto px, auto loader) {
         typedef decltype(px) PX;
-        GemmArgs<PX, ALStrided, EpStrided> g;
-        g.al = al; g.ep = ep;
+        typedef decltype(loader) AL;
+        GemmArgs<PX, AL, EpStrided> g;
+        g.al = loader; g.ep = ep;
         g.W = static_cast<const f16*>(d->w);
         g.w_plane = d->w_plane;
         g.ldw = d->ldw;
         g.M = d->M; g.N = d->N; g.K = d->K;
         constexpr int smem = gemm_smem_bytes<PX, TG>() + kEpiScratch;
-        if (swap) hipLaunchKernelGGL((gemm_strided_kernel<PX, true>), grid, dim3(TG::THREADS), smem, st, g, bs);
-        else      hipLaunchKernelGGL((gemm_strided_kernel<PX, false>), grid, dim3(TG::THREADS), smem, st, g, bs);
+        if constexpr (smem > 64 * 1024) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_strided_kernel<PX, AL, true>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_strided_kernel<PX, AL, false>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        }
+        if (swap) hipLaunchKernelGGL((gemm_strided_kernel<PX, AL, true>), grid, dim3(TG::THREADS), smem, st, g, bs);
+        else      hipLaunchKernelGGL((gemm_strided_kernel<PX, AL, false>), grid, dim3(TG::THREADS), smem, st, g, bs);
     };
-    if (d->terms == 2) launch(PrecF16x2W{});      // A as one fp16 plane, W hi/lo
-    else               launch(PrecF16x3{});
+    // the loader without per-element predicates wherever the operand allows it (strided_gemm.h: ALFast)
+    const long long a_extent = (long long)((d->M - 1) / d->a_m1) * d->a_sm2 + (long long)(d->a_m1 < d->M ? d->a_m1 - 1 : d->M - 1) * d->a_sm + (long long)(d->K - 1) * d->a_sk;
+    static const bool no_fast = getenv("SKSFNO_NO_FAST_LOADER") != nullptr;
+    const bool fast = !no_fast && d->terms != 2 && !d->a_kscale && !d->a2 && (d->K & 7) == 0 && d->a_sm >= 0 && d->a_sm2 >= 0 && d->a_sk > 0 && a_extent < (1ll << 30);
+    const bool vec = fast && d->a_sk == 1 && (reinterpret_cast<size_t>(d->a) & 15) == 0 && !(d->a_sm & 3) && !(d->a_sm2 & 3) && !(d->a_sb & 3);
+    if (vec)       launch(PrecF16x3{}, ALFast<true>{d->a, d->M, d->K, d->a_m1, d->a_sm, d->a_sm2, d->a_sk});
+    else if (fast) launch(PrecF16x3{}, ALFast<false>{d->a, d->M, d->K, d->a_m1, d->a_sm, d->a_sm2, d->a_sk});
+    else if (d->terms == 2) launch(PrecF16x2W{}, al);      // A as one fp16 plane, W hi/lo
+    else                    launch(PrecF16x3{}, al);
     return hipGetLastError() == hipSuccess ? 0 : SKSFNO_E_HIP;
 }
 

@@ -59,6 +59,52 @@ struct ALStrided {
     __device__ __forceinline__ uint4 direct(const Raw&) const { return make_uint4(0, 0, 0, 0); }
 };
 
+// ---- A operand: fp32, strided, the common case without the loader's per-element predicates -------------------------------- //
+// One source, no affine, K a multiple of 8, every element offset of one batch below 2^30 (checked at launch).  Rows beyond M are
+// clamped to the last row instead of predicated (their products are never stored); every k-tile but a ragged last one is fetched
+// as  uniform base (SGPR) + one 32-bit per-thread byte offset that does not change over the k loop  -- no address VALU, no
+// exec-mask branches (the general loader spends ~250 VALU instructions and ~40 branches per k-tile and thread on them).
+template <bool VEC>
+struct ALFast {
+    static constexpr bool kDirect = false, kUniformK = true;
+    const float* a;
+    int M, K, m1;
+    long long sm, sm2, sk;
+    struct Row { unsigned off; };
+    struct Raw { float v[8]; };
+    __device__ __forceinline__ Row row(int m) const {
+        m = m < M ? m : M - 1;
+        const int hi = m / m1, lo = m - hi * m1;
+        return Row{(unsigned)(hi * sm2 + lo * sm)};
+    }
+    __device__ __forceinline__ void issue2(const Row& r, int k_tile, int k_slot, int bk, Raw& o) const {
+        if (k_tile + bk <= K) {                                            // wave-uniform
+            const float* base = a + (long long)k_tile * sk;                // uniform
+            const unsigned vb = (r.off + (unsigned)k_slot * (unsigned)sk) * 4u;
+            if constexpr (VEC) {
+                const float4 x = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base) + vb);
+                const float4 y = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base + 4) + vb);
+                o.v[0] = x.x; o.v[1] = x.y; o.v[2] = x.z; o.v[3] = x.w; o.v[4] = y.x; o.v[5] = y.y; o.v[6] = y.z; o.v[7] = y.w;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) o.v[i] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base + (long long)i * sk) + vb);
+            }
+        } else {                                                           // ragged last k-tile: a chunk is inside K or outside (K % 8 == 0)
+            const int k = k_tile + k_slot;
+            const bool ok = k < K;
+            const float* p = a + r.off + (long long)(ok ? k : 0) * sk;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { const float t = p[(long long)i * sk]; o.v[i] = ok ? t : 0.f; }
+        }
+    }
+    __device__ __forceinline__ void issue(const Row&, int, Raw&) const {}
+    __device__ __forceinline__ void finish(const Raw& r, float (&v)[8]) const {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = r.v[i];
+    }
+    __device__ __forceinline__ uint4 direct(const Raw&) const { return make_uint4(0, 0, 0, 0); }
+};
+
 __device__ __forceinline__ float swish(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }
 
 // ---- epilogue: bias, residual before the activation, GELU, residual after, strided fp32 store ---- //
@@ -163,7 +209,13 @@ struct EpStrided {
     }
 };
 
-typedef TileCfg<128, 256, 32, 2, 4> TG;      // wide N: the fp32 A operand is fetched and split once per 256 output columns
+#ifndef SKP_STRIDED_BK
+#define SKP_STRIDED_BK 32
+#endif
+#ifndef SKP_STRIDED_TILE
+#define SKP_STRIDED_TILE 128, 256, SKP_STRIDED_BK, 2, 4
+#endif
+typedef TileCfg<SKP_STRIDED_TILE> TG;      // wide N: the fp32 A operand is fetched and split once per 256 output columns
 
 struct BatchStrides { long long a, w, o; int k_lo_step, m_cap0, m_cap_step; };
 

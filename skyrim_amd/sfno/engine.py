@@ -160,6 +160,9 @@ class SfnoEngine:
         self.terms = terms
         self.fused = (os.environ.get("SKYRIM_SFNO_UNFUSED", "0") != "1") if fused is None else bool(fused)
         self.chain = None                 # shape class of the fused chains, set by load_params
+        # layout of the longitude spectrum between the DFT and Legendre GEMMs: "order" = [order, re/im][C][lat], "channel" = [C][order, re/im][lat]
+        self.f_ana = os.environ.get("SKSFNO_F_ANA", "order")
+        self.f_syn = os.environ.get("SKSFNO_F_SYN", "order")
         if not torch.cuda.is_available():
             raise RuntimeError("SfnoEngine needs an MI355X: the SFNO path has no CPU fallback")
         self.lib = load_library()
@@ -342,6 +345,12 @@ class SfnoEngine:
         # truncated DFT, one batch per channel: rows = latitudes, k = longitude -> spectrum [order, re/im][C][ldl] (order-major, so
         # that the Legendre GEMM of one order reads k = latitude contiguously)
         self._label = "dft"
+        if self.f_ana == "channel":        # spectrum [C][order, re/im][ldl]: the DFT of a channel writes one dense region
+            self._gemm(x, tr["dft"], self.b_f, H, Wd, 2 * Mm, batch=C, a_sb=H * Wd, a_sm=Wd, a_sk=1, o_sb=2 * Mm * ldl, o_sm=1, o_sn=ldl, w_batched=False)
+            self._label = "legendre_analysis"
+            self._gemm(self.b_f, tr["ana"], self.b_coef, 2 * C, H, L, batch=Mm, a_sb=2 * ldl, a_m1=C, a_sm=2 * Mm * ldl, a_sm2=ldl, a_sk=1,
+                       o_sb=2 * C, o_sm=1, o_sn=Mm * 2 * C)
+            return
         self._gemm(x, tr["dft"], self.b_f, H, Wd, 2 * Mm, batch=C, a_sb=H * Wd, a_sm=Wd, a_sk=1, o_sb=ldl, o_sm=1, o_sn=C * ldl, w_batched=False)
         # per order m: rows (re/im, channel), k = latitude
         self._label = "legendre_analysis"
@@ -354,6 +363,12 @@ class SfnoEngine:
         H, Wd, Mm, L, ldl = tr["n_lat"], tr["n_lon"], c.mmax, c.lmax, self.ldl
         self._label = "legendre_synthesis"
         # order m only has degrees l >= m: the contraction over l starts at (the 32-aligned floor of) m
+        if self.f_syn == "channel":        # spectrum [C][order, re/im][ldl]: the inverse DFT of a channel reads one dense region
+            self._gemm(coef, tr["syn"], self.b_f, 2 * C, L, H, batch=Mm, a_sb=2 * C, a_sm=1, a_sk=Mm * 2 * C,
+                       o_sb=2 * ldl, o_m1=C, o_sm=2 * Mm * ldl, o_sm2=ldl, o_sn=1, k_lo_step=1)
+            self._label = "idft"
+            self._gemm(self.b_f, tr["idft"], out, H, 2 * Mm, Wd, batch=C, a_sb=2 * Mm * ldl, a_sm=1, a_sk=ldl, o_sb=H * Wd, o_sm=Wd, o_sn=1, w_batched=False, **kw)
+            return
         self._gemm(coef, tr["syn"], self.b_f, 2 * C, L, H, batch=Mm, a_sb=2 * C, a_sm=1, a_sk=Mm * 2 * C,
                    o_sb=2 * C * ldl, o_sm=ldl, o_sn=1, k_lo_step=1)
         self._label = "idft"
