@@ -17,6 +17,8 @@
 // 32 bp + 8 (lane >> 4) + [0..7]: exactly an input fragment of the NEXT pair, so TAIL chains two pairs without leaving registers.
 // Activations are [C][HW] fp32 (pixels contiguous): a fragment is fetched with 8 dword loads per lane (16 consecutive pixels
 // of 4 x 8 channels per instruction) and stored the same way.  HW must be a multiple of 16.  gfx950 only.
+#include <cstdlib>
+
 #include "gemm_dma.h"
 #include "../../include/skyrim_sfno.h"
 
@@ -24,22 +26,26 @@ namespace skp {
 
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
 
-template <int MODE_, int CP_, int HP_, int KXP_, int OP_, int FM_ = 1, int NWAVES_ = 8>
+template <int MODE_, int CP_, int HP_, int KXP_, int OP_, int FM_ = 1, int NWAVES_ = 8, int WPE_ = 0>
 struct ChainShape {
     static constexpr int MODE = MODE_, CP = CP_, HP = HP_, KXP = KXP_, OP = OP_, FM = FM_, NWAVES = NWAVES_;
-    static constexpr int THREADS = 64 * NWAVES, WPE = NWAVES / 4, BM = NWAVES * FM * 16;
+    static constexpr int WPE = WPE_ ? WPE_ : NWAVES / 4;     // waves per SIMD the kernel is compiled for (2 with 4 waves = two workgroups per CU)
+    static constexpr int THREADS = 64 * NWAVES, BM = NWAVES * FM * 16;
     static constexpr bool TAIL = MODE == SKSFNO_CHAIN_TAIL;
     // pair 0:  K0 -> H0 -> CP        (ENC: the state's channels -> embed -> embed;  MLP / TAIL: embed -> hidden -> embed)
     static constexpr int K0 = MODE == SKSFNO_CHAIN_ENC ? KXP : CP, H0 = MODE == SKSFNO_CHAIN_ENC ? CP : HP;
     static constexpr int KS0 = K0 / 32, NCH0 = H0 / 32, CF0 = CP / 16;
     // pair 1 (TAIL): concat(embed, state) -> embed -> output channels
     static constexpr int KS1 = (CP + KXP) / 32, NCH1 = CP / 32, CF1 = OP / 16;
-    static constexpr int A_BLK = cmax(KS0 * 4, TAIL ? KS1 * 4 : 0), B_BLK = cmax(CF0 * 2, TAIL ? CF1 * 2 : 0);      // KiB per stage
+    // LDS stages (KiB): pair 0 keeps its W1 chunk at [0, A0) and its W2 chunk at [A0, A0 + B0); pair 1 reuses the same space as
+    // [0, A1) and [A1, A1 + B1) -- its first W1 chunk is requested only after every wave has left pair 0
+    static constexpr int A0 = KS0 * 4, B0 = CF0 * 2, A1 = KS1 * 4, B1 = CF1 * 2;
+    static constexpr int LDS_BLK = cmax(A0 + B0, TAIL ? A1 + B1 : 0);
     // table (floats): scale[K0] shift[K0] b1[H0] b2[CP]  (+ TAIL: xscale[KXP] xshift[KXP] d1[CP] d2[OP])
     static constexpr int T_SCALE = 0, T_SHIFT = K0, T_B1 = 2 * K0, T_B2 = T_B1 + H0;
     static constexpr int T_XSCALE = T_B2 + CP, T_XSHIFT = T_XSCALE + KXP, T_D1 = T_XSHIFT + KXP, T_D2 = T_D1 + CP;
     static constexpr int TAB = TAIL ? T_D2 + OP : T_B2 + CP;
-    static constexpr int SMEM = (A_BLK + B_BLK) * 1024 + TAB * 4;
+    static constexpr int SMEM = LDS_BLK * 1024 + TAB * 4;
     static_assert(CP % 32 == 0 && HP % 32 == 0 && KXP % 32 == 0 && OP % 32 == 0, "padded widths are multiples of 32");
     static_assert(SMEM <= 160 * 1024, "LDS");
 };
@@ -115,7 +121,11 @@ __device__ __forceinline__ void run_pair(const v8 (&xh)[S::FM][KS], const v8 (&x
                                          const float* b1, const char* stA, const char* stB, unsigned ldsA, unsigned ldsB, int wave, int lane, After&& after_last) {
     constexpr int FM = S::FM, DEPTH = 3, NS = KS * 2, W1_BLK = KS * 4, W2_BLK = CF * 2;
     const int g = lane >> 4;
+#ifdef SKP_PROBE_NO_COMPUTE      // timing probe: one chunk instead of NCH
+    for (int j = 0; j < 1; ++j) {
+#else
     for (int j = 0; j < NCH; ++j) {
+#endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                               // W1 block j landed; every wave is done with W2 block j - 1
         dma_blocks<W2_BLK, S::NWAVES>(w2f + ((long long)j * W2_BLK << 9), ldsB, wave, lane);
@@ -183,14 +193,12 @@ __global__ void __launch_bounds__(S::THREADS) __attribute__((amdgpu_waves_per_eu
 sfno_chain_kernel(const ChainArgs a) {
     constexpr int FM = S::FM, KS0 = S::KS0, CF0 = S::CF0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const char* stA = smem;
-    const char* stB = smem + S::A_BLK * 1024;
-    float* tab = reinterpret_cast<float*>(smem + (S::A_BLK + S::B_BLK) * 1024);
+    float* tab = reinterpret_cast<float*>(smem + S::LDS_BLK * 1024);
     const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const unsigned ldsA = (unsigned)(size_t)smem, ldsB = ldsA + S::A_BLK * 1024;
+    const unsigned lds0 = (unsigned)(size_t)smem;
 
-    dma_blocks<KS0 * 4, S::NWAVES>(a.w1f, ldsA, wave, lane);
+    dma_blocks<KS0 * 4, S::NWAVES>(a.w1f, lds0, wave, lane);
     for (int i = tid; i < S::TAB; i += S::THREADS) tab[i] = a.tab[i];
     __syncthreads();
 
@@ -208,9 +216,7 @@ sfno_chain_kernel(const ChainArgs a) {
 #pragma unroll
         for (int c = 0; c < CF0; ++c) yacc[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    run_pair<S, KS0, S::NCH0, CF0>(xh, xl, yacc, a.w1f, a.w2f, tab + S::T_B1, stA, stB, ldsA, ldsB, wave, lane, [&] {
-        if constexpr (S::TAIL) dma_blocks<S::KS1 * 4, S::NWAVES>(a.v1f, ldsA, wave, lane);
-    });
+    run_pair<S, KS0, S::NCH0, CF0>(xh, xl, yacc, a.w1f, a.w2f, tab + S::T_B1, smem, smem + S::A0 * 1024, lds0, lds0 + S::A0 * 1024, wave, lane, [] {});
 
     if constexpr (!S::TAIL) {
         // + b2 + residual (ENC: position embedding), store channel-major.  All loads before the first store.
@@ -239,6 +245,8 @@ sfno_chain_kernel(const ChainArgs a) {
             }
         }
     } else {
+        __syncthreads();                               // every wave has left pair 0: its stages are free
+        dma_blocks<S::KS1 * 4, S::NWAVES>(a.v1f, lds0, wave, lane);      // lands under the loads and the arithmetic below
         // block output = yacc + b2 + residual -> fragments 0 .. CP/32 - 1 of the decoder's input; the normalised state -> the rest
         constexpr int KS1 = S::KS1, CF1 = S::CF1;
         v8 zh[FM][KS1], zl[FM][KS1];
@@ -277,7 +285,7 @@ sfno_chain_kernel(const ChainArgs a) {
         for (int t = 0; t < FM; ++t)
 #pragma unroll
             for (int c = 0; c < CF1; ++c) zacc[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-        run_pair<S, KS1, S::NCH1, CF1>(zh, zl, zacc, a.v1f, a.v2f, tab + S::T_D1, stA, stB, ldsA, ldsB, wave, lane, [] {});
+        run_pair<S, KS1, S::NCH1, CF1>(zh, zl, zacc, a.v1f, a.v2f, tab + S::T_D1, smem, smem + S::A1 * 1024, lds0, lds0 + S::A1 * 1024, wave, lane, [] {});
 #pragma unroll
         for (int t = 0; t < FM; ++t) {
             if (!live[t]) continue;
@@ -381,10 +389,18 @@ hipError_t launch_chain(const ChainArgs& a, hipStream_t s) {
 // padded widths per shape class: {CP, HP, KXP, OP}
 constexpr int kShapes[2][4] = {{256, 512, 96, 96}, {64, 96, 32, 32}};
 
+// One 8-wave workgroup of 128 pixels per CU by default.  SKSFNO_CHAIN_WAVES=4: two independent 4-wave workgroups of 64 pixels per CU
+// (twice the weight traffic per pixel) -- measured equal at 721 x 1440 (18.54 vs 18.56 ms/step): the chunk loop, not the operand
+// loads / stores around it, sets the pace (with one chunk instead of all of them the three chains take 1.9 of their 4.9 ms).
 template <int MODE>
 hipError_t launch_mode(int shape, const ChainArgs& a, hipStream_t s) {
-    if (shape == 0) return launch_chain<ChainShape<MODE, kShapes[0][0], kShapes[0][1], kShapes[0][2], kShapes[0][3]>>(a, s);
-    return launch_chain<ChainShape<MODE, kShapes[1][0], kShapes[1][1], kShapes[1][2], kShapes[1][3]>>(a, s);
+    static const int waves = [] { const char* v = getenv("SKSFNO_CHAIN_WAVES"); return v ? atoi(v) : 8; }();
+    if (shape == 0) {
+        if (waves == 8) return launch_chain<ChainShape<MODE, kShapes[0][0], kShapes[0][1], kShapes[0][2], kShapes[0][3], 1, 8>>(a, s);
+        return launch_chain<ChainShape<MODE, kShapes[0][0], kShapes[0][1], kShapes[0][2], kShapes[0][3], 1, 4, 2>>(a, s);
+    }
+    if (waves == 8) return launch_chain<ChainShape<MODE, kShapes[1][0], kShapes[1][1], kShapes[1][2], kShapes[1][3], 1, 8>>(a, s);
+    return launch_chain<ChainShape<MODE, kShapes[1][0], kShapes[1][1], kShapes[1][2], kShapes[1][3], 1, 4, 2>>(a, s);
 }
 
 }  // namespace skp

@@ -12,3 +12,7 @@ run default
 for v in NO_LOAD NO_MFMA NO_EPILOGUE; do build $v -DSKP_PROBE_$v; run $v SKYRIM_SFNO_LIB=/tmp/libskyrim_sfno_$v.so; done
 build bk64 -DSKP_STRIDED_BK=64; run bk64 SKYRIM_SFNO_LIB=/tmp/libskyrim_sfno_bk64.so
 build t128x128 "-DSKP_STRIDED_TILE=128,128,32,2,2"; run t128x128 SKYRIM_SFNO_LIB=/tmp/libskyrim_sfno_t128x128.so
+# the fused chains with ONE hidden chunk instead of all of them: what their operand loads / stores alone cost
+hipcc $F -DSKP_PROBE_NO_COMPUTE -c $C/sfno_chain.hip -o /tmp/probe_chain.o && hipcc --offload-arch=gfx950 -shared -fPIC -o /tmp/libskyrim_sfno_nc.so $L/obj/sfno_ops.o /tmp/probe_chain.o $L/obj/aux.o
+run chain_1chunk SKYRIM_SFNO_LIB=/tmp/libskyrim_sfno_nc.so
+run chain_4waves SKSFNO_CHAIN_WAVES=4
