@@ -18,7 +18,7 @@
 extern "C" {
 #endif
 
-#define SKGC_ABI_VERSION 2
+#define SKGC_ABI_VERSION 3
 #define SKGC_E_ARG (-1)
 #define SKGC_E_HIP (-2)
 
@@ -83,6 +83,11 @@ typedef struct skgc_sum_desc {
     const float* res;        /* NULL or [rows][512]; out may alias res */
     float* out;              /* [rows][512] */
     long long rows;
+    /* ABI v3.  group == 3: `rows` counts GROUPS of three input rows and out[g] = sum over the group's members of the LayerNorm
+     * output (the receiver sum of the mesh->grid edges: three edges into every grid node).  The input has 48 * ceil(rows / 16)
+     * virtual rows -- row 48 t + 16 a + l is member a of group 16 t + l -- and every source is addressed through its index
+     * array in that order (entries of groups >= rows: any valid row); res must be NULL.  0 / 1: one output row per input row. */
+    int group;
 } skgc_sum_desc;
 int skgc_sum_linear_layer_norm(const skgc_sum_desc* desc, void* stream);
 

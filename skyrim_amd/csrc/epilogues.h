@@ -241,7 +241,10 @@ struct SinkStore {              // out[dest][c..c+7] = y as hi/lo planes
     }
 };
 
-template <class RowMap, class Sink>
+// GROUP > 1 (= the wave tile's FM): the tile's rows come in groups -- fragment a of a wave tile holds member a of the 16 groups
+// (m0w / (16 FM)) * 16 + (lane & 15) -- and what is stored is the SUM of the members' LayerNorm outputs, one row per group
+// (GraphCast's mesh->grid edges: the three edges into a grid node, summed by the receiver; graphcast_ops.hip).
+template <class RowMap, class Sink, int GROUP = 1>
 struct EpLayerNorm {
     static constexpr bool kDualOrder = false;
     // gamma | beta | bias of this tile's BN columns -> LDS (read back with ds_read: no VMEM load between the stores)
@@ -259,9 +262,11 @@ struct EpLayerNorm {
     const float* gamma;      // [BN]
     const float* beta;       // [BN]
     float eps;
+    int n_groups = 0;        // GROUP > 1: number of groups (= output rows)
     template <class TC, bool SWAP>
     __device__ __forceinline__ void run(f32x4 (&acc)[TC::FM][TC::FN], int m0w, int n0w, int lane, int wm, int wn, char* smem, int M, int N, int ntile) const {
         static_assert(SWAP && TC::FN % 2 == 0, "swapped order, fragment pairs");
+        static_assert(GROUP == 1 || (GROUP == TC::FM && !Sink::kLoads), "grouped rows: one member per fragment, no residual");
         constexpr int FM = TC::FM, FN = TC::FN, FP = TC::FN / 2, WN = TC::WN, BM = TC::BM, BN = TC::BN;
         const int l15 = lane & 15, l8 = (lane >> 4) * 8;
         const int nloc0 = n0w - ntile * BN;          // column of this wave inside the LN group
@@ -337,6 +342,27 @@ struct EpLayerNorm {
 #pragma unroll
             for (int w = 0; w < WN; ++w) s += red2[(wm * TC::WTM + a * 16 + l15) * WN + w];
             rstd[a] = rsqrtf(s * (1.0f / BN) + eps);
+        }
+        if constexpr (GROUP > 1) {
+            const long long grow = (long long)(m0w / (16 * FM)) * 16 + l15;
+#pragma unroll
+            for (int bp = 0; bp < FP; ++bp) {
+                const int c = nloc0 + bp * 32 + l8;
+                const float4 g0 = *reinterpret_cast<const float4*>(tab + c), g1 = *reinterpret_cast<const float4*>(tab + c + 4);
+                const float4 e0 = *reinterpret_cast<const float4*>(tab + BN + c), e1 = *reinterpret_cast<const float4*>(tab + BN + c + 4);
+                float y[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int a = 0; a < FM; ++a) {
+                    const f32x4 &x = acc[a][2 * bp], &z = acc[a][2 * bp + 1];
+                    const float mu = mean[a], rs = rstd[a];
+                    y[0] += (x[0] - mu) * rs * g0.x + e0.x; y[1] += (x[1] - mu) * rs * g0.y + e0.y;
+                    y[2] += (x[2] - mu) * rs * g0.z + e0.z; y[3] += (x[3] - mu) * rs * g0.w + e0.w;
+                    y[4] += (z[0] - mu) * rs * g1.x + e1.x; y[5] += (z[1] - mu) * rs * g1.y + e1.y;
+                    y[6] += (z[2] - mu) * rs * g1.z + e1.z; y[7] += (z[3] - mu) * rs * g1.w + e1.w;
+                }
+                if (grow < n_groups) sink.put(grow, BN, c, y, old[0][0]);
+            }
+            return;
         }
 #pragma unroll
         for (int a = 0; a < FM; ++a) {

@@ -133,6 +133,9 @@ struct SinkRowsF32 {
 // k-step against one 64 KB weight k-tile; the 64-row tile TLN64 re-stages that weight tile twice as often)
 typedef TileCfg<64, 512, 32, 1, 8> TLN64;
 typedef TileCfg<128, 512, 32, 2, 4> TLN128;
+// groups of three rows summed after the LayerNorm (skgc_sum_desc::group == 3): 2 x 4 waves with 48 x 128 wave tiles, fragment a of a
+// wave tile = member a of its 16 groups, so the sum over the members is a sum over a lane's own registers
+typedef TileCfg<96, 512, 32, 2, 4> TLN96;
 static int ln_tile_rows() { static const int v = [] { const char* e = getenv("SKGC_LN_TILE"); return e ? atoi(e) : 128; }(); return v; }
 
 template <class TLN, bool RES>
@@ -145,6 +148,11 @@ template <class TLN, bool RES>
 __global__ void __launch_bounds__(TLN::THREADS) sum_linear_ln_kernel(const GemmArgs<PrecF16x3, ALSumGather, EpLayerNorm<RowMapIndexed, SinkRowsF32<RES>>> g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     gemm_body<PrecF16x3, TLN, ALSumGather, EpLayerNorm<RowMapIndexed, SinkRowsF32<RES>>, true>(g, smem);
+}
+
+__global__ void __launch_bounds__(TLN96::THREADS) sum3_linear_ln_kernel(const GemmArgs<PrecF16x3, ALSumGather, EpLayerNorm<RowMapIndexed, SinkRowsF32<false>, 3>> g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    gemm_body<PrecF16x3, TLN96, ALSumGather, EpLayerNorm<RowMapIndexed, SinkRowsF32<false>, 3>, true>(g, smem);
 }
 
 __global__ void __launch_bounds__(TG::THREADS) gather_gemm_kernel(const GemmArgs<PrecF16x3, ALGather, EpStrided> g) {
@@ -272,6 +280,26 @@ static int sum_linear_layer_norm_t(const skgc_sum_desc* d, const ALSumGather& al
     return e == hipSuccess ? 0 : SKGC_E_HIP;
 }
 
+// rows = 48 x ceil(groups / 16) virtual rows: row 48 t + 16 a + l is member a of group 16 t + l (the index arrays carry that order)
+static int sum3_linear_layer_norm(const skgc_sum_desc* d, const ALSumGather& al, void* stream) {
+    typedef EpLayerNorm<RowMapIndexed, SinkRowsF32<false>, 3> EP;
+    const long long vrows = (d->rows + 15) / 16 * 48;
+    if (vrows > 0x7fffffff) return SKGC_E_ARG;
+    GemmArgs<PrecF16x3, ALSumGather, EP> g;
+    g.al = al;
+    g.al.M = (int)vrows;
+    g.ep = EP{RowMapIndexed{nullptr}, SinkRowsF32<false>{d->out, nullptr}, d->bias, d->gamma, d->beta, 1e-5f, (int)d->rows};
+    g.W = static_cast<const f16*>(d->w);
+    g.w_plane = d->w_plane;
+    g.ldw = d->ldw;
+    g.M = (int)vrows; g.N = TLN96::BN; g.K = d->K;
+    constexpr int smem = gemm_smem_bytes<PrecF16x3, TLN96>() + kEpiScratch;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sum3_linear_ln_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e != hipSuccess) return SKGC_E_HIP;
+    hipLaunchKernelGGL(sum3_linear_ln_kernel, dim3(1, (unsigned)(vrows / TLN96::BM + (vrows % TLN96::BM != 0))), dim3(TLN96::THREADS), smem, static_cast<hipStream_t>(stream), g);
+    return hipGetLastError() == hipSuccess ? 0 : SKGC_E_HIP;
+}
+
 extern "C" {
 
 int skgc_abi_version(void) { return SKGC_ABI_VERSION; }
@@ -347,6 +375,13 @@ int skgc_sum_linear_layer_norm(const skgc_sum_desc* d, void* stream) {
         }
     }
     al.n_src = d->n_src; al.M = (int)d->rows; al.K = d->K; al.act = d->act;
+    if (d->group == 3) {            // every source indexed (the index arrays define the virtual row order), no residual
+        for (int s = 0; s < d->n_src; ++s)
+            if (!d->idx[s]) return SKGC_E_ARG;
+        if (d->res) return SKGC_E_ARG;
+        return sum3_linear_layer_norm(d, al, stream);
+    }
+    if (d->group != 0 && d->group != 1) return SKGC_E_ARG;
     if (ln_tile_rows() == 64) return sum_linear_layer_norm_t<TLN64>(d, al, stream);
     return sum_linear_layer_norm_t<TLN128>(d, al, stream);
 }

@@ -40,7 +40,8 @@ class GatherDesc(ctypes.Structure):
 class SumDesc(ctypes.Structure):
     _fields_ = [("src", ctypes.c_void_p * 3), ("idx", ctypes.c_void_p * 3), ("ld", ctypes.c_longlong * 3), ("n_src", ctypes.c_int), ("K", ctypes.c_int),
                 ("act", ctypes.c_int), ("w", ctypes.c_void_p), ("w_plane", ctypes.c_longlong), ("ldw", ctypes.c_int), ("bias", ctypes.c_void_p),
-                ("gamma", ctypes.c_void_p), ("beta", ctypes.c_void_p), ("res", ctypes.c_void_p), ("out", ctypes.c_void_p), ("rows", ctypes.c_longlong)]
+                ("gamma", ctypes.c_void_p), ("beta", ctypes.c_void_p), ("res", ctypes.c_void_p), ("out", ctypes.c_void_p), ("rows", ctypes.c_longlong),
+                ("group", ctypes.c_int)]
 
 
 _lib = None
@@ -168,13 +169,14 @@ class GraphcastEngine:
         self._gemm(self.b_h, m["fc2"], self.b_t, rows, a_sm=L, a_sk=1, o_sm=L, o_sn=1, bias=m["b2"], label=label or name.split(".")[0])
         self._ln(self.b_t, m["g"], m["b"], res, out, rows)
 
-    def _sum_ln(self, name, sources, rows, out, res=None, label=None):
-        """out = (res +) LayerNorm(fc2(swish(sum of the gathered source rows))) -- sources: [(flat tensor, element offset, ld, index or None)]."""
+    def _sum_ln(self, name, sources, rows, out, res=None, label=None, group=0):
+        """out = (res +) LayerNorm(fc2(swish(sum of the gathered source rows))) -- sources: [(flat tensor, element offset, ld, index or None)].
+        group = 3: rows counts groups of three (virtual row order, see load_params) and out[g] is the sum over the group."""
         m, L = self.m[name], self.cfg.latent
         buf, plane, ldw = m["fc2p"]
-        self._mark(label or name.split(".")[0], 2.0 * rows * L * L)
+        self._mark(label or name.split(".")[0], 2.0 * rows * (group or 1) * L * L)
         ops.hip.gc_sum_linear_layer_norm([t for t, _, _, _ in sources], [o for _, o, _, _ in sources], [d for _, _, d, _ in sources], [i for _, _, _, i in sources],
-                                         L, 2, buf, plane, ldw, m["b2"], m["g"], m["b"], res, out, rows)
+                                         L, 2, buf, plane, ldw, m["b2"], m["g"], m["b"], res, out, rows, group)
 
     def _edge_mlp(self, name, edge_term, vs, idx_s, vr, idx_r, rows, out, res=None, label=None):
         """Edge update by distributivity.  edge_term: a precomputed [rows][L] tensor (e W_e^T + b1, input-independent edge latents) or the
@@ -264,6 +266,16 @@ class GraphcastEngine:
                 self.xbuf = torch.zeros(self.world, self.mn_per, L, dtype=torch.float32, device=dev)
                 self.xmine = torch.zeros(self.mn_per, L, dtype=torch.float32, device=dev)
             self.P, self.E1, self.EM, self.E2 = P, E1, EM, E2
+            # mesh -> grid: every grid node receives exactly three edges (the corners of its triangle), stored receiver by receiver.
+            # The edge MLP then runs in "virtual row" order -- row 48 t + 16 a + l = edge a of grid node 16 t + l -- so that its epilogue
+            # sums the three LayerNorm outputs of a node in registers: the updated edge latents and the receiver sum never reach HBM
+            self.m2g_group = None
+            r2 = g.m2g_edges[:, 1]
+            if self.split_edges and os.environ.get("SKGC_M2G_SEGSUM", "0") != "1" and E2 == 3 * P and np.array_equal(r2, np.repeat(np.arange(P), 3)):
+                v = np.arange((P + 15) // 16 * 48)
+                node = 16 * (v // 48) + v % 16
+                edge = np.where(node < P, 3 * np.minimum(node, P - 1) + (v % 48) // 16, 0)
+                self.m2g_group = (i32(edge), i32(g.m2g_edges[edge, 0]), i32(r2[edge]))
             buf = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)  # noqa: E731
             rows_max = max(P, E1, E2, EM, g.n_mesh)
             self.b_h, self.b_t = buf(rows_max, L), buf(rows_max, L)
@@ -364,11 +376,19 @@ class GraphcastEngine:
                         if r != self.rank and n1 > n0:
                             self.vm[n0:n1].copy_(self.xbuf[r, :n1 - n0])
             # decoder: mesh -> grid
-            if self.split_edges:
-                self._edge_mlp("m2g.edge", self.e2_0, self.vm, self.m2g_s, self.vg, self.m2g_r, self.E2, self.e2, label="decoder")
+            if self.m2g_group is not None:
+                # edge update + receiver sum in one kernel: node terms once per node, then sum over a node's three edges of
+                # LayerNorm(fc2(swish(e W_e + b + (v_m W_s)[sender] + (v_g W_r)[node])))
+                me, ie = self.m["m2g.edge"], self.m2g_group
+                self._gemm(self.vm, me["w_s"], self.b_ps, self.graph.n_mesh, a_sm=L, a_sk=1, o_sm=L, o_sn=1, label="decoder")
+                self._gemm(self.vg, me["w_r"], self.b_pr, P, a_sm=L, a_sk=1, o_sm=L, o_sn=1, label="decoder")
+                self._sum_ln("m2g.edge", [(self.e2_0, 0, L, ie[0]), (self.b_ps, 0, L, ie[1]), (self.b_pr, 0, L, ie[2])], P, self.agg_g, label="decoder", group=3)
             else:
-                self._mlp("m2g.edge", [(self.e2_0, None, L), (self.vm, self.m2g_s, L), (self.vg, self.m2g_r, L)], self.E2, self.e2, label="decoder")
-            self._segsum(self.e2, self.m2g_off, self.agg_g, P)
+                if self.split_edges:
+                    self._edge_mlp("m2g.edge", self.e2_0, self.vm, self.m2g_s, self.vg, self.m2g_r, self.E2, self.e2, label="decoder")
+                else:
+                    self._mlp("m2g.edge", [(self.e2_0, None, L), (self.vm, self.m2g_s, L), (self.vg, self.m2g_r, L)], self.E2, self.e2, label="decoder")
+                self._segsum(self.e2, self.m2g_off, self.agg_g, P)
             self._mlp("m2g.grid_node", [(self.vg, None, L), (self.agg_g, None, L)], P, self.vg, res=self.vg, label="decoder")
             # output layer: x(t+6h) = x(t) + diff_std * MLP(vg), written channel-major
             mo = self.m["out"]

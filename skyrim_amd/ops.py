@@ -181,7 +181,7 @@ def _gc_linear_layer_norm(a, lda: int, K: int, w, w_plane: int, ldw: int, bias, 
                                        _f32(beta, "beta", dev), _opt(res), _f32(out, "out"), rows, _stream(out)), "skgc_linear_layer_norm")
 
 
-def _gc_sum_linear_layer_norm(src, src_off, ld, idx, K: int, act: int, w, w_plane: int, ldw: int, bias, gamma, beta, res, out, rows: int) -> None:
+def _gc_sum_linear_layer_norm(src, src_off, ld, idx, K: int, act: int, w, w_plane: int, ldw: int, bias, gamma, beta, res, out, rows: int, group: int = 0) -> None:
     from .graphcast import engine
     lib = engine.load_library()
     dev = out.device
@@ -198,7 +198,7 @@ def _gc_sum_linear_layer_norm(src, src_off, ld, idx, K: int, act: int, w, w_plan
     d.bias = bias.data_ptr() if bias is not None else None
     d.gamma, d.beta = _f32(gamma, "gamma", dev).value, _f32(beta, "beta", dev).value
     d.res = res.data_ptr() if res is not None else None
-    d.out, d.rows = _f32(out, "out").value, rows
+    d.out, d.rows, d.group = _f32(out, "out").value, rows, group
     with torch.cuda.device(dev):
         _ok(lib.skgc_sum_linear_layer_norm(ctypes.byref(d), _stream(out)), "skgc_sum_linear_layer_norm")
 
@@ -239,7 +239,7 @@ _SCHEMAS = [
     ("gc_linear_layer_norm(Tensor a, int lda, int K, Tensor w, int w_plane, int ldw, Tensor bias, Tensor gamma, Tensor beta, Tensor? res, Tensor(a!) out, int rows) -> ()",
      _gc_linear_layer_norm),
     ("gc_sum_linear_layer_norm(Tensor[] src, int[] src_off, int[] ld, Tensor?[] idx, int K, int act, Tensor w, int w_plane, int ldw, Tensor? bias, Tensor gamma, "
-     "Tensor beta, Tensor? res, Tensor(a!) out, int rows) -> ()", _gc_sum_linear_layer_norm),
+     "Tensor beta, Tensor? res, Tensor(a!) out, int rows, int group=0) -> ()", _gc_sum_linear_layer_norm),
     ("gc_layer_norm(Tensor x, Tensor gamma, Tensor beta, Tensor? res, Tensor(a!) out, int rows, int N) -> ()", _gc_layer_norm),
     ("gc_segment_sum(Tensor e, Tensor offsets, Tensor(a!) out, Tensor(b!)? acc, int n_nodes, int N) -> ()", _gc_segment_sum),
 ]

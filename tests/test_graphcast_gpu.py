@@ -82,6 +82,48 @@ def test_latent_512_uses_the_fused_linear_layer_norm_kernel():
     assert O.per_channel_rel_err(y.cpu(), ref).max().item() < 1e-5 and O.increment_rel_err(y.cpu(), ref, x1).max().item() < 1e-3
 
 
+def test_mesh_to_grid_edge_update_and_receiver_sum_in_one_kernel(monkeypatch):
+    """Latent 512: the decoder's edge MLP runs in virtual-row order and sums a grid node's three edges in its epilogue
+    (skgc_sum_desc::group = 3) -- same step as the edge MLP + segment sum it replaces, and the op alone against float64."""
+    from skyrim_amd.graphcast.engine import GraphcastEngine
+    cfg = GraphcastConfig(n_lat=35, n_lon=72, splits=2, latent=512, steps=1, n_vars=7)
+    p = init_synthetic(cfg, 0)
+    x0, x1 = synthetic_states(cfg, 0)
+    f = forcings(cfg, 1000.0)
+    eng = GraphcastEngine(cfg, "cuda:0")
+    eng.load_params(p)
+    assert eng.m2g_group is not None and eng.P % 16 != 0          # 35 x 72 = 2520 nodes: a ragged last group of 16
+    monkeypatch.setenv("SKGC_M2G_SEGSUM", "1")
+    plain = GraphcastEngine(cfg, "cuda:0")
+    plain.load_params(p)
+    assert plain.m2g_group is None
+    a, b = eng.step(x0.cuda(), x1.cuda(), f.cuda()).cpu(), plain.step(x0.cuda(), x1.cuda(), f.cuda()).cpu()
+    assert O.increment_rel_err(a, b, x1).max().item() < 1e-4
+    # the op alone
+    gen = torch.Generator().manual_seed(4)
+    G, L, NS = 37, 512, 50                                           # 37 groups: 3 tiles of 16, the last one ragged
+    e, vs, vr = torch.randn(3 * G, L, generator=gen), torch.randn(NS, L, generator=gen), torch.randn(G, L, generator=gen)
+    send = torch.randint(0, NS, (3 * G,), generator=gen)
+    w, b2, gam, bet = torch.randn(L, L, generator=gen) / L ** 0.5, torch.randn(L, generator=gen) * 0.1, 1 + 0.1 * torch.randn(L, generator=gen), 0.1 * torch.randn(L, generator=gen)
+    h = torch.nn.functional.silu(e.double() + vs.double()[send] + vr.double().repeat_interleave(3, 0))
+    z = torch.nn.functional.layer_norm(h @ w.double().T + b2.double(), (L,), gam.double(), bet.double(), 1e-5)
+    ref = z.view(G, 3, L).sum(1)
+    v = torch.arange((G + 15) // 16 * 48)
+    node = 16 * (v // 48) + v % 16
+    edge = torch.where(node < G, 3 * node.clamp(max=G - 1) + (v % 48) // 16, torch.zeros_like(v))
+    i32 = lambda t: t.to(torch.int32).cuda()  # noqa: E731
+    planes = torch.empty(2 * L * L, dtype=torch.float16, device="cuda")      # perm8 row order: what the fused Linear + LayerNorm kernels read
+    from skyrim_amd.graphcast.engine import _check
+    wd = w.cuda().contiguous()
+    _check(eng.lib.skgc_prepare_weight_perm8(wd.data_ptr(), L, L, planes.data_ptr(), L * L, L, eng._stream()), "skgc_prepare_weight_perm8")
+    torch.cuda.synchronize()
+    out = torch.full((G, L), float("nan"), device="cuda")
+    torch.ops.skyrim_hip.gc_sum_linear_layer_norm([e.cuda(), vs.cuda(), vr.cuda()], [0, 0, 0], [L, L, L], [i32(edge), i32(send[edge]), i32(edge // 3)], L, 2,
+                                                  planes, L * L, L, b2.cuda(), gam.cuda(), bet.cuda(), None, out, G, 3)
+    assert ((out.cpu().double() - ref).abs().max() / ref.abs().max()).item() < 3e-6
+    with pytest.raises(RuntimeError):                                 # every source needs its index array in virtual-row order
+        torch.ops.skyrim_hip.gc_sum_linear_layer_norm([e.cuda()], [0], [L], [None], L, 2, planes, L * L, L, b2.cuda(), gam.cuda(), bet.cuda(), None, out, G, 3)
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_grid_sharded_step_equals_the_single_gpu_step(world):
     """BASELINE configs[3]: the grid split over `world` ranks (here: `world` engines on one GPU, one thread each, the exchange a
