@@ -334,8 +334,13 @@ class GraphcastEngine:
             # grid-node embedder: rows = grid nodes (contiguous), k = feature (stride n_grid), normalisation in the loader
             self._gemm(self.feat, m["fc1"], self.b_h, P, a_sm=1, a_sk=P, o_sm=L, o_sn=1, bias=m["b1"], act=2,
                        kscale=self.in_scale, kshift=self.in_shift, label="embed")
-            self._gemm(self.b_h, m["fc2"], self.b_t, P, a_sm=L, a_sk=1, o_sm=L, o_sn=1, bias=m["b2"], label="embed")
-            self._ln(self.b_t, m["g"], m["b"], None, self.vg, P)
+            if m.get("fc2p") is not None:            # latent 512: second Linear + LayerNorm in one kernel, the pre-norm rows stay on chip
+                buf, plane, ldw = m["fc2p"]
+                self._mark("embed", 2.0 * P * L * L)
+                ops.hip.gc_linear_layer_norm(self.b_h, L, L, buf, plane, ldw, m["b2"], m["g"], m["b"], None, self.vg, P)
+            else:
+                self._gemm(self.b_h, m["fc2"], self.b_t, P, a_sm=L, a_sk=1, o_sm=L, o_sn=1, bias=m["b2"], label="embed")
+                self._ln(self.b_t, m["g"], m["b"], None, self.vg, P)
             # encoder: grid -> mesh
             if self.split_edges:
                 self._edge_mlp("g2m.edge", self.e1_0, self.vg, self.g2m_s, None, None, self.E1, self.e1, label="encoder")
