@@ -124,14 +124,15 @@ def test_mesh_to_grid_edge_update_and_receiver_sum_in_one_kernel(monkeypatch):
     with pytest.raises(RuntimeError):                                 # every source needs its index array in virtual-row order
         torch.ops.skyrim_hip.gc_sum_linear_layer_norm([e.cuda()], [0], [L], [None], L, 2, planes, L * L, L, b2.cuda(), gam.cuda(), bet.cuda(), None, out, G, 3)
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_grid_sharded_step_equals_the_single_gpu_step(world):
+@pytest.mark.parametrize("world,latent", [(2, None), (3, None), (2, 512)])
+def test_grid_sharded_step_equals_the_single_gpu_step(world, latent):
     """BASELINE configs[3]: the grid split over `world` ranks (here: `world` engines on one GPU, one thread each, the exchange a
     barrier + sum standing in for the RCCL all-reduce) reproduces the unsharded step; the only data exchanged is the mesh aggregate."""
     import threading
     from skyrim_amd.graphcast.engine import GraphcastEngine
     from skyrim_amd.graphcast.mesh import build_graph
-    cfg = CONFIGS["tiny"]
+    # latent 512: the production kernels (edge MLPs by distributivity, mesh->grid receiver sum in the edge kernel) on every shard
+    cfg = CONFIGS["tiny"] if latent is None else GraphcastConfig(n_lat=33, n_lon=64, splits=2, latent=latent, steps=2, n_vars=7)
     full = build_graph(cfg.n_lat, cfg.n_lon, cfg.splits)
     p = init_synthetic(cfg, 0)
     x0, x1 = synthetic_states(cfg, 0)
@@ -172,6 +173,7 @@ def test_grid_sharded_step_equals_the_single_gpu_step(world):
             e = GraphcastEngine(cfg, "cuda:0", graph=full, shard=(r, world), reduce_fn=reduce_fn, gather_fn=gather_fn)
             assert e.shard_mesh
             e.load_params(p)
+            assert (e.m2g_group is not None) == (latent == 512)
             sl = slice(e.lat0, e.lat1)
             outs[r] = e.step(x0[:, sl].contiguous().cuda(), x1[:, sl].contiguous().cuda(), f[:, sl].contiguous().cuda()).cpu()
         except Exception as ex:                      # surface thread failures in the main thread
