@@ -115,6 +115,7 @@ def pmc_kernels(model: str, *needles: str):
 
 # bench stage -> what identifies its kernel in the counter summary
 PANGU_STAGE_KERNEL = {"mlp_r0": ("fused_mlp_kernel", "MlpShape<192"), "mlp_r1": ("fused_mlp_kernel", "MlpShape<384"),
+                      "proj_mlp_r0": ("proj_mlp_kernel", "BlockShape<192"), "proj_mlp_r1": ("proj_mlp_kernel", "BlockShape<384"),
                       "qkv_r0": ("rt_qkv_kernel", "QkvShape<192"), "qkv_r1": ("rt_qkv_kernel", "QkvShape<384"),
                       "attn_r0": ("earth_attention_kernel",), "attn_r1": ("earth_attention_kernel",),
                       "proj_r0": ("gemm_dma_kernel", "256x192", "EpLayerNorm", "RowMapIndexed"), "proj_r1": ("gemm_dma_kernel", "128x384", "EpLayerNorm")}

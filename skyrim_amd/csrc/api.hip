@@ -126,6 +126,7 @@ struct Engine : IEngine {
     int hid16 = 0;            // fp16-hidden mode (bf16x3 engines only)
     bool fused_mlp = false;   // one-kernel MLP (fused_mlp.hip): 3-term modes with the hidden as hi/lo pair
     bool rt_proj = false, rt_qkv = false;   // row-tile proj / QKV kernels (rowtile.hip)
+    bool fused_block = false;               // proj + LayerNorm + residual + MLP as one kernel (fused_block.hip)
     T* zrow = nullptr;
 
     // ---- per-stage timing with HIP events on the launch stream (bench.py roofline leg) ---- //
@@ -153,7 +154,9 @@ struct Engine : IEngine {
                                                    "proj_r1", "fc1_r1", "fc2_r1", "downsample", "upsample", "recover"};
         static const char* names_fused[C_COUNT] = {"embed", "qkv_r0", "attn_r0", "proj_r0", "mlp_r0", "fc2_r0", "qkv_r1", "attn_r1",
                                                    "proj_r1", "mlp_r1", "fc2_r1", "downsample", "upsample", "recover"};
-        const char* const* names = fused_mlp ? names_fused : names_split;
+        static const char* names_block[C_COUNT] = {"embed", "qkv_r0", "attn_r0", "proj_r0", "proj_mlp_r0", "fc2_r0", "qkv_r1", "attn_r1",
+                                                   "proj_r1", "proj_mlp_r1", "fc2_r1", "downsample", "upsample", "recover"};
+        const char* const* names = fused_block ? names_block : (fused_mlp ? names_fused : names_split);
         double ms[C_COUNT] = {0}; int cnt[C_COUNT] = {0};
         if (prof_used > 0) {
             hipError_t e = hipEventSynchronize(prof_ev[prof_used - 1]);
@@ -179,6 +182,9 @@ struct Engine : IEngine {
             fl[C_FC2_0 + o] = 2 * nt * C * 4 * C;      by[C_FC2_0 + o] = nt * 4 * C * sa + 2 * nt * C * 4 + 4 * C * C * wb;
             if (fused_mlp) {   // one kernel: both GEMMs, stream read once + written once, both weight matrices
                 fl[C_FC1_0 + o] = 4 * nt * C * 4 * C;  by[C_FC1_0 + o] = 2 * nt * C * 4 + 8 * C * C * wb;
+            }
+            if (fused_block) { // ... and the projection in front of them: + its FLOPs, + the attention rows read, + its weights
+                fl[C_FC1_0 + o] += 2 * mw * C * C;     by[C_FC1_0 + o] += nt * C * sa + C * C * wb;
             }
         }
         fl[C_EMBED] = 2 * hw * 112 * 192 + 2 * 7 * hw * 160 * 192; by[C_EMBED] = (69.0 + 3) * g.n_lat * g.n_lon * 4 + g.ntok[0] * 192.0 * 4;
@@ -222,7 +228,7 @@ struct Engine : IEngine {
                 if (hid16 && !std::is_same<T, f16>::value) { bw.fc2h.plane = (long long)c * 4 * c; bw.fc2h.w = a.take<f16>((size_t)bw.fc2h.plane * 2); }
                 bw.w1f = fused_mlp ? a.take<T>((size_t)8 * c * c) : nullptr;      // 4c x c elements, hi + lo
                 bw.w2f = fused_mlp ? a.take<T>((size_t)8 * c * c) : nullptr;
-                bw.projf = rt_proj ? a.take<T>((size_t)2 * c * c) : nullptr;
+                bw.projf = (rt_proj || fused_block) ? a.take<T>((size_t)2 * c * c) : nullptr;
                 bw.qkvf = rt_qkv ? a.take<T>((size_t)6 * c * c) : nullptr;
                 bw.qkv_b = a.take<float>(3 * c); bw.proj_b = a.take<float>(c);
                 bw.fc1_b = a.take<float>(4 * c); bw.fc2_b = a.take<float>(c);
@@ -239,7 +245,7 @@ struct Engine : IEngine {
         w.rec_u = take_lin(a, 160, 384); w.rec_s = take_lin(a, 64, 384);
         w.rec_u_b = a.take<float>(5); w.rec_s_b = a.take<float>(4);
         for (int r = 0; r < 2; ++r)
-            for (int roll = 0; roll < 2; ++roll) w.widx[r][roll] = a.take<int>(g.mwin[r]);
+            for (int roll = 0; roll < 2; ++roll) { w.widx[r][roll] = a.take<int>(g.mwin[r]); w.winv[r][roll] = a.take<int>(g.ntok[r]); }
         zrow = a.take<T>(4096);
         prep_bytes = (a.off + 255) / 256 * 256;
     }
@@ -271,6 +277,7 @@ struct Engine : IEngine {
         // proj in row-tile form measures the same as the tiled GEMM (0.199 vs 0.197 ms at C = 384, 0.264 vs 0.264 at C = 192: with 16 rows
         // per wave its LDS reads run at 2/3 of the LDS rate): kept behind SKP_RT_PROJ=1, the tiled LayerNorm GEMM stays the default
         rt_proj = (P::NA == 2 && P::NW == 2 && mlp_mode == 0 && getenv("SKP_RT_PROJ") != nullptr);
+        fused_block = fused_mlp && getenv("SKP_SPLIT_BLOCK") == nullptr;
         rt_qkv = (std::is_same<P, PrecF16x3>::value && qkv_a1 && mlp_mode == 0);
         wk.hid16 = hid16_;
         wk.qkv_a1 = qkv_a1;
@@ -321,7 +328,7 @@ struct Engine : IEngine {
                 CK(lin(bw.fc2, P_(m, p + "mlp.fc2.weight"), c, 4 * c, 4 * c, 1, s));
                 if (hid16 && !std::is_same<T, f16>::value) CK((prep_weight<f16, 2>(P_(m, p + "mlp.fc2.weight"), const_cast<f16*>(bw.fc2h.w), bw.fc2h.plane, c, 4 * c, 4 * c, 4 * c, 1, 1, 1, s)));
                 if constexpr (P::NA == 2 && P::NW == 2) {
-                    if (rt_proj) CK(prep_rowtile_weights<T>(P_(m, p + "attn.proj.weight"), const_cast<T*>(bw.projf), c, c, s));
+                    if (rt_proj || fused_block) CK(prep_rowtile_weights<T>(P_(m, p + "attn.proj.weight"), const_cast<T*>(bw.projf), c, c, s));
                     if (rt_qkv) CK(prep_rowtile_weights<T>(P_(m, p + "attn.qkv.weight"), const_cast<T*>(bw.qkvf), 3 * c, c, s));
                     if (fused_mlp) CK(prep_mlp_weights<T>(P_(m, p + "mlp.fc1.weight"), P_(m, p + "mlp.fc2.weight"), const_cast<T*>(bw.w1f), const_cast<T*>(bw.w2f), c, s));
                 }
@@ -351,7 +358,10 @@ struct Engine : IEngine {
         const int H[2] = {g.H1, g.H2}, W[2] = {g.W1, g.W2};
         for (int r = 0; r < 2; ++r)
             for (int roll = 0; roll < 2; ++roll)
+            {
                 CK(prep_window_index(const_cast<int*>(w.widx[r][roll]), g.Z, H[r], W[r], g.Hp[r], g.top[r], roll ? g.roll_sign : 0, s));
+                CK(prep_window_inverse(w.widx[r][roll], g.mwin[r], const_cast<int*>(w.winv[r][roll]), s));
+            }
         return hipSuccess;
     }
 
@@ -377,6 +387,14 @@ struct Engine : IEngine {
         mark(C_ATTN0 + o, s);
         AttnArgs<P> a{wk.q, wk.k, wk.vt, wk.qkv_plane, bw.bias_exp, wk.ao, wk.ao_plane, C, g.nwin[res], g.nW[res], heads};
         CK(launch_attention<P>(a, s));
+        if constexpr (P::NA == 2 && P::NW == 2) {
+            if (fused_block) {                    // everything after the attention in one kernel; timed under "mlp"
+                mark(C_FC1_0 + o, s);
+                CK((op_proj_mlp_fused<P>(g, bw, w.winv[res][i & 1], res, xs, wk, s)));
+                mark(-1, s);
+                return hipSuccess;
+            }
+        }
         mark(C_PROJ0 + o, s);
         if constexpr (P::NA == 2 && P::NW == 2) {
             if (rt_proj) CK((op_proj_rowtile<P>(g, bw, widx, res, xs, wk, s)));

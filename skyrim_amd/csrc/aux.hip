@@ -99,6 +99,16 @@ hipError_t prep_window_index(int* idx, int Z, int H, int W, int Hp, int top, int
     return hipGetLastError();
 }
 
+// inverse of the window table: every stream token sits in exactly one (non-padding) window row
+__global__ void prep_window_inverse_kernel(const int* __restrict__ idx, int n, int* __restrict__ inv) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m < n && idx[m] >= 0) inv[idx[m]] = m;
+}
+hipError_t prep_window_inverse(const int* idx, int n, int* inv, hipStream_t s) {
+    hipLaunchKernelGGL(prep_window_inverse_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, idx, n, inv);
+    return hipGetLastError();
+}
+
 __global__ void prep_reciprocal_kernel(const float* __restrict__ src, float* __restrict__ dst, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dst[i] = 1.0f / src[i];

@@ -42,6 +42,7 @@ struct ModelW {
     LinW<T> rec_u, rec_s;
     const float *rec_u_b, *rec_s_b;
     const int* widx[2][2];   // [resolution][roll] window gather table: mwin entries, -1 = padding
+    const int* winv[2][2];   // its inverse: stream token -> window row (ntok entries)
 };
 
 template <class P>
@@ -93,6 +94,8 @@ template <class T> hipError_t prep_mlp_weights(const float* w1, const float* w2,
 template <class P> hipError_t op_proj_rowtile(const Geom&, const BlockW<typename P::T>&, const int* widx, int res, typename P::T* Xs, const Work<P>&, hipStream_t);
 hipError_t op_qkv_rowtile(const Geom&, const BlockW<f16>&, const int* widx, int res, const f16* Xs, const Work<PrecF16x3>&, hipStream_t);
 template <class T> hipError_t prep_rowtile_weights(const float* w, T* wf, int N, int K, hipStream_t);
+// proj + LayerNorm + residual + MLP + LayerNorm + residual in one kernel (fused_block.hip): weights from prep_rowtile_weights / prep_mlp_weights
+template <class P> hipError_t op_proj_mlp_fused(const Geom&, const BlockW<typename P::T>&, const int* winv, int res, typename P::T* Xs, const Work<P>&, hipStream_t);
 template <class T, int NPL> hipError_t split_planes(const float* x, T* planes, long long plane, long long n, int C, hipStream_t);
 template <class T> hipError_t merge_planes(const T* planes, long long plane, float* x, long long n, int C, hipStream_t);
 
@@ -101,6 +104,7 @@ template <class T, int NW>
 hipError_t prep_weight(const float* src, T* dst, long long plane, int N, int K, int ldd, long long sn, long long sk, int blocked, int perm, hipStream_t);
 hipError_t prep_bias_expand(const float* table, f16* out, int types, int heads, int nH, int roll, float mask_value, hipStream_t);   // roll: 0 | -1 | +1
 hipError_t prep_window_index(int* idx, int Z, int H, int W, int Hp, int top, int roll, hipStream_t);
+hipError_t prep_window_inverse(const int* idx, int n, int* inv, hipStream_t);
 hipError_t prep_reciprocal(const float* src, float* dst, int n, hipStream_t);
 template <class T> hipError_t merge_stats(const T* x, long long plane, float2* stats, int Z, int H1, int W1, int H2, int W2, int C, float eps, hipStream_t);
 

@@ -157,9 +157,10 @@ def test_profile_hooks_cover_the_step(eng, toy):
     stats = eng.profile_read()
     eng.profile(False)
     by = {s["name"]: s for s in stats}
-    mlp = "mlp_r1" if eng.precision in ("f16x3q", "f16x3", "bf16x3") else "fc1_r1"      # 3-term modes: the fused MLP kernel, one launch per block
+    # 3-term modes: projection + MLP as one kernel per block (fused_block.hip); the others: proj, fc1, fc2 as separate launches
+    mlp = "proj_mlp_r1" if eng.precision in ("f16x3q", "f16x3", "bf16x3") else "fc1_r1"
     assert by[mlp]["launches"] == 12 and by["qkv_r0"]["launches"] == 4 and by["embed"]["launches"] == 1
-    assert by["fc2_r1"]["launches"] == (0 if mlp == "mlp_r1" else 12)
+    assert by["fc2_r1"]["launches"] == by["proj_r1"]["launches"] == (0 if mlp == "proj_mlp_r1" else 12)
     assert all(s["total_ms"] > 0 for s in stats if s["launches"])
 
 
