@@ -161,6 +161,8 @@ class SfnoEngine:
         self.fused = (os.environ.get("SKYRIM_SFNO_UNFUSED", "0") != "1") if fused is None else bool(fused)
         self.chain = None                 # shape class of the fused chains, set by load_params
         # layout of the longitude spectrum between the DFT and Legendre GEMMs: "order" = [order, re/im][C][lat], "channel" = [C][order, re/im][lat]
+        # grid-changing blocks: the inner skip as a channel mix of the SH coefficients instead of a 1x1 convolution on the output grid
+        self.skip_in_spectrum = os.environ.get("SKYRIM_SFNO_GRID_SKIP", "0") != "1"
         self.f_ana = os.environ.get("SKSFNO_F_ANA", "order")
         self.f_syn = os.environ.get("SKSFNO_F_SYN", "order")
         if not torch.cuda.is_available():
@@ -212,8 +214,11 @@ class SfnoEngine:
                     n0_g=f32(g("norm0.weight")), n0_b=f32(g("norm0.bias")), n1_g=f32(g("norm1.weight")), n1_b=f32(g("norm1.bias")),
                     mix=_Weight(self, mix), skip=_Weight(self, g("inner_skip.weight")), skip_b=f32(g("inner_skip.bias")),
                     fc1=_Weight(self, g("mlp.fc1.weight")), fc1_b=f32(g("mlp.fc1.bias")),
-                    fc2=_Weight(self, g("mlp.fc2.weight")), fc2_b=f32(g("mlp.fc2.bias"))))
+                    fc2=_Weight(self, g("mlp.fc2.weight")), fc2_b=f32(g("mlp.fc2.bias")),
+                    skip_b00=f32(g("inner_skip.bias") * (4.0 * np.pi) ** 0.5)))        # the bias as the (0, 0) coefficient of a constant field
                 del mix
+            self.zero_a = torch.zeros(8, dtype=torch.float32, device=dev)
+            self.zero_w = _Weight(self, torch.zeros(e, 8))
             # decoder.fc1 acts on concat(features, normalised input): one GEMM with two A sources along K (k < e: features,
             # k >= e: the raw state, normalised by the loader's per-k affine) when e is a multiple of 8, else two GEMMs
             wd = p["decoder.fc1.weight"]
@@ -412,10 +417,21 @@ class SfnoEngine:
                 self._label = "dhconv"
                 self._gemm(self.b_coef, blk["mix"], self.b_mixed, c.mmax, 2 * e, 2 * e, batch=c.lmax, a_sb=c.mmax * 2 * e, a_sm=2 * e, a_sk=1,
                            o_sb=c.mmax * 2 * e, o_sm=2 * e, o_sn=1, m_cap0=1, m_cap_step=1)      # degree l has orders m <= l only
-                self._synthesis(self.b_mixed, tout, self.b_sp, e)
-                # GELU(filter output + inner skip(residual))
                 outer = "_outer" if tout is self.tr["outer"] else ""
-                self._pointwise(res, blk["skip"], self.b_y, hw_out, e, e, label="inner_skip" + outer, bias=blk["skip_b"], res_pre=self.b_sp, act=1)
+                if tin is not tout and self.skip_in_spectrum:
+                    # the residual of a grid-changing block is iSHT(coef): band-limited, so the 1x1 inner skip commutes with the synthesis --
+                    # skip(iSHT(coef)) = iSHT(W_skip coef).  Mix the channels of the COEFFICIENTS (lmax * mmax * 2 rows instead of one row
+                    # per output pixel: 9x fewer for the last block) on top of the dhconv output, put the bias on the (l, m) = (0, 0)
+                    # coefficient (a constant field b is b * sqrt(4 pi) there) and let the inverse DFT's epilogue apply the GELU
+                    rows = c.lmax * c.mmax * 2
+                    self._label = "inner_skip" + outer
+                    self._gemm(self.b_coef, blk["skip"], self.b_mixed, rows, e, e, a_sm=e, a_sk=1, o_sm=e, o_sn=1, res_post=self.b_mixed)
+                    self._gemm(self.zero_a, self.zero_w, self.b_mixed, 1, 8, e, a_sm=8, a_sk=1, o_sm=e, o_sn=1, bias=blk["skip_b00"], res_post=self.b_mixed)
+                    self._synthesis(self.b_mixed, tout, self.b_y, e, act=1)
+                else:
+                    self._synthesis(self.b_mixed, tout, self.b_sp, e)
+                    # GELU(filter output + inner skip(residual))
+                    self._pointwise(res, blk["skip"], self.b_y, hw_out, e, e, label="inner_skip" + outer, bias=blk["skip_b"], res_pre=self.b_sp, act=1)
                 if self.chain is not None and hw_out % 16 == 0:
                     # norm1 as the chain's input affine; the last block's chain runs on into the decoder and writes the next state
                     self._stats(self.b_y, blk["n1_g"], blk["n1_b"], blk["ch_tab"], e, hw_out)
@@ -455,7 +471,8 @@ class SfnoEngine:
         n = 1 if fo else 2                                    # encoder
         for i in range(c.num_layers):
             last = i == c.num_layers - 1
-            n += 1 + 2 + 1 + 2 + 1 + (2 if i in (0, c.num_layers - 1) else 0)       # norm0, analysis, dhconv, synthesis, skip (+ residual synthesis)
+            change = i in (0, c.num_layers - 1)                   # grid-changing blocks: + residual synthesis (2), skip in the spectrum (+ its bias row)
+            n += 1 + 2 + 1 + 2 + 1 + ((2 + (1 if self.skip_in_spectrum else 0)) if change else 0)       # norm0, analysis, dhconv, synthesis, skip
             n += 2 if (fo if last else fi) else 3             # statistics + chain  |  norm1 + fc1 + fc2
         if not fo:
             n += 2 if self.cfg.embed_dim % 8 == 0 else 3      # decoder (part of the last chain otherwise)
