@@ -22,7 +22,7 @@ import torch
 
 from .. import ops
 from ..sfno import engine as _sf
-from .mesh import GraphStructure, build_graph, latitude_band, shard_graph
+from .mesh import GraphStructure, build_graph, grouped_rows_by3, latitude_band, shard_graph
 from .spec import N_FORCING, N_STATIC, GraphcastConfig, mlp_names, param_spec
 
 _LIB_PATH = Path(__file__).resolve().parent.parent / "lib" / "libskyrim_graphcast.so"
@@ -272,9 +272,7 @@ class GraphcastEngine:
             self.m2g_group = None
             r2 = g.m2g_edges[:, 1]
             if self.split_edges and os.environ.get("SKGC_M2G_SEGSUM", "0") != "1" and E2 == 3 * P and np.array_equal(r2, np.repeat(np.arange(P), 3)):
-                v = np.arange((P + 15) // 16 * 48)
-                node = 16 * (v // 48) + v % 16
-                edge = np.where(node < P, 3 * np.minimum(node, P - 1) + (v % 48) // 16, 0)
+                edge = grouped_rows_by3(P)
                 self.m2g_group = (i32(edge), i32(g.m2g_edges[edge, 0]), i32(r2[edge]))
             buf = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)  # noqa: E731
             rows_max = max(P, E1, E2, EM, g.n_mesh)

@@ -212,3 +212,13 @@ def shard_graph(g: GraphStructure, n_lat: int, n_lon: int, rank: int, world: int
         n_grid=p1 - p0, n_mesh=g.n_mesh, mesh_pos=g.mesh_pos, grid_pos=g.grid_pos[p0:p1], mesh_edges=g.mesh_edges, g2m_edges=g2m, m2g_edges=m2g,
         mesh_edge_feat=g.mesh_edge_feat, g2m_edge_feat=g.g2m_edge_feat[keep], m2g_edge_feat=g.m2g_edge_feat[3 * p0:3 * p1],
         mesh_node_feat=g.mesh_node_feat, grid_node_feat=g.grid_node_feat[p0:p1], faces=g.faces)
+
+
+def grouped_rows_by3(n_groups: int) -> np.ndarray:
+    """Row order of the mesh->grid edge kernel that sums a grid node's three edges in its epilogue (skgc_sum_desc::group = 3,
+    include/skyrim_graphcast.h): virtual row 48 t + 16 a + l is edge a of node 16 t + l, i.e. edge index 3 (16 t + l) + a when the
+    edges are stored node by node; rows of nodes >= n_groups (the ragged last 16) point at edge 0 and are never stored."""
+    v = np.arange((n_groups + 15) // 16 * 48)
+    node = 16 * (v // 48) + v % 16
+    return np.where(node < n_groups, 3 * np.minimum(node, n_groups - 1) + (v % 48) // 16, 0).astype(np.int64)
+

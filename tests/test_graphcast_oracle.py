@@ -197,3 +197,19 @@ def test_graphcast_library_exports_declared_symbols_and_rejects_bad_arguments():
     assert lib.skgc_gather_gemm(ctypes.byref(E.GatherDesc()), None) == -1
     assert lib.skgc_layer_norm(None, None, None, None, None, 4, 32, None) == -1
     assert lib.skgc_segment_sum(None, None, None, None, 4, 32, None) == -1
+
+
+@pytest.mark.parametrize("n", [1, 16, 37, 2520])
+def test_grouped_row_order_of_the_mesh_to_grid_kernel(n):
+    """skgc_sum_desc::group = 3: virtual row 48 t + 16 a + l = edge a of node 16 t + l; every edge of every node exactly once, the
+    three members of a node in the same lane position (row % 16) of three consecutive 16-row fragments."""
+    from skyrim_amd.graphcast.mesh import grouped_rows_by3
+    rows = grouped_rows_by3(n)
+    assert len(rows) == (n + 15) // 16 * 48
+    v = np.arange(len(rows))
+    node = 16 * (v // 48) + v % 16
+    live = node < n
+    assert sorted(rows[live].tolist()) == list(range(3 * n))
+    assert (rows[live] // 3 == node[live]).all() and (rows[live] % 3 == ((v % 48) // 16)[live]).all()
+    assert (rows[~live] == 0).all()
+
