@@ -20,8 +20,14 @@ namespace skp {
 
 
 
-template <class PX, class AL, bool SWAP>
-__global__ void __launch_bounds__(TG::THREADS) gemm_strided_kernel(GemmArgs<PX, AL, EpStrided> g, BatchStrides bs) {
+// Two tiles.  TG (128 x 256, strided_gemm.h): 64 x 64 wave tiles, 162-177 VGPRs, ONE 8-wave workgroup per CU.  TS (128 x 128): 64 x 32 wave
+// tiles fit 128 VGPRs, so TWO 8-wave workgroups (16 waves) share a CU and one's loads / stores run under the other's MFMAs -- measured
+// a little faster for the DFTs (-9 %), the synthesis (-9 %) and dhconv (-5 %), slower for the Legendre analysis (N = 240 fits one 256-wide
+// tile: +15 %), which therefore keeps TG; 17.8 -> 17.6 ms/step in all (SKSFNO_TILE=256 / 128 force one tile).
+typedef TileCfg<128, 128, 32, 2, 4> TS;
+
+template <class PX, class AL, bool SWAP, class TC>
+__device__ __forceinline__ void gemm_strided_body(GemmArgs<PX, AL, EpStrided>& g, const BatchStrides& bs) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const long long z = blockIdx.z;
     g.al.a += z * bs.a;
@@ -40,9 +46,19 @@ __global__ void __launch_bounds__(TG::THREADS) gemm_strided_kernel(GemmArgs<PX, 
     if (bs.m_cap_step > 0) {
         const int cap = bs.m_cap0 + (int)z * bs.m_cap_step;
         if (cap < g.M) { g.M = cap; g.al.M = cap; }
-        if ((int)blockIdx.y * TG::BM >= g.M) return;
+        if ((int)blockIdx.y * TC::BM >= g.M) return;
     }
-    gemm_body<PX, TG, AL, EpStrided, SWAP>(g, smem);
+    gemm_body<PX, TC, AL, EpStrided, SWAP>(g, smem);
+}
+
+template <class PX, class AL, bool SWAP>
+__global__ void __launch_bounds__(TG::THREADS) gemm_strided_kernel(GemmArgs<PX, AL, EpStrided> g, BatchStrides bs) {
+    gemm_strided_body<PX, AL, SWAP, TG>(g, bs);
+}
+
+template <class PX, class AL, bool SWAP>
+__global__ void __launch_bounds__(TS::THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) gemm_strided_kernel_s(GemmArgs<PX, AL, EpStrided> g, BatchStrides bs) {
+    gemm_strided_body<PX, AL, SWAP, TS>(g, bs);
 }
 
 // ---- instance norm over (H, W) per channel: two passes for the statistics, one to apply ---- //
@@ -116,10 +132,14 @@ int sksfno_gemm_run(const sksfno_gemm* d, void* stream) {
     const ALStrided al{d->a, d->M, d->K, d->a_m1, d->a_sm, d->a_sm2, d->a_sk, d->a_kscale, d->a_kshift, d->a2, d->a2_sk, d->a2_k_split};
     const EpStrided ep{d->out, d->bias, d->res_pre, d->res_post, d->o_m1, d->act, d->o_sm, d->o_sm2, d->o_sn};
     const BatchStrides bs{d->a_sb, d->w_sb, d->o_sb, d->k_lo_step, d->m_cap0, d->m_cap_step};
-    const dim3 grid((d->N + TG::BN - 1) / TG::BN, (d->M + TG::BM - 1) / TG::BM, d->batch);
-    if (grid.y > 65535 || grid.z > 65535) return SKSFNO_E_ARG;
     // rows contiguous in the output (NCHW activations): un-swapped order gives 4 consecutive rows per lane
     const bool swap = !(d->o_sm == 1 && d->o_sn != 1);
+    static const int tile_env = [] { const char* v = getenv("SKSFNO_TILE"); return v ? atoi(v) : 0; }();      // 128 / 256: force one tile
+    const bool wide = tile_env == 256 || (tile_env != 128 && !swap && d->N > 128 && d->N <= 256);            // one 256-wide tile covers N
+    const int bn = wide ? TG::BN : TS::BN;
+    const dim3 grid((d->N + bn - 1) / bn, (d->M + TG::BM - 1) / TG::BM, d->batch);
+    static_assert(TG::BM == TS::BM && TG::THREADS == TS::THREADS, "the two tiles share the row split and the block size");
+    if (grid.y > 65535 || grid.z > 65535) return SKSFNO_E_ARG;
     hipStream_t st = static_cast<hipStream_t>(stream);
     auto launch = [&](auto px, auto loader) {
         typedef decltype(px) PX;
@@ -135,8 +155,14 @@ int sksfno_gemm_run(const sksfno_gemm* d, void* stream) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_strided_kernel<PX, AL, true>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_strided_kernel<PX, AL, false>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         }
-        if (swap) hipLaunchKernelGGL((gemm_strided_kernel<PX, AL, true>), grid, dim3(TG::THREADS), smem, st, g, bs);
-        else      hipLaunchKernelGGL((gemm_strided_kernel<PX, AL, false>), grid, dim3(TG::THREADS), smem, st, g, bs);
+        constexpr int smem_s = gemm_smem_bytes<PX, TS>() + kEpiScratch;
+        if (wide) {
+            if (swap) hipLaunchKernelGGL((gemm_strided_kernel<PX, AL, true>), grid, dim3(TG::THREADS), smem, st, g, bs);
+            else      hipLaunchKernelGGL((gemm_strided_kernel<PX, AL, false>), grid, dim3(TG::THREADS), smem, st, g, bs);
+        } else {
+            if (swap) hipLaunchKernelGGL((gemm_strided_kernel_s<PX, AL, true>), grid, dim3(TS::THREADS), smem_s, st, g, bs);
+            else      hipLaunchKernelGGL((gemm_strided_kernel_s<PX, AL, false>), grid, dim3(TS::THREADS), smem_s, st, g, bs);
+        }
     };
     // the loader without per-element predicates wherever the operand allows it (strided_gemm.h: ALFast)
     const long long a_extent = (long long)((d->M - 1) / d->a_m1) * d->a_sm2 + (long long)(d->a_m1 < d->M ? d->a_m1 - 1 : d->M - 1) * d->a_sm + (long long)(d->K - 1) * d->a_sk;
