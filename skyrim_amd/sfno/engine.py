@@ -210,6 +210,12 @@ class SfnoEngine:
                 mix[:, :e, e:] = -wi
                 mix[:, e:, :e] = wi
                 mix[:, e:, e:] = wr
+                if self.skip_in_spectrum and i in (0, c.num_layers - 1):
+                    # grid-changing block: the inner skip is a channel mix of the coefficients (see step()) -- the same matrix for every
+                    # degree and for the real and the imaginary part, i.e. one more term on the diagonal blocks of the dhconv matrices
+                    ws = g("inner_skip.weight").float()
+                    mix[:, :e, :e] += ws
+                    mix[:, e:, e:] += ws
                 self.blocks.append(dict(
                     n0_g=f32(g("norm0.weight")), n0_b=f32(g("norm0.bias")), n1_g=f32(g("norm1.weight")), n1_b=f32(g("norm1.bias")),
                     mix=_Weight(self, mix), skip=_Weight(self, g("inner_skip.weight")), skip_b=f32(g("inner_skip.bias")),
@@ -420,12 +426,10 @@ class SfnoEngine:
                 outer = "_outer" if tout is self.tr["outer"] else ""
                 if tin is not tout and self.skip_in_spectrum:
                     # the residual of a grid-changing block is iSHT(coef): band-limited, so the 1x1 inner skip commutes with the synthesis --
-                    # skip(iSHT(coef)) = iSHT(W_skip coef).  Mix the channels of the COEFFICIENTS (lmax * mmax * 2 rows instead of one row
-                    # per output pixel: 9x fewer for the last block) on top of the dhconv output, put the bias on the (l, m) = (0, 0)
-                    # coefficient (a constant field b is b * sqrt(4 pi) there) and let the inverse DFT's epilogue apply the GELU
-                    rows = c.lmax * c.mmax * 2
+                    # skip(iSHT(coef)) = iSHT(W_skip coef), a channel mix of the COEFFICIENTS with the same matrix for every degree: it is
+                    # part of this block's dhconv matrices (load_params).  What is left: the bias on the (l, m) = (0, 0) coefficient (a
+                    # constant field b is b * sqrt(4 pi) there), and the GELU in the inverse DFT's epilogue
                     self._label = "inner_skip" + outer
-                    self._gemm(self.b_coef, blk["skip"], self.b_mixed, rows, e, e, a_sm=e, a_sk=1, o_sm=e, o_sn=1, res_post=self.b_mixed)
                     self._gemm(self.zero_a, self.zero_w, self.b_mixed, 1, 8, e, a_sm=8, a_sk=1, o_sm=e, o_sn=1, bias=blk["skip_b00"], res_post=self.b_mixed)
                     self._synthesis(self.b_mixed, tout, self.b_y, e, act=1)
                 else:
@@ -471,8 +475,8 @@ class SfnoEngine:
         n = 1 if fo else 2                                    # encoder
         for i in range(c.num_layers):
             last = i == c.num_layers - 1
-            change = i in (0, c.num_layers - 1)                   # grid-changing blocks: + residual synthesis (2), skip in the spectrum (+ its bias row)
-            n += 1 + 2 + 1 + 2 + 1 + ((2 + (1 if self.skip_in_spectrum else 0)) if change else 0)       # norm0, analysis, dhconv, synthesis, skip
+            change = i in (0, c.num_layers - 1)                   # grid-changing blocks: + residual synthesis (2)
+            n += 1 + 2 + 1 + 2 + 1 + (2 if change else 0)       # norm0, analysis, dhconv, synthesis, skip (grid space) or its bias row (spectrum)
             n += 2 if (fo if last else fi) else 3             # statistics + chain  |  norm1 + fc1 + fc2
         if not fo:
             n += 2 if self.cfg.embed_dim % 8 == 0 else 3      # decoder (part of the last chain otherwise)
