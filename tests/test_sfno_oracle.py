@@ -161,3 +161,22 @@ def test_sht_pinned_against_scipy_spherical_harmonics(grid, n_lat, n_lon, lmax):
     f = field @ m_.dft.astype(np.float64).T                                                  # [lat][2m]
     coef = np.einsum("km,mlk->lm", f[:, 0::2] + 1j * f[:, 1::2], m_.analysis.astype(np.float64))
     assert np.abs(coef - c).max() < 2e-6 * np.abs(c).max()
+
+
+@pytest.mark.parametrize("grid,n_lat,n_lon", [("equiangular", 33, 64), ("legendre-gauss", 16, 32)])
+def test_channel_mix_commutes_with_the_synthesis(grid, n_lat, n_lon):
+    """What SfnoEngine relies on for the grid-changing blocks: a 1x1 convolution of a band-limited field is the synthesis
+    of the channel-mixed coefficients, skip(iSHT(coef)) = iSHT(W coef), and a constant field b is the (l, m) = (0, 0) coefficient
+    b sqrt(4 pi) -- checked in float64 on the oracle's own transforms (the engine folds W into the block's dhconv matrices)."""
+    lmax = mmax = 16
+    sht = O.SHT(n_lat, n_lon, lmax, mmax, grid, torch.float64)
+    gen = torch.Generator().manual_seed(0)
+    C = 6
+    x = torch.randn(C, n_lat, n_lon, generator=gen, dtype=torch.float64)
+    coef = sht.forward(x)                                                            # (C, L, M) complex
+    w = torch.randn(C, C, generator=gen, dtype=torch.float64)
+    b = torch.randn(C, generator=gen, dtype=torch.float64)
+    grid_space = torch.einsum("oc,chw->ohw", w, sht.inverse(coef)) + b[:, None, None]
+    mixed = torch.einsum("oc,clm->olm", w.to(coef.dtype), coef)
+    mixed[:, 0, 0] += b * (4.0 * torch.pi) ** 0.5
+    assert (sht.inverse(mixed) - grid_space).abs().max().item() < 1e-11
