@@ -213,3 +213,29 @@ def test_grouped_row_order_of_the_mesh_to_grid_kernel(n):
     assert (rows[live] // 3 == node[live]).all() and (rows[live] % 3 == ((v % 48) // 16)[live]).all()
     assert (rows[~live] == 0).all()
 
+
+
+def test_edge_mlp_by_distributivity_and_grouped_receiver_sum_cpu():
+    """The two algebraic rewrites of the GraphCast engine, checked in float64 against the oracle's concatenated form:
+    fc1(concat(e, v_s[send], v_r[recv])) = e W_e^T + (v_s W_s^T)[send] + (v_r W_r^T)[recv] + b, and -- with three edges per receiver stored
+    receiver by receiver -- the receiver sum of the edge MLP's outputs taken over the kernel's virtual row order (grouped_rows_by3)."""
+    from skyrim_amd.graphcast.mesh import grouped_rows_by3
+    gen = torch.Generator().manual_seed(1)
+    L, n_send, n_recv = 32, 11, 21
+    E = 3 * n_recv
+    r = lambda *s: torch.randn(*s, generator=gen, dtype=torch.float64)  # noqa: E731
+    p = {"m.fc1.weight": r(L, 3 * L) / (3 * L) ** 0.5, "m.fc1.bias": r(L) * 0.1, "m.fc2.weight": r(L, L) / L ** 0.5, "m.fc2.bias": r(L) * 0.1,
+         "m.ln.weight": 1 + 0.1 * r(L), "m.ln.bias": 0.1 * r(L)}
+    e, vs, vr = r(E, L), r(n_send, L), r(n_recv, L)
+    edges = torch.stack([torch.randint(0, n_send, (E,), generator=gen), torch.arange(n_recv).repeat_interleave(3)], dim=1)
+    want_edges = O.edge_update(p, "m", e, vs, vr, edges)                           # concatenated form
+    want = O.aggregate(want_edges, edges[:, 1], n_recv)
+    w1 = p["m.fc1.weight"]
+    we, ws, wr = w1[:, :L], w1[:, L:2 * L], w1[:, 2 * L:]
+    rows = torch.from_numpy(grouped_rows_by3(n_recv))                              # virtual row -> edge
+    hidden = e[rows] @ we.T + p["m.fc1.bias"] + (vs @ ws.T)[edges[rows, 0]] + (vr @ wr.T)[edges[rows, 1]]
+    out = torch.nn.functional.layer_norm(torch.nn.functional.silu(hidden) @ p["m.fc2.weight"].T + p["m.fc2.bias"], (L,), p["m.ln.weight"], p["m.ln.bias"], 1e-5)
+    v = torch.arange(len(rows))
+    node = 16 * (v // 48) + v % 16
+    got = torch.zeros(n_recv, L, dtype=torch.float64).index_add_(0, node[node < n_recv], out[node < n_recv])      # what the epilogue sums in registers
+    assert (got - want).abs().max().item() < 1e-12
