@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SKPANGU_ABI_VERSION 2
+#define SKPANGU_ABI_VERSION 3
 
 /* precision modes: how each matrix product is formed on the MFMA pipe */
 #define SKPANGU_PREC_BF16X3 0 /* bf16 hi/lo split, 3 MFMA terms, fp32 range (wide-range mode; ~8e-5 per-channel error per step) */
@@ -60,6 +60,11 @@ typedef struct skpangu_config {
     int mlp_mode;  /* 0 (default): the row-tile kernels -- fc1 -> GELU -> fc2 -> LayerNorm -> residual as ONE kernel in the 3-term modes (the
                       hidden activation never reaches HBM), proj + LayerNorm + residual and the 2-term QKV with the token rows in
                       registers; 1: every linear as a tiled LDS-DMA GEMM (the round-1 path) */
+    int term_plan; /* per-layer MFMA term plan of the fp16-plane modes (F16X3, F16X3_Q) with mlp_mode 0.  Bit l (l = 0..3) set: the blocks of
+                      layer l + 1 run proj / fc1 / fc2 with TWO terms, A_hi W_hi + A_lo W_hi -- the weights as ONE fp16 plane, the
+                      activations still hi/lo pairs (a third fewer MFMAs, half the LDS and LDS-DMA bytes; 2^-12 relative weight rounding:
+                      ~5e-4 per-channel error per step with all four bits set against ~1e-4 with none).  0: three terms everywhere.
+                      The host default is F16X3_Q with term_plan 0xF ("f16x2"). */
 } skpangu_config;
 
 typedef struct skpangu_sizes {

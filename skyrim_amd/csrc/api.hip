@@ -28,6 +28,7 @@ bool make_geom(const skpangu_config& c, Geom& g) {
     if (c.roll_sign < -1 || c.roll_sign > 1 || (c.pad_mode != SKPANGU_PAD_CENTRE && c.pad_mode != SKPANGU_PAD_BACK)) return false;
     if (c.mask_value > 0.f || c.mask_value < -60000.f) return false;      // the mask lives in the fp16 bias tiles
     if (c.mlp_mode != 0 && c.mlp_mode != 1) return false;
+    if (c.term_plan < 0 || c.term_plan > 0xF) return false;
     g.roll_sign = c.roll_sign > 0 ? 1 : -1;
     g.mask_value = c.mask_value == 0.f ? -100.f : c.mask_value;
     g.n_lat = c.n_lat; g.n_lon = c.n_lon; g.n_levels = 13; g.n_channels = 69; g.surf0 = 65;
@@ -127,6 +128,8 @@ struct Engine : IEngine {
     bool fused_mlp = false;   // one-kernel MLP (fused_mlp.hip): 3-term modes with the hidden as hi/lo pair
     bool rt_proj = false, rt_qkv = false;   // row-tile proj / QKV kernels (rowtile.hip)
     bool fused_block = false;               // proj + LayerNorm + residual + MLP as one kernel (fused_block.hip)
+    int plan2 = 0;                          // bit l: layer l + 1 runs proj / fc1 / fc2 with TWO terms (weights as one fp16 plane, fused_block2.hip)
+    bool two_term(int layer) const { return (plan2 >> layer) & 1; }
     T* zrow = nullptr;
 
     // ---- per-stage timing with HIP events on the launch stream (bench.py roofline leg) ---- //
@@ -226,9 +229,13 @@ struct Engine : IEngine {
                 bw.fc1 = take_lin(a, 4 * c, c); bw.fc2 = take_lin(a, c, 4 * c);
                 bw.fc2h = LinW<f16>{nullptr, 0, 4 * c};
                 if (hid16 && !std::is_same<T, f16>::value) { bw.fc2h.plane = (long long)c * 4 * c; bw.fc2h.w = a.take<f16>((size_t)bw.fc2h.plane * 2); }
-                bw.w1f = fused_mlp ? a.take<T>((size_t)8 * c * c) : nullptr;      // 4c x c elements, hi + lo
-                bw.w2f = fused_mlp ? a.take<T>((size_t)8 * c * c) : nullptr;
-                bw.projf = (rt_proj || fused_block) ? a.take<T>((size_t)2 * c * c) : nullptr;
+                const bool t2 = two_term(layer);
+                bw.w1f = fused_mlp && !t2 ? a.take<T>((size_t)8 * c * c) : nullptr;      // 4c x c elements, hi + lo
+                bw.w2f = fused_mlp && !t2 ? a.take<T>((size_t)8 * c * c) : nullptr;
+                bw.projf = (rt_proj || fused_block) && !t2 ? a.take<T>((size_t)2 * c * c) : nullptr;
+                bw.projh = t2 ? a.take<T>((size_t)c * c) : nullptr;                       // hi plane only
+                bw.w1h = t2 ? a.take<T>((size_t)4 * c * c) : nullptr;
+                bw.w2h = t2 ? a.take<T>((size_t)4 * c * c) : nullptr;
                 bw.qkvf = rt_qkv ? a.take<T>((size_t)6 * c * c) : nullptr;
                 bw.qkv_b = a.take<float>(3 * c); bw.proj_b = a.take<float>(c);
                 bw.fc1_b = a.take<float>(4 * c); bw.fc2_b = a.take<float>(c);
@@ -272,13 +279,14 @@ struct Engine : IEngine {
         ws_bytes = (a.off + 255) / 256 * 256;
     }
 
-    explicit Engine(const Geom& geom, int hid16_ = 0, int qkv_a1 = 0, int mlp_mode = 0) : g(geom), hid16(hid16_) {
+    explicit Engine(const Geom& geom, int hid16_ = 0, int qkv_a1 = 0, int mlp_mode = 0, int term_plan = 0) : g(geom), hid16(hid16_) {
         fused_mlp = (P::NA == 2 && P::NW == 2 && !hid16_ && mlp_mode == 0);
         // proj in row-tile form measures the same as the tiled GEMM (0.199 vs 0.197 ms at C = 384, 0.264 vs 0.264 at C = 192: with 16 rows
         // per wave its LDS reads run at 2/3 of the LDS rate): kept behind SKP_RT_PROJ=1, the tiled LayerNorm GEMM stays the default
         rt_proj = (P::NA == 2 && P::NW == 2 && mlp_mode == 0 && getenv("SKP_RT_PROJ") != nullptr);
         fused_block = fused_mlp && getenv("SKP_SPLIT_BLOCK") == nullptr;
         rt_qkv = (std::is_same<P, PrecF16x3>::value && qkv_a1 && mlp_mode == 0);
+        plan2 = (std::is_same<P, PrecF16x3>::value && fused_block) ? term_plan : 0;     // the two-term kernel exists for fp16 planes, fused form
         wk.hid16 = hid16_;
         wk.qkv_a1 = qkv_a1;
         params = build_params(g, nullptr);
@@ -328,9 +336,13 @@ struct Engine : IEngine {
                 CK(lin(bw.fc2, P_(m, p + "mlp.fc2.weight"), c, 4 * c, 4 * c, 1, s));
                 if (hid16 && !std::is_same<T, f16>::value) CK((prep_weight<f16, 2>(P_(m, p + "mlp.fc2.weight"), const_cast<f16*>(bw.fc2h.w), bw.fc2h.plane, c, 4 * c, 4 * c, 4 * c, 1, 1, 1, s)));
                 if constexpr (P::NA == 2 && P::NW == 2) {
-                    if (rt_proj || fused_block) CK(prep_rowtile_weights<T>(P_(m, p + "attn.proj.weight"), const_cast<T*>(bw.projf), c, c, s));
+                    if (bw.projf) CK(prep_rowtile_weights<T>(P_(m, p + "attn.proj.weight"), const_cast<T*>(bw.projf), c, c, s));
                     if (rt_qkv) CK(prep_rowtile_weights<T>(P_(m, p + "attn.qkv.weight"), const_cast<T*>(bw.qkvf), 3 * c, c, s));
-                    if (fused_mlp) CK(prep_mlp_weights<T>(P_(m, p + "mlp.fc1.weight"), P_(m, p + "mlp.fc2.weight"), const_cast<T*>(bw.w1f), const_cast<T*>(bw.w2f), c, s));
+                    if (bw.w1f) CK(prep_mlp_weights<T>(P_(m, p + "mlp.fc1.weight"), P_(m, p + "mlp.fc2.weight"), const_cast<T*>(bw.w1f), const_cast<T*>(bw.w2f), c, s));
+                    if (bw.projh) {
+                        CK(prep_rowtile_weights<T>(P_(m, p + "attn.proj.weight"), const_cast<T*>(bw.projh), c, c, s, 1));
+                        CK(prep_mlp_weights<T>(P_(m, p + "mlp.fc1.weight"), P_(m, p + "mlp.fc2.weight"), const_cast<T*>(bw.w1h), const_cast<T*>(bw.w2h), c, s, 1));
+                    }
                 }
                 CK(copyf(bw.qkv_b, P_(m, p + "attn.qkv.bias"), 3 * c, s));
                 CK(copyf(bw.proj_b, P_(m, p + "attn.proj.bias"), c, s));
@@ -387,6 +399,14 @@ struct Engine : IEngine {
         mark(C_ATTN0 + o, s);
         AttnArgs<P> a{wk.q, wk.k, wk.vt, wk.qkv_plane, bw.bias_exp, wk.ao, wk.ao_plane, C, g.nwin[res], g.nW[res], heads};
         CK(launch_attention<P>(a, s));
+        if constexpr (std::is_same<P, PrecF16x3>::value) {
+            if (two_term(layer0)) {               // ... with two MFMA terms and the halves of the workgroup half a chunk apart
+                mark(C_FC1_0 + o, s);
+                CK(op_proj_mlp_skew(g, bw, w.winv[res][i & 1], res, xs, wk, s));
+                mark(-1, s);
+                return hipSuccess;
+            }
+        }
         if constexpr (P::NA == 2 && P::NW == 2) {
             if (fused_block) {                    // everything after the attention in one kernel; timed under "mlp"
                 mark(C_FC1_0 + o, s);
@@ -499,8 +519,8 @@ IEngine* make_engine(const skpangu_config& cfg, const Geom& g) {
         case SKPANGU_PREC_BF16X3: return new Engine<PrecBF16x3>(g, 0, 0, cfg.mlp_mode);
         case SKPANGU_PREC_F16: return new Engine<PrecF16>(g);
         case SKPANGU_PREC_BF16X3_H16: return new Engine<PrecBF16x3>(g, 1);
-        case SKPANGU_PREC_F16X3: return new Engine<PrecF16x3>(g, 0, 0, cfg.mlp_mode);
-        case SKPANGU_PREC_F16X3_Q: return new Engine<PrecF16x3>(g, 0, 1, cfg.mlp_mode);
+        case SKPANGU_PREC_F16X3: return new Engine<PrecF16x3>(g, 0, 0, cfg.mlp_mode, cfg.term_plan);
+        case SKPANGU_PREC_F16X3_Q: return new Engine<PrecF16x3>(g, 0, 1, cfg.mlp_mode, cfg.term_plan);
         case SKPANGU_PREC_F16X3_QH: return new Engine<PrecF16x3>(g, 1, 1);
         default: return nullptr;
     }

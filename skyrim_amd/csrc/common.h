@@ -160,6 +160,31 @@ __device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
     return ((f32x2)(0.5f) * x) * ((f32x2)(1.0f) + t);
 }
 __device__ __forceinline__ float gelu_erf(float x) { return gelu_erf2((f32x2){x, x}).x; }
+// The same polynomial in Estrin form: 4 + 2 + 1 FMAs in three levels instead of a chain of 7 dependent ones.  Where the evaluation is
+// spliced between MFMAs (fused_block2.hip) the dependent v_pk_fma chain of the Horner form costs a wait state per link; the Estrin
+// form leaves the scheduler independent work at every level.  Same coefficients; the results differ by fp32 rounding only.
+__device__ __forceinline__ f32x2 gelu_erf2e(f32x2 x) {
+    f32x2 a;
+    a.x = __builtin_amdgcn_fmed3f(__builtin_fabsf(x.x), 0.f, 5.9396970f);
+    a.y = __builtin_amdgcn_fmed3f(__builtin_fabsf(x.y), 0.f, 5.9396970f);
+    // Q(a) = a (c0 + c1 a + ... + c7 a^7), c0 = -1.151117682, ..., c7 = -6.177511978e-07
+    const f32x2 a2 = a * a;
+    const f32x2 q01 = __builtin_elementwise_fma(a, (f32x2)(-4.591012597e-01f), (f32x2)(-1.151117682e+00f));
+    const f32x2 q23 = __builtin_elementwise_fma(a, (f32x2)(7.545167115e-03f), (f32x2)(-5.282834917e-02f));
+    const f32x2 q45 = __builtin_elementwise_fma(a, (f32x2)(-4.273382365e-05f), (f32x2)(-4.982745158e-04f));
+    const f32x2 q67 = __builtin_elementwise_fma(a, (f32x2)(-6.177511978e-07f), (f32x2)(1.091520153e-05f));
+    const f32x2 a4 = a2 * a2;
+    const f32x2 q03 = __builtin_elementwise_fma(a2, q23, q01);
+    const f32x2 q47 = __builtin_elementwise_fma(a2, q67, q45);
+    f32x2 p = __builtin_elementwise_fma(a4, q47, q03);
+    p = p * a;
+    f32x2 t;                                  // erf(|x|/sqrt2) = 1 - erfc
+    t.x = 1.0f - __builtin_amdgcn_exp2f(p.x);
+    t.y = 1.0f - __builtin_amdgcn_exp2f(p.y);
+    t.x = __builtin_copysignf(t.x, x.x);
+    t.y = __builtin_copysignf(t.y, x.y);
+    return ((f32x2)(0.5f) * x) * ((f32x2)(1.0f) + t);
+}
 // GELU of the 8 consecutive columns held in a fragment pair
 __device__ __forceinline__ void gelu_erf8(const f32x4& lo, const f32x4& hi, float (&v)[8]) {
     const f32x2 r0 = gelu_erf2((f32x2){lo[0], lo[1]}), r1 = gelu_erf2((f32x2){lo[2], lo[3]});

@@ -302,10 +302,11 @@ fused_mlp_kernel(const MlpArgs<T> a) {
 }
 
 // ---- prepare: fp32 master weights -> fragment-order hi/lo planes ---------------------------------------------------------------- //
+//   (planes = 1: the hi plane only, blocks [(j KS + ks) 2 + n] and [j CF + c] -- fused_block2.hip)
 //   w1f[((j KS + ks) 2 + n) 2 + plane][lane][e] = fc1.weight[32 j + 16 n + (lane & 15)][32 ks + 8 (lane >> 4) + e]
 //   w2f[(j CF + c) 2 + plane][lane][e]          = fc2.weight[perm8_col(16 c + (lane & 15))][32 j + 16 (e >> 2) + 4 (lane >> 4) + (e & 3)]
 template <class T>
-__global__ void prep_mlp_w1_kernel(const float* __restrict__ w1, T* __restrict__ out, int C) {
+__global__ void prep_mlp_w1_kernel(const float* __restrict__ w1, T* __restrict__ out, int C, int planes) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;     // one (block pair, lane, e)
     const int KS = C / 32;
     const long long total = (long long)(4 * C / 32) * KS * 2 * 512;
@@ -317,13 +318,13 @@ __global__ void prep_mlp_w1_kernel(const float* __restrict__ w1, T* __restrict__
     const int j = (int)(q / KS);
     const float v = w1[(long long)(32 * j + 16 * n + (lane & 15)) * C + 32 * ks + 8 * (lane >> 4) + e];
     const T h = (T)v;
-    const long long o = ((((long long)j * KS + ks) * 2 + n) * 2 << 9) + lane * 8 + e;
+    const long long o = ((((long long)j * KS + ks) * 2 + n) * planes << 9) + lane * 8 + e;
     out[o] = h;
-    out[o + 512] = (T)(v - (float)h);
+    if (planes == 2) out[o + 512] = (T)(v - (float)h);
 }
 
 template <class T>
-__global__ void prep_mlp_w2_kernel(const float* __restrict__ w2, T* __restrict__ out, int C) {
+__global__ void prep_mlp_w2_kernel(const float* __restrict__ w2, T* __restrict__ out, int C, int planes) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int CF = C / 16;
     const long long total = (long long)(4 * C / 32) * CF * 512;
@@ -336,21 +337,21 @@ __global__ void prep_mlp_w2_kernel(const float* __restrict__ w2, T* __restrict__
     const int hid = 32 * j + 16 * (e >> 2) + 4 * (lane >> 4) + (e & 3);
     const float v = w2[(long long)col * (4 * C) + hid];
     const T h = (T)v;
-    const long long o = ((((long long)j * CF + c) * 2) << 9) + lane * 8 + e;
+    const long long o = ((((long long)j * CF + c) * planes) << 9) + lane * 8 + e;
     out[o] = h;
-    out[o + 512] = (T)(v - (float)h);
+    if (planes == 2) out[o + 512] = (T)(v - (float)h);
 }
 
 template <class T>
-hipError_t prep_mlp_weights(const float* w1, const float* w2, T* w1f, T* w2f, int C, hipStream_t s) {
-    if (C != 192 && C != 384) return hipErrorInvalidValue;
+hipError_t prep_mlp_weights(const float* w1, const float* w2, T* w1f, T* w2f, int C, hipStream_t s, int planes) {
+    if ((C != 192 && C != 384) || (planes != 1 && planes != 2)) return hipErrorInvalidValue;
     const long long t1 = (long long)(4 * C / 32) * (C / 32) * 2 * 512, t2 = (long long)(4 * C / 32) * (C / 16) * 512;
-    hipLaunchKernelGGL((prep_mlp_w1_kernel<T>), dim3((unsigned)((t1 + 255) / 256)), dim3(256), 0, s, w1, w1f, C);
-    hipLaunchKernelGGL((prep_mlp_w2_kernel<T>), dim3((unsigned)((t2 + 255) / 256)), dim3(256), 0, s, w2, w2f, C);
+    hipLaunchKernelGGL((prep_mlp_w1_kernel<T>), dim3((unsigned)((t1 + 255) / 256)), dim3(256), 0, s, w1, w1f, C, planes);
+    hipLaunchKernelGGL((prep_mlp_w2_kernel<T>), dim3((unsigned)((t2 + 255) / 256)), dim3(256), 0, s, w2, w2f, C, planes);
     return hipGetLastError();
 }
-template hipError_t prep_mlp_weights<bf16>(const float*, const float*, bf16*, bf16*, int, hipStream_t);
-template hipError_t prep_mlp_weights<f16>(const float*, const float*, f16*, f16*, int, hipStream_t);
+template hipError_t prep_mlp_weights<bf16>(const float*, const float*, bf16*, bf16*, int, hipStream_t, int);
+template hipError_t prep_mlp_weights<f16>(const float*, const float*, f16*, f16*, int, hipStream_t, int);
 
 template <class T, class S>
 static hipError_t launch_fused_mlp(const MlpArgs<T>& a, hipStream_t s) {

@@ -65,6 +65,15 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
                  : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
 }
 
+// The same with a wave-uniform base address in SGPRs and ONE per-lane byte offset (lane * 16 for a contiguous KiB): no 64-bit
+// per-lane address arithmetic, no address VGPR pair per request.
+__device__ __forceinline__ void glds16_s(const void* sbase, unsigned voff, unsigned lds_dst) {
+    unsigned keep;
+    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_dst);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(dst) : "memory");
+}
+
 template <class P, class AS, class EP>
 struct DmaArgs {
     AS as;

@@ -25,6 +25,7 @@ struct BlockW {
     LinW<f16> fc2h;          // fc2 weight as fp16 hi/lo planes (only in the fp16-hidden mode)
     const T *w1f, *w2f;      // fc1 / fc2 in the fused MLP's fragment order (fused_mlp.hip), or null
     const T *projf, *qkvf;   // proj / qkv in the row-tile kernels' fragment order (rowtile.hip), or null
+    const T *projh, *w1h, *w2h;   // proj / fc1 / fc2 in fragment order, HI PLANE ONLY: the two-term block kernel (fused_block2.hip), or null
     const float *qkv_b, *proj_b, *fc1_b, *fc2_b, *n1_g, *n1_b, *n2_g, *n2_b;
     const f16* bias_exp;     // [types][heads][9][9][64][4] (+ shifted-window mask on odd blocks)
 };
@@ -89,13 +90,15 @@ template <class P> hipError_t op_down(const Geom&, const ModelW<typename P::T>&,
 template <class P> hipError_t op_up(const Geom&, const ModelW<typename P::T>&, const typename P::T* X2s, typename P::T* X4s, const Work<P>&, hipStream_t);
 // fc1 -> GELU -> fc2 -> LayerNorm -> residual in one kernel (3-term modes); weights from prep_mlp_weights
 template <class P> hipError_t op_mlp_fused(const Geom&, const BlockW<typename P::T>&, int res, typename P::T* Xs, const Work<P>&, hipStream_t);
-template <class T> hipError_t prep_mlp_weights(const float* w1, const float* w2, T* w1f, T* w2f, int C, hipStream_t);
+template <class T> hipError_t prep_mlp_weights(const float* w1, const float* w2, T* w1f, T* w2f, int C, hipStream_t, int planes = 2);
 // row-tile forms of proj (+ LayerNorm + window reverse + residual) and of the 2-term QKV linear (rowtile.hip)
 template <class P> hipError_t op_proj_rowtile(const Geom&, const BlockW<typename P::T>&, const int* widx, int res, typename P::T* Xs, const Work<P>&, hipStream_t);
 hipError_t op_qkv_rowtile(const Geom&, const BlockW<f16>&, const int* widx, int res, const f16* Xs, const Work<PrecF16x3>&, hipStream_t);
-template <class T> hipError_t prep_rowtile_weights(const float* w, T* wf, int N, int K, hipStream_t);
+template <class T> hipError_t prep_rowtile_weights(const float* w, T* wf, int N, int K, hipStream_t, int planes = 2);
 // proj + LayerNorm + residual + MLP + LayerNorm + residual in one kernel (fused_block.hip): weights from prep_rowtile_weights / prep_mlp_weights
 template <class P> hipError_t op_proj_mlp_fused(const Geom&, const BlockW<typename P::T>&, const int* winv, int res, typename P::T* Xs, const Work<P>&, hipStream_t);
+// the same with TWO MFMA terms (weights as one fp16 plane) and the two waves of a SIMD half a chunk apart (fused_block2.hip)
+hipError_t op_proj_mlp_skew(const Geom&, const BlockW<f16>&, const int* winv, int res, f16* Xs, const Work<PrecF16x3>&, hipStream_t);
 template <class T, int NPL> hipError_t split_planes(const float* x, T* planes, long long plane, long long n, int C, hipStream_t);
 template <class T> hipError_t merge_planes(const T* planes, long long plane, float* x, long long n, int C, hipStream_t);
 

@@ -317,7 +317,7 @@ __global__ void __launch_bounds__(S::THREADS) rt_qkv_kernel(const QkvArgs a) {
 // ---- prepare: [N][K] fp32 -> fragment-order hi/lo planes, rows in perm8 order -------------------------------------------------- //
 //   wf[((j KS + ks) 2 + n) 2 + plane][lane][e] = W[perm8_col(32 j + 16 n + (lane & 15))][32 ks + 8 (lane >> 4) + e]
 template <class T>
-__global__ void prep_rowtile_kernel(const float* __restrict__ w, T* __restrict__ out, int N, int K) {
+__global__ void prep_rowtile_kernel(const float* __restrict__ w, T* __restrict__ out, int N, int K, int planes) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int KS = K / 32;
     const long long total = (long long)(N / 32) * KS * 2 * 512;
@@ -329,20 +329,20 @@ __global__ void prep_rowtile_kernel(const float* __restrict__ w, T* __restrict__
     const int j = (int)(q / KS);
     const float v = w[(long long)perm8_col(32 * j + 16 * n + (lane & 15)) * K + 32 * ks + 8 * (lane >> 4) + e];
     const T h = (T)v;
-    const long long o = ((((long long)j * KS + ks) * 2 + n) * 2 << 9) + lane * 8 + e;
+    const long long o = ((((long long)j * KS + ks) * 2 + n) * planes << 9) + lane * 8 + e;
     out[o] = h;
-    out[o + 512] = (T)(v - (float)h);
+    if (planes == 2) out[o + 512] = (T)(v - (float)h);
 }
 
 template <class T>
-hipError_t prep_rowtile_weights(const float* w, T* wf, int N, int K, hipStream_t s) {
-    if ((N & 31) || (K & 31)) return hipErrorInvalidValue;
+hipError_t prep_rowtile_weights(const float* w, T* wf, int N, int K, hipStream_t s, int planes) {
+    if ((N & 31) || (K & 31) || (planes != 1 && planes != 2)) return hipErrorInvalidValue;
     const long long total = (long long)(N / 32) * (K / 32) * 2 * 512;
-    hipLaunchKernelGGL((prep_rowtile_kernel<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, wf, N, K);
+    hipLaunchKernelGGL((prep_rowtile_kernel<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, wf, N, K, planes);
     return hipGetLastError();
 }
-template hipError_t prep_rowtile_weights<bf16>(const float*, bf16*, int, int, hipStream_t);
-template hipError_t prep_rowtile_weights<f16>(const float*, f16*, int, int, hipStream_t);
+template hipError_t prep_rowtile_weights<bf16>(const float*, bf16*, int, int, hipStream_t, int);
+template hipError_t prep_rowtile_weights<f16>(const float*, f16*, int, int, hipStream_t, int);
 
 template <class T, class S>
 static hipError_t launch_proj(const ProjArgs<T>& a, hipStream_t s) {

@@ -23,17 +23,20 @@ PREC_F16X3 = 3
 PREC_F16X3_Q = 4
 PREC_F16X3_QH = 5
 PRECISIONS = {"bf16x3": PREC_BF16X3, "f16": PREC_F16, "bf16x3h": PREC_BF16X3_H16,
-              "f16x3": PREC_F16X3, "f16x3q": PREC_F16X3_Q, "f16x3qh": PREC_F16X3_QH}
-# default: fp16 hi/lo planes (22-bit operands), 3 MFMA terms, QKV 2 terms; ~1e-4 per-channel error per step.
-# "bf16x3" is the wide-range alternative (activations beyond fp16's 65504).
-DEFAULT_PRECISION = "f16x3q"
+              "f16x3": PREC_F16X3, "f16x3q": PREC_F16X3_Q, "f16x3qh": PREC_F16X3_QH, "f16x2": PREC_F16X3_Q}
+# per-layer MFMA term plan (skpangu_config.term_plan): bit l = layer l + 1 runs proj / fc1 / fc2 with two terms (weights as ONE fp16 plane)
+TERM_PLANS = {"f16x2": 0xF}
+# default "f16x2": fp16 hi/lo ACTIVATION planes, weights as one fp16 plane in proj / fc1 / fc2 (2 MFMA terms), QKV 2 terms (stream hi plane x
+# weight hi/lo), attention single-term fp16; ~5e-4 per-channel error per step (bar 1e-3).  "f16x3q" is the same with 3 terms in proj / fc1 /
+# fc2 (~1e-4); "bf16x3" is the wide-range alternative (activations beyond fp16's 65504).
+DEFAULT_PRECISION = "f16x2"
 
 _LIB_PATH = Path(__file__).resolve().parent.parent / "lib" / "libskyrim_pangu.so"
 
 
 class SkConfig(ctypes.Structure):
     _fields_ = [("n_lat", ctypes.c_int), ("n_lon", ctypes.c_int), ("precision", ctypes.c_int),
-                ("roll_sign", ctypes.c_int), ("pad_mode", ctypes.c_int), ("mask_value", ctypes.c_float), ("mlp_mode", ctypes.c_int)]
+                ("roll_sign", ctypes.c_int), ("pad_mode", ctypes.c_int), ("mask_value", ctypes.c_float), ("mlp_mode", ctypes.c_int), ("term_plan", ctypes.c_int)]
 
 
 class SkSizes(ctypes.Structure):
@@ -106,15 +109,20 @@ PAD_MODES = {"centre": 0, "back": 1}
 MLP_MODES = {"fused": 0, "split": 1}
 
 
-def make_config(geom: PanguGeometry, precision: str = DEFAULT_PRECISION, roll_sign: int = -1, mask_value: float = -100.0, mlp: str = "fused") -> SkConfig:
-    """``skpangu_config`` of a geometry + the switchable conventions (include/skyrim_pangu.h; oracle: pangu_oracle.Conventions)."""
+def make_config(geom: PanguGeometry, precision: str = DEFAULT_PRECISION, roll_sign: int = -1, mask_value: float = -100.0, mlp: str = "fused",
+                term_plan: int | None = None) -> SkConfig:
+    """``skpangu_config`` of a geometry + the switchable conventions (include/skyrim_pangu.h; oracle: pangu_oracle.Conventions).
+    ``term_plan`` overrides the precision name's per-layer term plan (bit l: layer l + 1 runs proj / fc1 / fc2 with two MFMA terms)."""
     if roll_sign not in (-1, 1):
         raise ValueError("roll_sign is -1 (Swin: roll by -(1,3,6) first) or +1 (pseudocode as written)")
-    return SkConfig(geom.n_lat, geom.n_lon, PRECISIONS[precision], roll_sign, PAD_MODES[geom.pad], float(mask_value), MLP_MODES[mlp])
+    plan = TERM_PLANS.get(precision, 0) if term_plan is None else int(term_plan)
+    if plan and (precision not in ("f16x2", "f16x3", "f16x3q") or mlp != "fused"):
+        raise ValueError("a term plan needs fp16 planes (f16x2 / f16x3 / f16x3q) and the fused kernels")
+    return SkConfig(geom.n_lat, geom.n_lon, PRECISIONS[precision], roll_sign, PAD_MODES[geom.pad], float(mask_value), MLP_MODES[mlp], plan)
 
 
-def query_sizes(geom: PanguGeometry, precision: str = DEFAULT_PRECISION) -> SkSizes:
-    cfg = make_config(geom, precision)
+def query_sizes(geom: PanguGeometry, precision: str = DEFAULT_PRECISION, cfg: SkConfig | None = None) -> SkSizes:
+    cfg = cfg or make_config(geom, precision)
     out = SkSizes()
     _check(load_library().skpangu_query_sizes(ctypes.byref(cfg), ctypes.byref(out)), "skpangu_query_sizes")
     return out
@@ -139,18 +147,22 @@ class PanguEngine:
     """Device-resident Pangu 6-h step.  ``step`` maps a (69, n_lat, n_lon) fp32 CUDA tensor to the next state."""
 
     def __init__(self, geom: PanguGeometry | None = None, precision: str = DEFAULT_PRECISION, device: str | torch.device = "cuda:0",
-                 roll_sign: int = -1, mask_value: float = -100.0, mlp: str = "fused"):
+                 roll_sign: int = -1, mask_value: float = -100.0, mlp: str = "fused", term_plan: int | None = None):
         """``roll_sign`` / ``mask_value`` / ``geom.pad``: the conventions the public pseudocode leaves open.
-        ``mlp``: "fused" (default; one kernel per MLP in the 3-term modes, csrc/fused_mlp.hip) or "split" (two tiled GEMMs)."""
+        ``mlp``: "fused" (default; one kernel per MLP in the 3-term modes, csrc/fused_mlp.hip) or "split" (two tiled GEMMs).
+        ``term_plan``: per-layer two-term mask (include/skyrim_pangu.h); None = the precision name's own ("f16x2": all four layers)."""
         self.lib = load_library()
         if not torch.cuda.is_available():
             raise RuntimeError("PanguEngine needs a ROCm GPU (gfx950); there is no CPU fallback")
         self.geom = geom or PanguGeometry()
         self.precision = precision
         self.device = torch.device(device)
-        self.cfg = make_config(self.geom, precision, roll_sign, mask_value, mlp)
+        if mlp != "fused" and precision == "f16x2" and term_plan is None:
+            term_plan = 0                                   # the tiled-GEMM path has no two-term kernels: "f16x2" + split = f16x3q + split
+        self.cfg = make_config(self.geom, precision, roll_sign, mask_value, mlp, term_plan)
         self.mlp = mlp
-        self.sizes = query_sizes(self.geom, precision)
+        self.term_plan = self.cfg.term_plan
+        self.sizes = query_sizes(self.geom, precision, self.cfg)
         with torch.cuda.device(self.device):
             self._prepared = torch.empty(self.sizes.prepared_bytes, dtype=torch.uint8, device=self.device)
             self._workspace = torch.empty(self.sizes.workspace_bytes, dtype=torch.uint8, device=self.device)

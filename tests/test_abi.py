@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in skyrim_pangu.h but not exported"
     assert set(syms) == set(E.EXPORTS)
-    assert lib.skpangu_abi_version() == 2
+    assert lib.skpangu_abi_version() == 3
 
 
 @pytest.mark.parametrize("prec", ["bf16x3", "f16", "f16x3q", "f16x3qh"])

@@ -2,7 +2,9 @@
 
 Tolerances (floating point; stated per the north star): per-channel max|y - ref| / max|ref| <= 1e-3.
 Modes (skyrim_amd/pangu/engine.py PRECISIONS): hi/lo split GEMMs with fp16 single-term attention --
-"f16x3q" (default: fp16 planes, QKV 2-term; observed ~1e-4 -> asserted <= 3e-4), "f16x3", "bf16x3" (3 terms
+"f16x2" (default: fp16 activation planes x ONE fp16 weight plane in proj / fc1 / fc2 = 2 MFMA terms, QKV 2-term; oracle emulation of
+exactly this rounding plan: 4.2e-4 after one step, 5.3e-4 after four -> asserted <= 8e-4),
+"f16x3q" (the same with 3 terms; observed ~1e-4 -> asserted <= 3e-4), "f16x3", "bf16x3" (3 terms
 everywhere; ~8e-5 -> <= 3e-4), "bf16x3h" / "f16x3qh" (additionally the MLP hidden as one fp16 plane; ~4e-4 ->
 asserted <= 1e-3), and "f16" (single-term speed mode, observed ~1.2e-3, does NOT meet the bar -> held to 5e-3).
 Stage-level tests use max-abs / max-abs-ref.
@@ -12,12 +14,14 @@ import pytest
 import torch
 
 from oracle import pangu_oracle as O
+from skyrim_amd.pangu.engine import DEFAULT_PRECISION
 from skyrim_amd.pangu.spec import PanguGeometry, init_synthetic, synthetic_state
 
 pytestmark = pytest.mark.gpu
 
-STAGE_TOL = {"bf16x3": 5e-4, "f16x3": 5e-4, "f16x3q": 5e-4, "bf16x3h": 2e-3, "f16x3qh": 2e-3, "f16": 4e-3}
-STEP_TOL = {"bf16x3": 3e-4, "f16x3": 3e-4, "f16x3q": 3e-4, "bf16x3h": 1e-3, "f16x3qh": 1e-3, "f16": 5e-3}   # 3-term modes: 3x inside the bar
+STAGE_TOL = {"f16x2": 1.5e-3, "bf16x3": 5e-4, "f16x3": 5e-4, "f16x3q": 5e-4, "bf16x3h": 2e-3, "f16x3qh": 2e-3, "f16": 4e-3}
+DEF_TOL = 8e-4       # the default mode's asserted step error (STEP_TOL[DEFAULT_PRECISION])
+STEP_TOL = {"f16x2": 8e-4, "bf16x3": 3e-4, "f16x3": 3e-4, "f16x3q": 3e-4, "bf16x3h": 1e-3, "f16x3qh": 1e-3, "f16": 5e-3}   # 3-term modes: 3x inside the bar
 
 
 def rel(a, b):
@@ -33,7 +37,7 @@ def ref(toy):
     return taps, y
 
 
-@pytest.fixture(scope="module", params=["f16x3q", "bf16x3", "f16x3", "bf16x3h", "f16x3qh", "f16"])
+@pytest.fixture(scope="module", params=["f16x2", "f16x3q", "bf16x3", "f16x3", "bf16x3h", "f16x3qh", "f16"])
 def eng(request, toy):
     from skyrim_amd.pangu.engine import PanguEngine
     g, params, x = toy
@@ -73,6 +77,10 @@ def test_downsample_upsample_recover(eng, toy, ref):
     assert rel(eng.upsample(taps["layer3"].cuda()), taps["up"]) < tol
     got = eng.patch_recover(taps["layer1.block1"].cuda(), taps["layer4"].cuda())
     assert O.per_channel_rel_err(got.cpu(), y).max().item() < tol
+
+
+def test_default_tolerance_is_the_default_modes():
+    assert DEF_TOL == STEP_TOL[DEFAULT_PRECISION] and DEF_TOL < 1e-3
 
 
 def test_full_step_per_channel(eng, toy, ref):
@@ -136,7 +144,7 @@ def test_other_geometries_step_vs_oracle(grid):
     e.load_params(params)
     y = e.step(x.cuda())
     err = O.per_channel_rel_err(y.cpu(), O.forward(params, x))
-    assert torch.isfinite(y).all() and err.max().item() < 3e-4, err
+    assert torch.isfinite(y).all() and err.max().item() < DEF_TOL, err
 
 
 def test_step_before_prepare_is_an_error(toy):
@@ -158,7 +166,7 @@ def test_profile_hooks_cover_the_step(eng, toy):
     eng.profile(False)
     by = {s["name"]: s for s in stats}
     # 3-term modes: projection + MLP as one kernel per block (fused_block.hip); the others: proj, fc1, fc2 as separate launches
-    mlp = "proj_mlp_r1" if eng.precision in ("f16x3q", "f16x3", "bf16x3") else "fc1_r1"
+    mlp = "proj_mlp_r1" if eng.precision in ("f16x2", "f16x3q", "f16x3", "bf16x3") else "fc1_r1"
     assert by[mlp]["launches"] == 12 and by["qkv_r0"]["launches"] == 4 and by["embed"]["launches"] == 1
     assert by["fc2_r1"]["launches"] == by["proj_r1"]["launches"] == (0 if mlp == "proj_mlp_r1" else 12)
     assert all(s["total_ms"] > 0 for s in stats if s["launches"])
@@ -193,7 +201,7 @@ def test_full_size_step_vs_oracle(full, full_ref):
     err = O.per_channel_rel_err(y.cpu(), full_ref[0])
     assert torch.isfinite(y).all()
     assert err.max().item() < 1e-3, err
-    assert err.max().item() < 3e-4, err          # what the default mode actually delivers (~1.5e-4)
+    assert err.max().item() < DEF_TOL, err       # what the default mode is asserted to deliver (two-term plan: ~5e-4)
 
 
 @pytest.mark.timeout(1500)
@@ -207,7 +215,7 @@ def test_full_size_24h_rollout_vs_oracle(full, full_ref):
         e.step(state, out=state)                # in place, as bench.py times it
         errs.append(O.per_channel_rel_err(state.cpu(), full_ref[k]).max().item())
     assert torch.isfinite(state).all()
-    assert max(errs) < 5e-4, errs
+    assert max(errs) < DEF_TOL, errs
 
 
 @pytest.mark.timeout(900)
@@ -221,7 +229,7 @@ def test_full_size_longitude_shift_equivariance_and_fp16_mode(full):
     e2 = PanguEngine(g, device="cuda:0")
     e2.load_params(p2)
     y2 = e2.step(torch.roll(x, 480, dims=-1).cuda())
-    assert O.per_channel_rel_err(torch.roll(y2, -480, dims=-1).cpu(), y.cpu()).max().item() < 5e-4
+    assert O.per_channel_rel_err(torch.roll(y2, -480, dims=-1).cpu(), y.cpu()).max().item() < 2 * DEF_TOL
     del e2
     e3 = PanguEngine(g, "f16", "cuda:0")
     e3.load_params(params)
@@ -344,10 +352,10 @@ def test_switchable_conventions_match_the_oracle(toy, conv):
     eng.load_params(params)
     y = eng.step(x.cuda()).cpu()
     want = O.forward(params, x, conv=O.Conventions(**conv))
-    assert O.per_channel_rel_err(y, want).max().item() < 3e-4
+    assert O.per_channel_rel_err(y, want).max().item() < DEF_TOL
     assert O.per_channel_rel_err(y, O.forward(params, x)).max().item() > 1e-3
     y2 = eng.step(eng.step(x.cuda())).cpu()                     # rolled + unrolled blocks compose over steps
-    assert O.per_channel_rel_err(y2, O.rollout(params, x, 2, conv=O.Conventions(**conv))[1]).max().item() < 3e-4
+    assert O.per_channel_rel_err(y2, O.rollout(params, x, 2, conv=O.Conventions(**conv))[1]).max().item() < DEF_TOL
 
 
 def test_fused_mlp_kernel_matches_the_two_gemm_path_and_the_oracle(toy, ref):
