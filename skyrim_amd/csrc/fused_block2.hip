@@ -2,26 +2,18 @@
 //
 //     A W^T  ~  A_hi W_hi^T + A_lo W_hi^T          (activations stay hi/lo pairs, the weights are ONE fp16 plane)
 //
-// with the MLP's chunk loop SOFTWARE-PIPELINED inside every wave.
-//
 // Why two terms.  The prepared weights are constants; rounding them to 11 significant bits perturbs the model by 2^-12 relative per
 // weight (measured on the oracle with exactly this plan -- proj, fc1, fc2 weights rounded, QKV activation rounded: 4.2e-4 per-channel
 // error after one step, 5.3e-4 after four, bar 1e-3).  It removes a third of the MFMAs, HALF of the bytes that cross LDS
 // (the token tile lives in registers, only weights stream through LDS) and half of the LDS-DMA traffic.
 //
-// Why the pipelining.  With 256 registers a SIMD holds two waves, and the timing probes of this kernel's first form (fc1(j) | GELU(j) |
-// fc2(j) per wave; PROBE below) showed every removed phase coming off the kernel time ONE FOR ONE -- GELU, the LDS reads' start-up
-// latencies, the LDS-DMA issue, the row gathers and stores: a wave is a serial chain, two chains per SIMD do not fill the matrix pipe
-// (45 % busy), and re-ordering work BETWEEN the waves (the halves of the workgroup half a chunk apart, two 4-wave workgroups per CU with
-// a start stagger) changes nothing as long as each chain is that long.  What shortens a chain is overlap INSIDE the wave:
-//
-//     interval j:   [ fc1(j) MFMAs  +  GELU(j-1) spliced between them ]   [ fc2(j-1) MFMAs  +  the LDS-DMA requests of W1(j+1), W2(j) ]
-//
-// fc2 runs one chunk behind fc1, so the GELU of chunk j-1 (VALU, ~110 instructions per 16 tokens) has no consumer waiting for it and
-// sits in the shadow of fc1(j)'s MFMAs; the weight-fragment ring runs through both phases without draining (one exposed LDS latency
-// per interval instead of two); the DMA requests ride between fc2's MFMAs instead of in front of the interval.  One barrier per
-// interval.  Ring: W1(j) in slot j & 1, W2(j) in slot 2 + (j & 1); the projection's 32-column blocks alternate between slots 2 and 3
-// while W1(0) lands in slot 0.
+// Two launch shapes (DESIGN.md 5.5 has the measurements, including what did NOT help):
+//   DUO (default)   4-wave workgroups, TWO per CU (one wave of each on every SIMD), two LDS slots of one chunk each and two barriers per
+//                   32-unit chunk, exactly fused_block.hip's loop:  | fc1(j) | GELU(j) | fc2(j) |.  The hi-only chunk is 24 KB at C = 384,
+//                   so two workgroups fit a CU where the three-term kernel fits one; the two run free of each other.
+//   one 8-wave workgroup per CU, a five-slot ring (W1(j) in slot j & 1, W2(j) in slot 2 + j % 3) and ONE barrier per chunk, optionally
+//                   with the halves of the workgroup (waves 0-3 / 4-7 = the two waves of each SIMD) taking the chunk in different orders
+//                   (lead: fc1(j) GELU(j) fc2(j); trail: GELU(j-1) fc2(j-1) fc1(j)) -- measured equal to the plain order.
 //
 // Row-tile structure, epilogues and data layouts are fused_block.hip's: a wave owns FM x 16 stream tokens, their attention rows are
 // gathered through the inverse window table as MFMA B-operand fragments, x_mid = x + LayerNorm(proj) becomes the MLP's operand in
@@ -32,22 +24,22 @@
 
 namespace skp {
 
-template <int C_, int FM_, int RD_, int NV_, int PROBE_ = 0>
+template <int C_, int FM_, int RD_, bool SKEW_, bool DUO_, int PROBE_ = 0>
 struct Blk2Shape {
     // timing probes (measurement only; results are wrong): 1 no GELU polynomial, 2 one fragment pair read per phase, 4 no weight DMA
     // in the MLP loop, 8 no barrier in the MLP loop, 16 no row gathers / stores
     static constexpr int PROBE = PROBE_;
-    static constexpr int C = C_, FM = FM_, NWAVES = 8, THREADS = 512, RD = RD_;
-    static constexpr int NV = NV_;                   // VALU instructions the scheduler is asked to place behind every MFMA of a spliced step (0: its own choice)
+    static constexpr bool SKEW = SKEW_, DUO = DUO_;
+    static constexpr int C = C_, FM = FM_, NWAVES = DUO_ ? 4 : 8, THREADS = 64 * NWAVES, RD = RD_;
     static constexpr int KS = C / 32, CF = C / 16, HID = 4 * C, NCH = HID / 32, NPB = C / 32, BM = NWAVES * FM * 16;
     static constexpr int SLOT_KIB = KS * 2;          // KiB of a projection block [ks][n] = of an fc1 chunk [ks][n] = of an fc2 chunk [c]
-    static constexpr int SLOT = SLOT_KIB * 1024, NSLOT = 4;
-    static constexpr int PPW = 2 * SLOT_KIB / NWAVES;   // DMA pieces per wave and interval (one W1 chunk + one W2 chunk)
+    static constexpr int SLOT = SLOT_KIB * 1024, NSLOT = DUO_ ? 2 : 5;
+    static constexpr int PSLOT0 = DUO_ ? 0 : 3;      // the projection's blocks alternate between slots PSLOT0 and PSLOT0 + 1
     static constexpr int T_PB = 0, T_G1 = C, T_E1 = 2 * C, T_B1 = 3 * C, T_B2 = 3 * C + HID, T_G2 = T_B2 + C, T_E2 = T_G2 + C;
     static constexpr int TAB = T_E2 + C;
     static constexpr int SMEM = NSLOT * SLOT + TAB * 4;
-    static_assert((2 * SLOT_KIB) % NWAVES == 0 && NPB % 2 == 0 && NCH >= 3 && PPW <= KS, "DMA pieces per wave; even projection block count");
-    static_assert(SMEM <= 160 * 1024, "LDS");
+    static_assert((2 * SLOT_KIB) % NWAVES == 0 && NPB % 2 == 0 && NCH >= 3 && !(SKEW_ && DUO_), "DMA pieces per wave; even projection block count");
+    static_assert(SMEM <= (DUO_ ? 80 : 160) * 1024, "LDS");
 };
 
 template <class T>
@@ -69,9 +61,15 @@ __device__ __forceinline__ void sk_ld2(const char* p, uint4 (&w)[2]) {
 }
 
 // NP fragment pairs at consecutive KiB of `st`, through a ring of RD register pairs read RD - 1 pairs ahead of their MFMAs
-template <int NP, int RD, class Body>
+template <int NP, int RD, bool ONE = false, class Body>
 __device__ __forceinline__ void sk_stream(const char* st, Body&& body) {
     uint4 ring[RD][2];
+    if constexpr (ONE) {                         // probe: one pair read, every step computes on it
+        sk_ld2(st, ring[0]);
+#pragma unroll
+        for (int p = 0; p < NP; ++p) { body(p, ring[0][0], ring[0][1]); __builtin_amdgcn_sched_barrier(0); }
+        return;
+    }
 #pragma unroll
     for (int p = 0; p < RD - 1 && p < NP; ++p) sk_ld2(st + (p << 11), ring[p % RD]);
 #pragma unroll
@@ -87,7 +85,6 @@ __global__ void __launch_bounds__(S::THREADS) __attribute__((amdgpu_waves_per_eu
 proj_mlp2_kernel(const Block2Args<T> a) {
     constexpr int C = S::C, FM = S::FM, KS = S::KS, CF = S::CF, NCH = S::NCH, NPB = S::NPB, NWAVES = S::NWAVES, RD = S::RD;
     constexpr bool P_GELU = S::PROBE & 1, P_LDS = S::PROBE & 2, P_DMA = S::PROBE & 4, P_BAR = S::PROBE & 8, P_IO = S::PROBE & 16;
-    static_assert(CF / 2 == KS && (KS % 2) == 0, "fc1 and fc2 chunks hold the same, even number of fragment pairs (two-deep ring)");
     typedef typename OpT<T>::v8 v8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* tab = reinterpret_cast<float*>(smem + S::NSLOT * S::SLOT);
@@ -95,27 +92,32 @@ proj_mlp2_kernel(const Block2Args<T> a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const unsigned lds_base = (unsigned)(size_t)smem;
     const char* lrd = smem + lane * 16;                          // a lane's 16 bytes of every fragment
+    const bool lead = !S::SKEW || wave < 4;
 
-    // SLOT_KIB consecutive KiB of `src` -> LDS `dst`, piece q by wave q % 8 (wave-uniform base in SGPRs + the lane's 16-byte offset)
-    const unsigned voff = lane * 16;
+    // SLOT_KIB consecutive KiB of `src` -> LDS `dst`, piece q by wave q % NWAVES
     auto dma1 = [&](const T* src, unsigned dst) {
+        const T* s = src + lane * 8;
 #pragma unroll
         for (int i = 0; i < (S::SLOT_KIB + NWAVES - 1) / NWAVES; ++i) {
             const int q = wave + i * NWAVES;
-            if (q < S::SLOT_KIB) glds16_s(src + (q << 9), voff, dst + (unsigned)(q << 10));
+            if (q < S::SLOT_KIB) glds16(s + (q << 9), dst + (unsigned)(q << 10));
         }
     };
-    // piece i (0 .. PPW-1) of this wave's share of the requests of interval j: W1(j + 1) -> slot (j + 1) & 1, W2(j) -> slot 2 + (j & 1)
-    auto dma_piece = [&](int j, int i) {
-        const int q = wave + i * NWAVES;
-        const bool first = (S::SLOT_KIB % NWAVES == 0) ? (i < S::SLOT_KIB / NWAVES) : (q < S::SLOT_KIB);
-        const int jj = first ? j + 1 : j, r = first ? q : q - S::SLOT_KIB;
-        if (jj >= NCH) return;
-        const T* src = (first ? a.w1h : a.w2h) + (((long long)jj * S::SLOT_KIB + r) << 9);
-        glds16_s(src, voff, lds_base + (unsigned)(((first ? 0 : 2) + (jj & 1)) * S::SLOT + (r << 10)));
+    // the weights of chunk j: W1(j) -> slot j & 1, W2(j) -> slot 2 + j % 3 (m3 = j % 3); 2 SLOT_KIB pieces over the 8 waves
+    auto dma_chunk = [&](int j, int m3) {
+        const T* s1 = a.w1h + ((long long)j * S::SLOT_KIB << 9) + lane * 8;
+        const T* s2 = a.w2h + ((long long)j * S::SLOT_KIB << 9) + lane * 8;
+        const unsigned d1 = lds_base + (unsigned)((j & 1) * S::SLOT), d2 = lds_base + (unsigned)((2 + m3) * S::SLOT);
+#pragma unroll
+        for (int i = 0; i < 2 * S::SLOT_KIB / NWAVES; ++i) {
+            const int q = wave + i * NWAVES;
+            if (q < S::SLOT_KIB) glds16(s1 + (q << 9), d1 + (unsigned)(q << 10));
+            else glds16(s2 + ((q - S::SLOT_KIB) << 9), d2 + (unsigned)((q - S::SLOT_KIB) << 10));
+        }
     };
-    dma1(a.projh, lds_base + 2 * S::SLOT);
-    dma1(a.w1h, lds_base);
+    dma1(a.projh, lds_base + S::PSLOT0 * S::SLOT);
+    if constexpr (!S::DUO) dma_chunk(0, 0);
+
     for (int i = tid; i < C; i += S::THREADS) {
         tab[S::T_PB + i] = a.proj_b[i]; tab[S::T_G1 + i] = a.g1[i]; tab[S::T_E1 + i] = a.e1[i];
         tab[S::T_B2 + i] = a.b2[i]; tab[S::T_G2 + i] = a.g2[i]; tab[S::T_E2 + i] = a.e2[i];
@@ -150,13 +152,14 @@ proj_mlp2_kernel(const Block2Args<T> a) {
 #pragma unroll
         for (int c = 0; c < CF; ++c) yacc[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // ---- phase 1: projection, blocks of 32 output columns alternating between slots 2 and 3 ------------------------------------- //
+    // ---- phase 1: projection, blocks of 32 output columns alternating between two slots (no VALU phase: lock-step is harmless here) -- //
 #pragma unroll
     for (int j = 0; j < NPB; ++j) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                               // block j landed; every wave is done with block j - 1
-        if (j + 1 < NPB) dma1(a.projh + ((long long)(j + 1) * S::SLOT_KIB << 9), lds_base + (unsigned)((2 + ((j + 1) & 1)) * S::SLOT));
-        sk_stream<KS, RD>(lrd + (2 + (j & 1)) * S::SLOT, [&](int ks, const uint4& w0, const uint4& w1) {
+        if (j + 1 < NPB) dma1(a.projh + ((long long)(j + 1) * S::SLOT_KIB << 9), lds_base + (unsigned)((S::PSLOT0 + ((j + 1) & 1)) * S::SLOT));
+        else if constexpr (S::DUO) dma1(a.w1h, lds_base);      // NPB is even: the last block sits in slot 1, slot 0 is free for fc1's chunk 0
+        sk_stream<KS, RD>(lrd + (S::PSLOT0 + (j & 1)) * S::SLOT, [&](int ks, const uint4& w0, const uint4& w1) {
 #pragma unroll
             for (int t = 0; t < FM; ++t) yacc[t][2 * j] = OpT<T>::mfma(as_v8<T>(w0), xl[t][ks], yacc[t][2 * j]);
 #pragma unroll
@@ -219,162 +222,100 @@ proj_mlp2_kernel(const Block2Args<T> a) {
         for (int c = 0; c < CF; ++c) yacc[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 
-    // ---- phase 2: the MLP, software-pipelined: interval j = [fc1(j) + GELU(j - 1)] [fc2(j - 1) + DMA requests], one barrier ---------- //
-    f32x4 hacc[FM][2], hprev[FM][2];
+    // ---- phase 2: the MLP ------------------------------------------------------------------------------------------------------------ //
+    f32x4 hacc[FM][2];
     uint4 hh[FM], hl[FM];
-    f32x2 vt[FM][4];
-    float4 bb0, bb1;
-    // bias + GELU + hi / lo split of the previous chunk in 18 FM small work items (5-10 VALU instructions each), so that every fc1 step
-    // gets its share: per fragment t and value pair k four stages of gelu_erf2e (common.h: the Estrin form of the erfc fit), then the split
-    // into fc2's operand registers in two halves (the lane's 8 hidden units 16 n + 4 g + r are k-slots 8 g + 4 n + r of fc2)
-    constexpr int NITEMS = 18 * FM;
-    f32x2 gx, ga, g0, g1, g2, g3, g4;                    // the pair in flight
-    // An item's arithmetic depends on nothing the MFMAs of its step produce, and hipcc's instruction selection is free to emit it at
-    // the top of the loop body (it does: all of the GELU in front of the first MFMA).  The empty volatile asm on an item's input keeps
-    // its place among the scheduling barriers, and everything that depends on its output stays behind it.
-    auto item = [&](int i) {
-        const int t = i / 18, r = i % 18;
-        if (r < 16) {
-            const int k = r >> 2, st = r & 3;
-            if (st == 0) {
-                asm volatile("" : "+v"(hprev[t][k >> 1]));
-                const f32x4& h = hprev[t][k >> 1];
-                const float b0 = (k & 2) ? ((k & 1) ? bb1.z : bb1.x) : ((k & 1) ? bb0.z : bb0.x), b1 = (k & 2) ? ((k & 1) ? bb1.w : bb1.y) : ((k & 1) ? bb0.w : bb0.y);
-                gx = f32x2{h[2 * (k & 1)] + b0, h[2 * (k & 1) + 1] + b1};
-                if constexpr (P_GELU) return;
-                ga.x = __builtin_amdgcn_fmed3f(__builtin_fabsf(gx.x), 0.f, 5.9396970f);
-                ga.y = __builtin_amdgcn_fmed3f(__builtin_fabsf(gx.y), 0.f, 5.9396970f);
-                g0 = ga * ga;
-                g1 = __builtin_elementwise_fma(ga, (f32x2)(-4.591012597e-01f), (f32x2)(-1.151117682e+00f));
-                g2 = __builtin_elementwise_fma(ga, (f32x2)(7.545167115e-03f), (f32x2)(-5.282834917e-02f));
-            } else if (st == 1) {
-                if constexpr (P_GELU) return;
-                asm volatile("" : "+v"(ga));
-                g3 = __builtin_elementwise_fma(ga, (f32x2)(-4.273382365e-05f), (f32x2)(-4.982745158e-04f));
-                g4 = __builtin_elementwise_fma(ga, (f32x2)(-6.177511978e-07f), (f32x2)(1.091520153e-05f));
-                g1 = __builtin_elementwise_fma(g0, g2, g1);
-                g3 = __builtin_elementwise_fma(g0, g4, g3);
-                g0 = g0 * g0;
-            } else if (st == 2) {
-                if constexpr (P_GELU) return;
-                asm volatile("" : "+v"(g0));
-                g1 = __builtin_elementwise_fma(g0, g3, g1) * ga;
-                g2.x = __builtin_amdgcn_exp2f(g1.x);
-                g2.y = __builtin_amdgcn_exp2f(g1.y);
-            } else {
-                if constexpr (P_GELU) { vt[t][k] = gx; return; }
-                asm volatile("" : "+v"(g2));
-                f32x2 e;
-                e.x = __builtin_copysignf(1.0f - g2.x, gx.x);
-                e.y = __builtin_copysignf(1.0f - g2.y, gx.y);
-                vt[t][k] = ((f32x2)(0.5f) * gx) * ((f32x2)(1.0f) + e);
-            }
-            return;
-        }
-        asm volatile("" : "+v"(vt[t][r == 16 ? 0 : 3]));
-        const float v[8] = {vt[t][0].x, vt[t][0].y, vt[t][1].x, vt[t][1].y, vt[t][2].x, vt[t][2].y, vt[t][3].x, vt[t][3].y};
-        if (r == 16) {
-            uint4 o[1];
-            split8<T, 1>(v, o);
-            hh[t] = o[0];
-        } else {
-            const v8 h = as_v8<T>(hh[t]);
-            T l[8];
+    auto fc1 = [&](int slot) {                          // W1 chunk in `slot` -> hacc
 #pragma unroll
-            for (int e = 0; e < 8; ++e) l[e] = (T)(v[e] - (float)h[e]);
-            hl[t] = __builtin_bit_cast(uint4, *reinterpret_cast<v8*>(l));
+        for (int t = 0; t < FM; ++t) { hacc[t][0] = f32x4{0.f, 0.f, 0.f, 0.f}; hacc[t][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        sk_stream<KS, RD, P_LDS>(lrd + slot * S::SLOT, [&](int ks, const uint4& w0, const uint4& w1) {
+#pragma unroll
+            for (int t = 0; t < FM; ++t) hacc[t][0] = OpT<T>::mfma(as_v8<T>(w0), xl[t][ks], hacc[t][0]);
+#pragma unroll
+            for (int t = 0; t < FM; ++t) hacc[t][1] = OpT<T>::mfma(as_v8<T>(w1), xl[t][ks], hacc[t][1]);
+#pragma unroll
+            for (int t = 0; t < FM; ++t) hacc[t][0] = OpT<T>::mfma(as_v8<T>(w0), xh[t][ks], hacc[t][0]);
+#pragma unroll
+            for (int t = 0; t < FM; ++t) hacc[t][1] = OpT<T>::mfma(as_v8<T>(w1), xh[t][ks], hacc[t][1]);
+        });
+    };
+    // bias + GELU + hi/lo split of chunk j: the lane's 8 hidden units 16 n + 4 g + r become k-slots 8 g + 4 n + r of fc2
+    auto gelu = [&](int j) {
+        const float4 bb0 = *reinterpret_cast<const float4*>(tab + S::T_B1 + j * 32 + 4 * g), bb1 = *reinterpret_cast<const float4*>(tab + S::T_B1 + j * 32 + 16 + 4 * g);
+#pragma unroll
+        for (int t = 0; t < FM; ++t) {
+            auto act = [](f32x2 v) { if constexpr (P_GELU) return v; else return gelu_erf2(v); };
+            const f32x2 a0 = act(f32x2{hacc[t][0][0] + bb0.x, hacc[t][0][1] + bb0.y}), a1 = act(f32x2{hacc[t][0][2] + bb0.z, hacc[t][0][3] + bb0.w});
+            const f32x2 a2 = act(f32x2{hacc[t][1][0] + bb1.x, hacc[t][1][1] + bb1.y}), a3 = act(f32x2{hacc[t][1][2] + bb1.z, hacc[t][1][3] + bb1.w});
+            const float v[8] = {a0.x, a0.y, a1.x, a1.y, a2.x, a2.y, a3.x, a3.y};
+            uint4 o[2];
+            split8<T, 2>(v, o);
+            hh[t] = o[0]; hl[t] = o[1];
         }
     };
-    auto fc1_step = [&](int ks, const uint4& w0, const uint4& w1) {
-        if (ks == 0) {
+    auto fc2 = [&](int slot) {                          // W2 chunk in `slot`, operand hh / hl -> yacc
+        sk_stream<CF / 2, RD, P_LDS>(lrd + slot * S::SLOT, [&](int p, const uint4& w0, const uint4& w1) {
 #pragma unroll
-            for (int t = 0; t < FM; ++t) { hacc[t][0] = f32x4{0.f, 0.f, 0.f, 0.f}; hacc[t][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-        }
+            for (int t = 0; t < FM; ++t) yacc[t][2 * p] = OpT<T>::mfma(as_v8<T>(w0), as_v8<T>(hl[t]), yacc[t][2 * p]);
 #pragma unroll
-        for (int t = 0; t < FM; ++t) hacc[t][0] = OpT<T>::mfma(as_v8<T>(w0), xl[t][ks], hacc[t][0]);
+            for (int t = 0; t < FM; ++t) yacc[t][2 * p + 1] = OpT<T>::mfma(as_v8<T>(w1), as_v8<T>(hl[t]), yacc[t][2 * p + 1]);
 #pragma unroll
-        for (int t = 0; t < FM; ++t) hacc[t][1] = OpT<T>::mfma(as_v8<T>(w1), xl[t][ks], hacc[t][1]);
+            for (int t = 0; t < FM; ++t) yacc[t][2 * p] = OpT<T>::mfma(as_v8<T>(w0), as_v8<T>(hh[t]), yacc[t][2 * p]);
 #pragma unroll
-        for (int t = 0; t < FM; ++t) hacc[t][0] = OpT<T>::mfma(as_v8<T>(w0), xh[t][ks], hacc[t][0]);
-#pragma unroll
-        for (int t = 0; t < FM; ++t) hacc[t][1] = OpT<T>::mfma(as_v8<T>(w1), xh[t][ks], hacc[t][1]);
+            for (int t = 0; t < FM; ++t) yacc[t][2 * p + 1] = OpT<T>::mfma(as_v8<T>(w1), as_v8<T>(hh[t]), yacc[t][2 * p + 1]);
+        });
     };
-    auto fc2_step = [&](int p, const uint4& w0, const uint4& w1) {
-#pragma unroll
-        for (int t = 0; t < FM; ++t) yacc[t][2 * p] = OpT<T>::mfma(as_v8<T>(w0), as_v8<T>(hl[t]), yacc[t][2 * p]);
-#pragma unroll
-        for (int t = 0; t < FM; ++t) yacc[t][2 * p + 1] = OpT<T>::mfma(as_v8<T>(w1), as_v8<T>(hl[t]), yacc[t][2 * p + 1]);
-#pragma unroll
-        for (int t = 0; t < FM; ++t) yacc[t][2 * p] = OpT<T>::mfma(as_v8<T>(w0), as_v8<T>(hh[t]), yacc[t][2 * p]);
-#pragma unroll
-        for (int t = 0; t < FM; ++t) yacc[t][2 * p + 1] = OpT<T>::mfma(as_v8<T>(w1), as_v8<T>(hh[t]), yacc[t][2 * p + 1]);
-    };
-    auto top = [&]() {
+    // 8-wave form, top of interval j: chunk j's weights landed (requested one interval ago), every wave is done with interval j - 1;
+    // request chunk j + 1 into the slots of W1(j - 1) and W2(j - 2)
+    auto top = [&](int j, int m3n) {
         if constexpr (!P_BAR) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
         }
-    };
-    auto load_bias = [&](int j) {
-        bb0 = *reinterpret_cast<const float4*>(tab + S::T_B1 + j * 32 + 4 * g);
-        bb1 = *reinterpret_cast<const float4*>(tab + S::T_B1 + j * 32 + 16 + 4 * g);
-    };
-    auto roll = [&]() {
-#pragma unroll
-        for (int t = 0; t < FM; ++t) { hprev[t][0] = hacc[t][0]; hprev[t][1] = hacc[t][1]; }
-    };
-    auto ld2 = [&](const char* p, uint4 (&w)[2]) {      // two consecutive fragments, NOT pinned: the group pipeline below places them
-        w[0] = *reinterpret_cast<const uint4*>(p);
-        w[1] = *reinterpret_cast<const uint4*>(p + 1024);
+        if constexpr (!P_DMA) { if (j + 1 < NCH) dma_chunk(j + 1, m3n); }
     };
 
-    // interval 0: fc1(0) alone; W1(1) and W2(0) requested between its MFMAs
-    top();                                              // W1(0) landed; every wave is done with the projection's last block
-    sk_stream<KS, RD>(lrd, [&](int ks, const uint4& w0, const uint4& w1) {
-        fc1_step(ks, w0, w1);
-        if constexpr (!P_DMA) { if (ks < S::PPW) dma_piece(0, ks); }
-    });
-    roll();
-    for (int j = 1; j < NCH; ++j) {
-        top();                                          // W1(j), W2(j - 1) landed; every wave is done with interval j - 1
-        load_bias(j - 1);
-        __builtin_amdgcn_sched_barrier(0);
-        const char* stA = lrd + (j & 1) * S::SLOT;
-        const char* stB = lrd + (2 + ((j - 1) & 1)) * S::SLOT;
-        uint4 ring[2][2];
-        // phase A: fc1(j), fragment pairs read one pair ahead of their MFMAs (pinned), and behind the MFMAs of every step its share of the
-        // GELU of chunk j - 1 (one MFMA, NV VALU, one MFMA, ...)
-        sk_ld2(stA, ring[0]);
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            if constexpr (!P_LDS) { if (ks + 1 < KS) sk_ld2(stA + ((ks + 1) << 11), ring[(ks + 1) & 1]); else sk_ld2(stB, ring[(ks + 1) & 1]); }
-            fc1_step(ks, ring[P_LDS ? 0 : ks & 1][0], ring[P_LDS ? 0 : ks & 1][1]);
-#pragma unroll
-            for (int i = 0; i < NITEMS; ++i)
-                if ((i * KS) / NITEMS == ks) item(i);
-            if constexpr (S::NV > 0) {
-#pragma unroll
-                for (int k = 0; k < 4 * FM; ++k) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, S::NV, 0); }
+    if constexpr (S::DUO) {
+        for (int j = 0; j < NCH; ++j) {
+            if constexpr (!P_BAR) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();                           // W1(j) landed in slot 0; every wave is done with W2(j - 1) / the projection in slot 1
             }
-            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (!P_DMA) dma1(a.w2h + ((long long)j * S::SLOT_KIB << 9), lds_base + S::SLOT);
+            fc1(0);
+            gelu(j);
+            if constexpr (!P_BAR) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();                           // W2(j) landed; every wave is done with W1(j)
+            }
+            if constexpr (!P_DMA) { if (j + 1 < NCH) dma1(a.w1h + ((long long)(j + 1) * S::SLOT_KIB << 9), lds_base); }
+            fc2(1);
         }
-        // phase B: fc2(j - 1) on the operand the GELU has just produced; the ring keeps running (its first pair was read under fc1's last
-        // MFMAs); the LDS-DMA requests of W1(j + 1) and W2(j) ride behind the first steps
-        if constexpr (P_LDS) { ld2(stB, ring[0]); __builtin_amdgcn_sched_barrier(0); }
-#pragma unroll
-        for (int p = 0; p < KS; ++p) {
-            if constexpr (!P_LDS) { if (p + 1 < KS) sk_ld2(stB + ((p + 1) << 11), ring[(KS + p + 1) & 1]); }
-            fc2_step(p, ring[P_LDS ? 0 : (KS + p) & 1][0], ring[P_LDS ? 0 : (KS + p) & 1][1]);
-            if constexpr (!P_DMA) { if (p < S::PPW) dma_piece(j, p); }
-            __builtin_amdgcn_sched_barrier(0);
+    } else if (lead) {
+        int m3 = 0;                                     // j % 3
+        for (int j = 0; j < NCH; ++j) {
+            const int m3n = m3 == 2 ? 0 : m3 + 1;
+            top(j, m3n);
+            fc1(j & 1);
+            gelu(j);
+            fc2(2 + m3);
+            m3 = m3n;
         }
-        roll();
+    } else {
+        top(0, 1);
+        fc1(0);
+        int m3 = 0;                                     // (j - 1) % 3
+        for (int j = 1; j < NCH; ++j) {
+            const int m3j = m3 == 2 ? 0 : m3 + 1, m3n = m3j == 2 ? 0 : m3j + 1;
+            top(j, m3n);
+            gelu(j - 1);
+            fc2(2 + m3);
+            fc1(j & 1);
+            m3 = m3j;
+        }
+        gelu(NCH - 1);
+        fc2(2 + m3);
     }
-    top();                                              // W2(NCH - 1) landed
-    load_bias(NCH - 1);
-#pragma unroll
-    for (int i = 0; i < NITEMS; ++i) item(i);
-    sk_stream<KS, RD>(lrd + (2 + ((NCH - 1) & 1)) * S::SLOT, fc2_step);
 
     // ---- epilogue: + fc2 bias, LayerNorm(norm2), + x_mid (registers), whole blocks of the stream ------------------------------------ //
 #pragma unroll
@@ -430,7 +371,8 @@ static hipError_t launch_blk2(const Block2Args<T>& a, hipStream_t s) {
     return hipGetLastError();
 }
 
-// SKP_BLK2_VARIANT (measurement only): 0 default | 1 no forced splice (NV = 0) | 2 NV = 2 | 3 NV = 6 | 4 ring depth 3 | 10.. timing probes (C = 384)
+// SKP_BLK2_VARIANT (measurement only): 0 default (two 4-wave workgroups per CU) | 1 one 8-wave workgroup, one barrier per chunk | 2 ... with the
+// halves of the workgroup half a chunk apart | 10.. timing probes of variant 1 (C = 384)
 hipError_t op_proj_mlp_skew(const Geom& g, const BlockW<f16>& b, const int* winv, int res, f16* Xs, const Work<PrecF16x3>& wk, hipStream_t s) {
     typedef f16 T;
     Block2Args<T> a{wk.ao, wk.ao_plane, g.ntok[res], Xs, wk.xs_plane[res], winv, b.projh, b.w1h, b.w2h,
@@ -439,26 +381,22 @@ hipError_t op_proj_mlp_skew(const Geom& g, const BlockW<f16>& b, const int* winv
     static const int variant = [] { const char* v = getenv("SKP_BLK2_VARIANT"); return v ? atoi(v) : 0; }();
     if (res == 0) {
         switch (variant) {
-            case 1: return launch_blk2<T, Blk2Shape<192, 2, 2, 0>>(a, s);
-            case 2: return launch_blk2<T, Blk2Shape<192, 2, 2, 2>>(a, s);
-            case 3: return launch_blk2<T, Blk2Shape<192, 2, 2, 6>>(a, s);
-            case 4: return launch_blk2<T, Blk2Shape<192, 2, 3, 4>>(a, s);
-            default: return launch_blk2<T, Blk2Shape<192, 2, 2, 4>>(a, s);
+            case 1: return launch_blk2<T, Blk2Shape<192, 2, 2, false, false>>(a, s);
+            case 2: return launch_blk2<T, Blk2Shape<192, 2, 2, true, false>>(a, s);
+            default: return launch_blk2<T, Blk2Shape<192, 2, 2, false, true>>(a, s);
         }
     }
     switch (variant) {
-        case 1: return launch_blk2<T, Blk2Shape<384, 1, 2, 0>>(a, s);
-        case 2: return launch_blk2<T, Blk2Shape<384, 1, 2, 2>>(a, s);
-        case 3: return launch_blk2<T, Blk2Shape<384, 1, 2, 6>>(a, s);
-        case 4: return launch_blk2<T, Blk2Shape<384, 1, 3, 4>>(a, s);
-        case 10: return launch_blk2<T, Blk2Shape<384, 1, 2, 4, 1>>(a, s);
-        case 11: return launch_blk2<T, Blk2Shape<384, 1, 2, 4, 2>>(a, s);
-        case 12: return launch_blk2<T, Blk2Shape<384, 1, 2, 4, 4>>(a, s);
-        case 13: return launch_blk2<T, Blk2Shape<384, 1, 2, 4, 8>>(a, s);
-        case 14: return launch_blk2<T, Blk2Shape<384, 1, 2, 4, 16>>(a, s);
-        case 15: return launch_blk2<T, Blk2Shape<384, 1, 2, 4, 15>>(a, s);
-        case 16: return launch_blk2<T, Blk2Shape<384, 1, 2, 4, 31>>(a, s);
-        default: return launch_blk2<T, Blk2Shape<384, 1, 2, 4>>(a, s);
+        case 1: return launch_blk2<T, Blk2Shape<384, 1, 2, false, false>>(a, s);
+        case 2: return launch_blk2<T, Blk2Shape<384, 1, 2, true, false>>(a, s);
+        case 10: return launch_blk2<T, Blk2Shape<384, 1, 2, false, false, 1>>(a, s);
+        case 11: return launch_blk2<T, Blk2Shape<384, 1, 2, false, false, 2>>(a, s);
+        case 12: return launch_blk2<T, Blk2Shape<384, 1, 2, false, false, 4>>(a, s);
+        case 13: return launch_blk2<T, Blk2Shape<384, 1, 2, false, false, 8>>(a, s);
+        case 14: return launch_blk2<T, Blk2Shape<384, 1, 2, false, false, 16>>(a, s);
+        case 15: return launch_blk2<T, Blk2Shape<384, 1, 2, false, false, 15>>(a, s);
+        case 16: return launch_blk2<T, Blk2Shape<384, 1, 2, false, false, 31>>(a, s);
+        default: return launch_blk2<T, Blk2Shape<384, 1, 2, false, true>>(a, s);
     }
 }
 

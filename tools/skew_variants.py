@@ -17,7 +17,7 @@ def child(prec):
     from skyrim_amd.pangu.engine import PanguEngine
     from skyrim_amd.pangu.spec import PanguGeometry, init_synthetic, synthetic_state
     out = {"precision": prec, "variant": os.environ.get("SKP_BLK2_VARIANT", "-") + ":" + os.environ.get("SKP_DUO_STAGGER", "")}
-    if os.environ.get("SKEW_TOY", "1") == "1" and int(os.environ.get("SKP_BLK2_VARIANT", "0")) < 10:
+    if os.environ.get("SKEW_TOY", "1") == "1" and not (10 <= int(os.environ.get("SKP_BLK2_VARIANT", "0")) % 100 < 20):
         g = PanguGeometry(49, 192)
         p, x = init_synthetic(g, 0), synthetic_state(g, 0)
         e = PanguEngine(g, prec)
