@@ -63,8 +63,9 @@ typedef struct skpangu_config {
     int term_plan; /* per-layer MFMA term plan of the fp16-plane modes (F16X3, F16X3_Q) with mlp_mode 0.  Bit l (l = 0..3) set: the blocks of
                       layer l + 1 run proj / fc1 / fc2 with TWO terms, A_hi W_hi + A_lo W_hi -- the weights as ONE fp16 plane, the
                       activations still hi/lo pairs (a third fewer MFMAs, half the LDS and LDS-DMA bytes; 2^-12 relative weight rounding:
-                      ~5e-4 per-channel error per step with all four bits set against ~1e-4 with none).  0: three terms everywhere.
-                      The host default is F16X3_Q with term_plan 0xF ("f16x2"). */
+                      ~5e-4 per-channel error per step with all four bits set against ~1e-4 with none).  Bit 4 + l (F16X3_Q only): the
+                      layer's QKV linear runs with ONE term, stream hi plane x weight hi plane.  0: three terms everywhere (QKV two).
+                      Host modes: "f16x2" = F16X3_Q with term_plan 0x0F, "f16x2q" = 0xFF. */
 } skpangu_config;
 
 typedef struct skpangu_sizes {

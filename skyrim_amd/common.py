@@ -21,7 +21,9 @@ from pathlib import Path
 from typing import Callable, Literal
 from urllib.parse import urlparse
 
-AVAILABLE_MODELS = ["pangu", "fourcastnet", "fourcastnet_v2", "graphcast", "dlwp"]
+# the models the CLI offers = the models this build registers (core/models/__init__.py MODELS); the reference's list
+# (common.py:18) also names fourcastnet and dlwp, which are not on the north-star path and would only fail later in Skyrim.__init__
+AVAILABLE_MODELS = ["pangu", "fourcastnet_v2", "graphcast"]
 LOCAL_CACHE = os.path.join(os.path.expanduser("~"), ".cache", "skyrim")
 OUTPUT_DIR = str(Path.cwd() / "outputs")
 

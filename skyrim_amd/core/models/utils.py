@@ -2,6 +2,7 @@
 driving a TimeLoop and labelling its output."""
 from __future__ import annotations
 
+import os
 from datetime import datetime
 from typing import Any
 
@@ -20,8 +21,8 @@ def run_basic_inference(model, n: int, data_source: Any, time: datetime, x=None)
     if x is None:
         x = get_initial_condition_for_model(model, data_source, time)     # comes with the batch dimension
     else:
-        if isinstance(x, str):
-            x = open_dataarray(x)
+        if isinstance(x, (str, os.PathLike)):
+            x = open_dataarray(os.fspath(x))
         x = torch.as_tensor(np.asarray(x.values[-model.n_history_levels:]), dtype=torch.float32).to(model.device)
         x = x.unsqueeze(0)
 
@@ -29,7 +30,8 @@ def run_basic_inference(model, n: int, data_source: Any, time: datetime, x=None)
     # step through pageable memory, the sync point of its loop.  Here the n + 1 states land in ONE pinned host buffer
     # through a copy stream, so the D2H of step k overlaps the forward of step k + 1; the result is the same array.
     times, stacked, arrays, side = [], None, [], None
-    for k, (time, output, _) in enumerate(model(time, x)):
+    loop = model(time, x)
+    for k, (time, output, _) in enumerate(loop):
         out = output.squeeze(0) if output.dim() == 4 and output.shape[0] == 1 else output
         if out.is_cuda:
             if stacked is None:
@@ -45,6 +47,8 @@ def run_basic_inference(model, n: int, data_source: Any, time: datetime, x=None)
         times.append(time)
         if k == n:
             break
+    if hasattr(loop, "close"):
+        loop.close()            # lets the TimeLoop flush its deferred checks (FiniteGuard: the last yielded state) -- may raise
     if stacked is not None:
         side.synchronize()
         stacked = stacked[:len(times)].numpy()

@@ -28,7 +28,7 @@ bool make_geom(const skpangu_config& c, Geom& g) {
     if (c.roll_sign < -1 || c.roll_sign > 1 || (c.pad_mode != SKPANGU_PAD_CENTRE && c.pad_mode != SKPANGU_PAD_BACK)) return false;
     if (c.mask_value > 0.f || c.mask_value < -60000.f) return false;      // the mask lives in the fp16 bias tiles
     if (c.mlp_mode != 0 && c.mlp_mode != 1) return false;
-    if (c.term_plan < 0 || c.term_plan > 0xF) return false;
+    if (c.term_plan < 0 || c.term_plan > 0xFF) return false;
     g.roll_sign = c.roll_sign > 0 ? 1 : -1;
     g.mask_value = c.mask_value == 0.f ? -100.f : c.mask_value;
     g.n_lat = c.n_lat; g.n_lon = c.n_lon; g.n_levels = 13; g.n_channels = 69; g.surf0 = 65;
@@ -128,8 +128,10 @@ struct Engine : IEngine {
     bool fused_mlp = false;   // one-kernel MLP (fused_mlp.hip): 3-term modes with the hidden as hi/lo pair
     bool rt_proj = false, rt_qkv = false;   // row-tile proj / QKV kernels (rowtile.hip)
     bool fused_block = false;               // proj + LayerNorm + residual + MLP as one kernel (fused_block.hip)
+    bool attn2 = true;                      // attention with the bias gathered from the compact table in LDS (SKP_ATTN_V1=1: the expanded table)
     int plan2 = 0;                          // bit l: layer l + 1 runs proj / fc1 / fc2 with TWO terms (weights as one fp16 plane, fused_block2.hip)
     bool two_term(int layer) const { return (plan2 >> layer) & 1; }
+    bool qkv_one(int layer) const { return rt_qkv && ((plan2 >> (4 + layer)) & 1); }   // QKV with ONE term (stream hi plane x weight hi plane)
     T* zrow = nullptr;
 
     // ---- per-stage timing with HIP events on the launch stream (bench.py roofline leg) ---- //
@@ -179,7 +181,7 @@ struct Engine : IEngine {
             const int o = r == 0 ? 0 : 5;
             fl[C_QKV0 + o] = 2 * mw * C * 3 * C;      by[C_QKV0 + o] = nt * C * 2 * NA_ + 3 * mw * C * 2 + 3 * C * C * wb;
             fl[C_ATTN0 + o] = g.nwin[r] * heads * 4.0 * 144 * 144 * 32;
-            by[C_ATTN0 + o] = 3 * mw * C * 2 + mw * C * sa + (double)g.types[r] * heads * 81 * 256 * 2;
+            by[C_ATTN0 + o] = 3 * mw * C * 2 + mw * C * sa + (double)g.types[r] * heads * (attn2 ? 3456 : 81 * 256) * 2;
             fl[C_PROJ0 + o] = 2 * mw * C * C;          by[C_PROJ0 + o] = mw * C * sa + 2 * nt * C * 4 + C * C * wb;   // stream: 4 B/elem read + 4 B/elem written
             fl[C_FC1_0 + o] = 2 * nt * C * 4 * C;      by[C_FC1_0 + o] = nt * C * 2 * NA_ + nt * 4 * C * sa + 4 * C * C * wb;
             fl[C_FC2_0 + o] = 2 * nt * C * 4 * C;      by[C_FC2_0 + o] = nt * 4 * C * sa + 2 * nt * C * 4 + 4 * C * C * wb;
@@ -236,13 +238,15 @@ struct Engine : IEngine {
                 bw.projh = t2 ? a.take<T>((size_t)c * c) : nullptr;                       // hi plane only
                 bw.w1h = t2 ? a.take<T>((size_t)4 * c * c) : nullptr;
                 bw.w2h = t2 ? a.take<T>((size_t)4 * c * c) : nullptr;
-                bw.qkvf = rt_qkv ? a.take<T>((size_t)6 * c * c) : nullptr;
+                bw.qkvf = rt_qkv && !qkv_one(layer) ? a.take<T>((size_t)6 * c * c) : nullptr;
+                bw.qkvh = qkv_one(layer) ? a.take<T>((size_t)3 * c * c) : nullptr;
                 bw.qkv_b = a.take<float>(3 * c); bw.proj_b = a.take<float>(c);
                 bw.fc1_b = a.take<float>(4 * c); bw.fc2_b = a.take<float>(c);
                 bw.n1_g = a.take<float>(c); bw.n1_b = a.take<float>(c);
                 bw.n2_g = a.take<float>(c); bw.n2_b = a.take<float>(c);
-                bias_exp_elems[b] = (size_t)g.types[res] * heads * 81 * 256;
-                bw.bias_exp = a.take<f16>(bias_exp_elems[b]);
+                bias_exp_elems[b] = attn2 ? (size_t)g.types[res] * heads * 3456 : (size_t)g.types[res] * heads * 81 * 256;
+                bw.bias_exp = attn2 ? nullptr : a.take<f16>(bias_exp_elems[b]);
+                bw.bias_cmp = attn2 ? a.take<f16>(bias_exp_elems[b]) : nullptr;
             }
         }
         w.down_g = a.take<float>(768); w.down_b = a.take<float>(768);
@@ -280,6 +284,7 @@ struct Engine : IEngine {
     }
 
     explicit Engine(const Geom& geom, int hid16_ = 0, int qkv_a1 = 0, int mlp_mode = 0, int term_plan = 0) : g(geom), hid16(hid16_) {
+        attn2 = getenv("SKP_ATTN_V1") == nullptr;
         fused_mlp = (P::NA == 2 && P::NW == 2 && !hid16_ && mlp_mode == 0);
         // proj in row-tile form measures the same as the tiled GEMM (0.199 vs 0.197 ms at C = 384, 0.264 vs 0.264 at C = 192: with 16 rows
         // per wave its LDS reads run at 2/3 of the LDS rate): kept behind SKP_RT_PROJ=1, the tiled LayerNorm GEMM stays the default
@@ -337,7 +342,8 @@ struct Engine : IEngine {
                 if (hid16 && !std::is_same<T, f16>::value) CK((prep_weight<f16, 2>(P_(m, p + "mlp.fc2.weight"), const_cast<f16*>(bw.fc2h.w), bw.fc2h.plane, c, 4 * c, 4 * c, 4 * c, 1, 1, 1, s)));
                 if constexpr (P::NA == 2 && P::NW == 2) {
                     if (bw.projf) CK(prep_rowtile_weights<T>(P_(m, p + "attn.proj.weight"), const_cast<T*>(bw.projf), c, c, s));
-                    if (rt_qkv) CK(prep_rowtile_weights<T>(P_(m, p + "attn.qkv.weight"), const_cast<T*>(bw.qkvf), 3 * c, c, s));
+                    if (bw.qkvf) CK(prep_rowtile_weights<T>(P_(m, p + "attn.qkv.weight"), const_cast<T*>(bw.qkvf), 3 * c, c, s));
+                    if (bw.qkvh) CK(prep_rowtile_weights<T>(P_(m, p + "attn.qkv.weight"), const_cast<T*>(bw.qkvh), 3 * c, c, s, 1));
                     if (bw.w1f) CK(prep_mlp_weights<T>(P_(m, p + "mlp.fc1.weight"), P_(m, p + "mlp.fc2.weight"), const_cast<T*>(bw.w1f), const_cast<T*>(bw.w2f), c, s));
                     if (bw.projh) {
                         CK(prep_rowtile_weights<T>(P_(m, p + "attn.proj.weight"), const_cast<T*>(bw.projh), c, c, s, 1));
@@ -352,7 +358,8 @@ struct Engine : IEngine {
                 CK(copyf(bw.n1_b, P_(m, p + "norm1.bias"), c, s));
                 CK(copyf(bw.n2_g, P_(m, p + "norm2.weight"), c, s));
                 CK(copyf(bw.n2_b, P_(m, p + "norm2.bias"), c, s));
-                CK(prep_bias_expand(P_(m, p + "attn.bias_table"), const_cast<f16*>(bw.bias_exp), g.types[res], heads, g.nH[res], (i & 1) ? g.roll_sign : 0, g.mask_value, s));
+                if (attn2) CK(prep_bias_compact(P_(m, p + "attn.bias_table"), const_cast<f16*>(bw.bias_cmp), g.types[res], heads, g.nH[res], (i & 1) ? g.roll_sign : 0, g.mask_value, s));
+                else CK(prep_bias_expand(P_(m, p + "attn.bias_table"), const_cast<f16*>(bw.bias_exp), g.types[res], heads, g.nH[res], (i & 1) ? g.roll_sign : 0, g.mask_value, s));
             }
         }
         CK(copyf(w.down_g, P_(m, "down.norm.weight"), 768, s));
@@ -397,7 +404,7 @@ struct Engine : IEngine {
             CK((op_qkv<P>(g, bw, widx, res, xs, wk, s)));
         }
         mark(C_ATTN0 + o, s);
-        AttnArgs<P> a{wk.q, wk.k, wk.vt, wk.qkv_plane, bw.bias_exp, wk.ao, wk.ao_plane, C, g.nwin[res], g.nW[res], heads};
+        AttnArgs<P> a{wk.q, wk.k, wk.vt, wk.qkv_plane, bw.bias_exp, bw.bias_cmp, wk.ao, wk.ao_plane, C, g.nwin[res], g.nW[res], heads};
         CK(launch_attention<P>(a, s));
         if constexpr (std::is_same<P, PrecF16x3>::value) {
             if (two_term(layer0)) {               // ... with two MFMA terms and the halves of the workgroup half a chunk apart
@@ -508,7 +515,7 @@ struct Engine : IEngine {
         if (n.rfind("bias_exp", 0) == 0) {
             const int b = atoi(n.c_str() + 8);
             if (b < 0 || b > 15) return false;
-            return set(w.blk[b].bias_exp, bias_exp_elems[b] * sizeof(f16));
+            return set(attn2 ? w.blk[b].bias_cmp : w.blk[b].bias_exp, bias_exp_elems[b] * sizeof(f16));
         }
         return false;
     }

@@ -30,6 +30,46 @@ __device__ __forceinline__ int attn_key(int f, int row) {
     return f < 8 ? 32 * (f >> 1) + 8 * (row >> 2) + 4 * (f & 1) + (row & 3) : 128 + row;
 }
 
+// Softmax over the 144 keys of a query block + P V, on scores that already carry bias and mask.  The kernels are bound by VALU issue,
+// not by bytes (PMC: 31 % issuing, 56 % issue-stalled, matrix pipes 11 % busy), so the VALU work per score is what counts:
+//   * v_exp_f32 directly (__builtin_amdgcn_exp2f): exp2f() wraps it in a denormal-range rescue (compare, two selects, add, ldexp: six
+//     instructions per value); an argument below -126 is a softmax weight below 1e-38 and flushes to zero either way;
+//   * the row sum comes out of the matrix pipe: one more V^T "fragment" of ones gives every lane the sum over ALL keys of its query --
+//     five MFMAs on an idle pipe instead of 36 adds and two shuffles, and it sums the fp16-rounded P that multiplies V;
+//   * 1 / sum by v_rcp_f32 (1 ulp; the division expands to a ten-instruction sequence).
+__device__ __forceinline__ void attn_softmax_pv(f32x4 (&s)[9], const uint4 (&vf)[2][5], f32x4 (&o)[2], f32x4& osum) {
+    typedef f16 T;
+    const float LOG2E = 1.4426950408889634f;
+    float mx = s[0][0];
+#pragma unroll
+    for (int f = 0; f < 9; ++f)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[f][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float mxl = mx * LOG2E;
+#pragma unroll
+    for (int f = 0; f < 9; ++f)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s[f][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[f][r], LOG2E, -mxl));
+    o[0] = f32x4{0.f, 0.f, 0.f, 0.f}; o[1] = f32x4{0.f, 0.f, 0.f, 0.f}; osum = f32x4{0.f, 0.f, 0.f, 0.f};
+    const uint4 ones = make_uint4(0x3C003C00u, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u);      // 8 x fp16 1.0
+#pragma unroll
+    for (int kb = 0; kb < 5; ++kb) {
+        float pv[8];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            pv[r] = s[2 * kb][r];
+            pv[4 + r] = (kb < 4) ? s[(2 * kb + 1) % 9][r] : 0.f;
+        }
+        uint4 pf[1];
+        split8<T, 1>(pv, pf);
+#pragma unroll
+        for (int df = 0; df < 2; ++df) o[df] = OpT<T>::mfma(as_v8<T>(vf[df][kb]), as_v8<T>(pf[0]), o[df]);
+        osum = OpT<T>::mfma(as_v8<T>(ones), as_v8<T>(pf[0]), osum);
+    }
+}
+
 // Q, K, V and the softmax output P are single fp16 planes in EVERY precision mode: attention is the least
 // rounding-sensitive part of the network (measured on the oracle: fp16 q/k/v -> 7e-5, fp16 P -> 4e-5 per-channel
 // error, vs 3.3e-4 / 3.6e-4 for the attention output / MLP hidden, which therefore stay hi/lo split), so
@@ -76,7 +116,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
                 else { const uint2 lo = *reinterpret_cast<const uint2*>(s + 128 + g * 4); vf[p][df][kb] = make_uint4(lo.x, lo.y, 0, 0); }
             }
 
-    const float LOG2E = 1.4426950408889634f;
     // software prefetch: Q fragment and the 9 bias/mask fragments of query block qf+1 are in flight while block qf
     // computes (one exposed L2/HBM round trip per window instead of nine)
     uint4 qn[NPL];
@@ -104,73 +143,24 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
             bn8 = *reinterpret_cast<const uint2*>(bp + (qf + 1) * 2304 + 2048 + lane * 4);
         }
 
+        // the bias / mask tile is the accumulator the score MFMA starts from (one conversion per value, no add)
         f32x4 s[9];
-#pragma unroll
-        for (int f = 0; f < 9; ++f) {
-            f32x4 a = {0.f, 0.f, 0.f, 0.f};
-            if constexpr (NPL == 2) {
-                a = OpT<T>::mfma(as_v8<T>(kf[1][f]), as_v8<T>(qv[0]), a);
-                a = OpT<T>::mfma(as_v8<T>(kf[0][f]), as_v8<T>(qv[1]), a);
-            }
-            a = OpT<T>::mfma(as_v8<T>(kf[0][f]), as_v8<T>(qv[0]), a);
-            s[f] = a;
-        }
-        float mx = -3.0e38f;
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
             const typename OpT<f16>::v8 b = as_v8<f16>(bcur[kb]);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                s[2 * kb][r] += (float)b[r];
-                s[2 * kb + 1][r] += (float)b[4 + r];
-                mx = fmaxf(mx, fmaxf(s[2 * kb][r], s[2 * kb + 1][r]));
-            }
+            s[2 * kb] = f32x4{(float)b[0], (float)b[1], (float)b[2], (float)b[3]};
+            s[2 * kb + 1] = f32x4{(float)b[4], (float)b[5], (float)b[6], (float)b[7]};
         }
         {
             typedef f16 h4 __attribute__((ext_vector_type(4)));
             const h4 b = __builtin_bit_cast(h4, bcur8);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                s[8][r] += (float)b[r];
-                mx = fmaxf(mx, s[8][r]);
-            }
+            s[8] = f32x4{(float)b[0], (float)b[1], (float)b[2], (float)b[3]};
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 16));
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        float sum = 0.f;
-        const float mxl = mx * LOG2E;
 #pragma unroll
-        for (int f = 0; f < 9; ++f)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float e = exp2f(s[f][r] * LOG2E - mxl);
-                s[f][r] = e;
-                sum += e;
-            }
-        sum += __shfl_xor(sum, 16);
-        sum += __shfl_xor(sum, 32);
-        const float inv = 1.0f / sum;
-
-        f32x4 o[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-        for (int kb = 0; kb < 5; ++kb) {
-            float pv[8];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                pv[r] = s[2 * kb][r];
-                pv[4 + r] = (kb < 4) ? s[(2 * kb + 1) % 9][r] : 0.f;
-            }
-            uint4 pf[NPL];
-            split8<T, NPL>(pv, pf);
-#pragma unroll
-            for (int df = 0; df < 2; ++df) {
-                if constexpr (NPL == 2) {
-                    o[df] = OpT<T>::mfma(as_v8<T>(vf[1][df][kb]), as_v8<T>(pf[0]), o[df]);
-                    o[df] = OpT<T>::mfma(as_v8<T>(vf[0][df][kb]), as_v8<T>(pf[1]), o[df]);
-                }
-                o[df] = OpT<T>::mfma(as_v8<T>(vf[0][df][kb]), as_v8<T>(pf[0]), o[df]);
-            }
-        }
+        for (int f = 0; f < 9; ++f) s[f] = OpT<T>::mfma(as_v8<T>(kf[0][f]), as_v8<T>(qv[0]), s[f]);
+        f32x4 o[2], osum;
+        attn_softmax_pv(s, vf[0], o, osum);
+        const float inv = __builtin_amdgcn_rcpf(osum[0]);
         // blocked [row/16][col/32][16][32] layout: this head's 32 columns are exactly one column block
         TO* orow = out + blk_off((long long)win * WIN_TOKENS + qf * 16 + l15, head * HEAD_DIM, ld_out) + g * 8;
         const float y[8] = {o[0][0] * inv, o[0][1] * inv, o[0][2] * inv, o[0][3] * inv, o[1][0] * inv, o[1][1] * inv, o[1][2] * inv, o[1][3] * inv};
@@ -178,9 +168,109 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------------- //
+//  The same attention with the earth-specific bias GATHERED from its compact table ("bias gathered from the compact
+//  (3312, type, head) table in-kernel"): the expanded tiles above are 41 KB of the 86 KB a wave moves, and the kernel is bound by the
+//  CU's memory pipeline.  One workgroup = one (window type, head); its four waves walk the type's nW longitude windows, which all
+//  share ONE bias.  The workgroup stages that bias in LDS once, from the prepared [144][24] fp16 form (prep_bias_compact: row =
+//  (z_q + 2 z_k) 36 + (h_q + 6 h_k), column = w_k - w_q + 11, shifted-window mask folded into the rows): a lane's four consecutive keys
+//  are then four consecutive fp16 of one row -- one ds_read_b64, IF the address is 8-byte aligned, which depends on w_q mod 4 only:
+//  the table is stored four times, copy c shifted by c entries, and a lane reads copy (w_q + 1) mod 4 (32 KB of LDS, 81 reads per
+//  window and lane).  Per window a wave now moves 27 KB of Q / K / V and 18 KB of output.
+constexpr int BT_ROW = 28, BT_COPY = 144 * BT_ROW;      // fp16 entries per table row / per shifted copy
+
+template <class TO, int NPL_O>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) earth_attention2_kernel(const f16* __restrict__ q, const f16* __restrict__ k,
+                                                              const f16* __restrict__ vt, const f16* __restrict__ bias_cmp, TO* __restrict__ out,
+                                                              long long out_plane, int ld_out, int nW, int heads) {
+    typedef f16 T;
+    __shared__ __attribute__((aligned(16))) f16 tabs[4 * BT_COPY];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int th = blockIdx.x;
+    const int head = th % heads, type = th / heads;
+    const int l15 = lane & 15, g = lane >> 4;
+    {
+        const f16* src = bias_cmp + (long long)th * 3456;
+        for (int i = threadIdx.x; i < 3456; i += 256) {
+            const int r = i / 24, e = i - 24 * r;
+            const f16 v = src[i];
+            if (e < 23) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) tabs[c * BT_COPY + r * BT_ROW + e + c] = v;
+            }
+        }
+    }
+    // byte offset of a lane's key group (4 consecutive keys k0 ..): rows of (z_k, h_k), column w_k0
+    int koff[9];
+#pragma unroll
+    for (int f = 0; f < 9; ++f) {
+        const int k0 = f < 8 ? 32 * (f >> 1) + 8 * g + 4 * (f & 1) : 128 + 4 * g;
+        const int zk = k0 / 72, hk = (k0 / 12) % 6, wk0 = k0 % 12;
+        koff[f] = 2 * ((2 * zk * 36 + 6 * hk) * BT_ROW + wk0);
+    }
+    __syncthreads();
+    const char* tb = reinterpret_cast<const char*>(tabs);
+
+    for (int wi = wave; wi < nW; wi += 4) {
+        const int win = type * nW + wi;
+        const long long base = (long long)win * heads + head;
+        const T* qp = q + base * (WIN_TOKENS * HEAD_DIM) + l15 * HEAD_DIM + g * 8;
+        const T* kp = k + base * (WIN_TOKENS * HEAD_DIM) + g * 8;
+        const T* vp = vt + base * (WIN_TOKENS * HEAD_DIM) + (8 * (l15 >> 2) + (l15 & 3)) * WIN_TOKENS;      // + 4 df rows
+
+        uint4 kf[9];
+#pragma unroll
+        for (int f = 0; f < 9; ++f) kf[f] = *reinterpret_cast<const uint4*>(kp + attn_key(f, l15) * HEAD_DIM);
+        uint4 vf[2][5];
+#pragma unroll
+        for (int df = 0; df < 2; ++df)
+#pragma unroll
+            for (int kb = 0; kb < 5; ++kb) {
+                const T* s = vp + df * 4 * WIN_TOKENS;
+                if (kb < 4) vf[df][kb] = *reinterpret_cast<const uint4*>(s + kb * 32 + g * 8);
+                else { const uint2 lo = *reinterpret_cast<const uint2*>(s + 128 + g * 4); vf[df][kb] = make_uint4(lo.x, lo.y, 0, 0); }
+            }
+        uint4 qn = *reinterpret_cast<const uint4*>(qp);
+#pragma unroll 1
+        for (int qf = 0; qf < 9; ++qf) {
+            const uint4 qv = qn;
+            if (qf < 8) qn = *reinterpret_cast<const uint4*>(qp + (qf + 1) * 16 * HEAD_DIM);
+            // the lane's query: q = 16 qf + l15 -> (z_q, h_q, w_q); copy c = (w_q + 1) mod 4 makes every group address a multiple of 8 bytes
+            const int qi = 16 * qf + l15;
+            const int zq = qi >= 72 ? 1 : 0, hq = (qi - 72 * zq) / 12, wq = qi - 72 * zq - 12 * hq;
+            const int c = (wq + 1) & 3;
+            const char* bq = tb + 2 * (c * BT_COPY + (zq * 36 + hq) * BT_ROW + (11 - wq) + c);
+            uint2 bias[9];
+#pragma unroll
+            for (int f = 0; f < 9; ++f) bias[f] = *reinterpret_cast<const uint2*>(bq + koff[f]);
+
+            f32x4 s[9];
+#pragma unroll
+            for (int f = 0; f < 9; ++f) {
+                typedef f16 h4 __attribute__((ext_vector_type(4)));
+                const h4 b = __builtin_bit_cast(h4, bias[f]);
+                s[f] = OpT<T>::mfma(as_v8<T>(kf[f]), as_v8<T>(qv), f32x4{(float)b[0], (float)b[1], (float)b[2], (float)b[3]});
+            }
+            f32x4 o[2], osum;
+            attn_softmax_pv(s, vf, o, osum);
+            const float inv = __builtin_amdgcn_rcpf(osum[0]);
+            TO* orow = out + blk_off((long long)win * WIN_TOKENS + qf * 16 + l15, head * HEAD_DIM, ld_out) + g * 8;
+            const float y[8] = {o[0][0] * inv, o[0][1] * inv, o[0][2] * inv, o[0][3] * inv, o[1][0] * inv, o[1][1] * inv, o[1][2] * inv, o[1][3] * inv};
+            store8_planes<TO, NPL_O>(orow, out_plane, y);
+        }
+    }
+}
+
 template <class P>
 hipError_t launch_attention(const AttnArgs<P>& a, hipStream_t stream) {
     constexpr int NPL_O = (P::NA > P::NW ? P::NA : P::NW);
+    if (a.bias_cmp) {
+        const int types = a.n_win / a.nW;
+        hipLaunchKernelGGL((earth_attention2_kernel<typename P::T, NPL_O>), dim3((unsigned)(types * a.heads)), dim3(256), 0, stream,
+                           a.q, a.k, a.vt, a.bias_cmp, a.out, a.out_plane, a.ld_out, a.nW, a.heads);
+        return hipGetLastError();
+    }
     const long long waves = (long long)a.n_win * a.heads;
     const unsigned blocks = (unsigned)((waves + 3) / 4);
     hipLaunchKernelGGL((earth_attention_kernel<typename P::T, NPL_O>), dim3(blocks), dim3(256), 0, stream,

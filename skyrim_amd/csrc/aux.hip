@@ -75,6 +75,38 @@ hipError_t prep_bias_expand(const float* table, f16* out, int types, int heads, 
     return hipGetLastError();
 }
 
+// The same table in the COMPACT form the second attention kernel gathers from (attention.hip, earth_attention2_kernel): per (type, head)
+// 144 rows r = (z_q + 2 z_k) 36 + (h_q + 6 h_k) of 24 fp16, column e = 22 - (w_q - w_k + 11) = w_k - w_q + 11 (reversed, so that
+// four consecutive keys w_k .. w_k + 3 of one query are four consecutive ASCENDING entries), column 23 zero.  The shifted-window
+// mask depends on (type, z_q, z_k, h_q, h_k) only -- exactly a row -- and is folded into the row.  6.9 KB per (type, head) where the
+// expanded form takes 41 KB.
+__global__ void prep_bias_compact_kernel(const float* __restrict__ table, f16* __restrict__ out, int types, int heads, int nH, int roll, float mask_value) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = (long long)types * heads * 3456;
+    if (i >= total) return;
+    const int e = (int)(i % 24), r = (int)((i / 24) % 144);
+    const long long th = i / 3456;
+    const int head = (int)(th % heads), type = (int)(th / heads);
+    if (e == 23) { out[i] = (f16)0.f; return; }
+    const int rz = r / 36, rh = r % 36;
+    const int zq = rz & 1, zk = rz >> 1, hq = rh % 6, hk = rh / 6;
+    float v = table[((long long)(r * 23 + (22 - e)) * types + type) * heads + head];
+    if (roll) {
+        const int zi = type / nH, hi = type % nH;
+        const int nZ = types / nH;
+        const bool mz = (zi == (roll < 0 ? nZ - 1 : 0)) && (zq != zk);
+        const bool mh = (hi == (roll < 0 ? nH - 1 : 0)) && ((hq < 3) != (hk < 3));
+        if (mz || mh) v += mask_value;
+    }
+    out[i] = (f16)v;
+}
+
+hipError_t prep_bias_compact(const float* table, f16* out, int types, int heads, int nH, int roll, float mask_value, hipStream_t s) {
+    const long long total = (long long)types * heads * 3456;
+    hipLaunchKernelGGL(prep_bias_compact_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, table, out, types, heads, nH, roll, mask_value);
+    return hipGetLastError();
+}
+
 // Window gather table: row m = win*144 + t of the (padded, rolled, window-partitioned) token grid
 // -> source token row, or -1 for latitude padding.  win = (zi*nH + hi)*nW + wi, t = (tz*6 + th)*12 + tw.
 __global__ void prep_window_index_kernel(int* __restrict__ idx, int Z, int H, int W, int Hp, int top, int roll) {

@@ -26,8 +26,10 @@ struct BlockW {
     const T *w1f, *w2f;      // fc1 / fc2 in the fused MLP's fragment order (fused_mlp.hip), or null
     const T *projf, *qkvf;   // proj / qkv in the row-tile kernels' fragment order (rowtile.hip), or null
     const T *projh, *w1h, *w2h;   // proj / fc1 / fc2 in fragment order, HI PLANE ONLY: the two-term block kernel (fused_block2.hip), or null
+    const T* qkvh;                // qkv in fragment order, hi plane only: the one-term QKV of the term plan, or null
     const float *qkv_b, *proj_b, *fc1_b, *fc2_b, *n1_g, *n1_b, *n2_g, *n2_b;
-    const f16* bias_exp;     // [types][heads][9][9][64][4] (+ shifted-window mask on odd blocks)
+    const f16* bias_exp;     // [types][heads][9][9][64][4] (+ shifted-window mask on odd blocks): the first attention kernel; or null
+    const f16* bias_cmp;     // [types][heads][144][24] compact, w reversed (+ mask): the second attention kernel; or null
 };
 
 template <class T>
@@ -66,6 +68,7 @@ struct AttnArgs {
     const f16 *q, *k, *vt;
     long long plane;
     const f16* bias_exp;
+    const f16* bias_cmp;     // non-null: earth_attention2_kernel (bias gathered from the compact table staged in LDS)
     typename P::T* out;
     long long out_plane;
     int ld_out, n_win, nW, heads;
@@ -106,6 +109,7 @@ template <class T> hipError_t merge_planes(const T* planes, long long plane, flo
 template <class T, int NW>
 hipError_t prep_weight(const float* src, T* dst, long long plane, int N, int K, int ldd, long long sn, long long sk, int blocked, int perm, hipStream_t);
 hipError_t prep_bias_expand(const float* table, f16* out, int types, int heads, int nH, int roll, float mask_value, hipStream_t);   // roll: 0 | -1 | +1
+hipError_t prep_bias_compact(const float* table, f16* out, int types, int heads, int nH, int roll, float mask_value, hipStream_t);
 hipError_t prep_window_index(int* idx, int Z, int H, int W, int Hp, int top, int roll, hipStream_t);
 hipError_t prep_window_inverse(const int* idx, int n, int* inv, hipStream_t);
 hipError_t prep_reciprocal(const float* src, float* dst, int n, hipStream_t);

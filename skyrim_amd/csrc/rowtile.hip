@@ -181,13 +181,14 @@ rt_proj_kernel(const ProjArgs<T> a) {
 // ------------------------------------------------------------------------------------------------------------------------------- //
 //  QKV linear + head split (2 MFMA terms: hi plane of the stream x hi/lo weights)
 // ------------------------------------------------------------------------------------------------------------------------------- //
-template <int C_, int FM_, int NWAVES_>
+template <int C_, int FM_, int NWAVES_, int NW_ = 2>
 struct QkvShape {
     static constexpr int C = C_, FM = FM_, NWAVES = NWAVES_, THREADS = 64 * NWAVES_;
+    static constexpr int NW = NW_;             // weight planes: 2 = hi / lo (2 MFMA terms), 1 = hi only (ONE term: the term plan's QKV bit)
     static constexpr int KS = C / 32, HEADS = C / 32, BM = NWAVES * FM * 16;
-    static constexpr int W_BLK = KS * 2 * 2, STAGE = W_BLK * 1024;
+    static constexpr int W_BLK = KS * 2 * NW, STAGE = W_BLK * 1024;
     static constexpr int SMEM = 2 * STAGE + C * 4;
-    static_assert(W_BLK % NWAVES == 0 && FM % 2 == 0, "DMA blocks per wave; fragment pairs");
+    static_assert(FM % 2 == 0, "fragment pairs");
 };
 
 struct QkvArgs {
@@ -213,9 +214,9 @@ __device__ __forceinline__ void rt_qkv_body(const QkvArgs& a, char* smem) {
         const f16* src = a.wf + ((long long)(which * HEADS + j) * S::W_BLK << 9) + lane * 8;
         const unsigned dst = lds_base + (unsigned)((j & 1) * S::STAGE);
 #pragma unroll
-        for (int i = 0; i < S::W_BLK / NWAVES; ++i) {
+        for (int i = 0; i < (S::W_BLK + NWAVES - 1) / NWAVES; ++i) {
             const int b = wave + i * NWAVES;
-            glds16(src + (b << 9), dst + (unsigned)(b << 10));
+            if (b < S::W_BLK) glds16(src + (b << 9), dst + (unsigned)(b << 10));
         }
     };
     issue(0);
@@ -251,6 +252,28 @@ __device__ __forceinline__ void rt_qkv_body(const QkvArgs& a, char* smem) {
 #pragma unroll
         for (int t = 0; t < FM; ++t) { acc[t][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[t][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
         uint4 ring[DEPTH][2];
+        if constexpr (S::NW == 1) {
+            // one weight plane: a ring step is the fragment PAIR (ks, n = 0 / 1) = two consecutive KiB, one MFMA term each
+#pragma unroll
+            for (int s = 0; s < DEPTH - 1 && s < KS; ++s) rt_ld_pair(st + ((s * 2) << 10) + lane * 16, ring[s % DEPTH]);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                if (ks + DEPTH - 1 < KS) rt_ld_pair(st + (((ks + DEPTH - 1) * 2) << 10) + lane * 16, ring[(ks + DEPTH - 1) % DEPTH]);
+                const f16x8 w0 = as_v8<f16>(ring[ks % DEPTH][0]), w1 = as_v8<f16>(ring[ks % DEPTH][1]);
+                if constexpr (!VPART) {
+#pragma unroll
+                    for (int t = 0; t < FM; ++t) acc[t][0] = OpT<f16>::mfma(w0, xh[t][ks], acc[t][0]);
+#pragma unroll
+                    for (int t = 0; t < FM; ++t) acc[t][1] = OpT<f16>::mfma(w1, xh[t][ks], acc[t][1]);
+                } else {
+#pragma unroll
+                    for (int t = 0; t < FM; ++t) acc[t][0] = OpT<f16>::mfma(xh[t][ks], w0, acc[t][0]);
+#pragma unroll
+                    for (int t = 0; t < FM; ++t) acc[t][1] = OpT<f16>::mfma(xh[t][ks], w1, acc[t][1]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
 #pragma unroll
         for (int s = 0; s < DEPTH - 1 && s < NS; ++s) rt_ld_pair(st + ((s * 2) << 10) + lane * 16, ring[s % DEPTH]);
 #pragma unroll
@@ -270,6 +293,7 @@ __device__ __forceinline__ void rt_qkv_body(const QkvArgs& a, char* smem) {
                 for (int t = 0; t < FM; ++t) acc[t][n] = OpT<f16>::mfma(xh[t][ks], wh, acc[t][n]);
             }
             __builtin_amdgcn_sched_barrier(0);
+        }
         }
         if constexpr (!VPART) {
             // prepared rows 16 n + 4 g + r of the block are output columns 8 g + 4 n + r (perm8): 8 consecutive d of head j
@@ -378,9 +402,13 @@ static hipError_t launch_qkv(const QkvArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
-// fp16 planes, QKV from the hi plane only (the default mode's 2-term QKV)
+// fp16 planes, QKV from the hi plane only: 2 terms against hi / lo weights (b.qkvf), or ONE term against the hi plane (b.qkvh)
 hipError_t op_qkv_rowtile(const Geom& g, const BlockW<f16>& b, const int* widx, int res, const f16* Xs, const Work<PrecF16x3>& wk, hipStream_t s) {
-    QkvArgs a{Xs, widx, g.mwin[res], b.qkvf, b.qkv_b, wk.q, wk.k, wk.vt, wk.zrow, 0.17677669529663687f};
+    QkvArgs a{Xs, widx, g.mwin[res], b.qkvh ? b.qkvh : b.qkvf, b.qkv_b, wk.q, wk.k, wk.vt, wk.zrow, 0.17677669529663687f};
+    if (b.qkvh) {
+        if (res == 0) return launch_qkv<QkvShape<192, 2, 8, 1>>(a, s);
+        return launch_qkv<QkvShape<384, 2, 8, 1>>(a, s);
+    }
     if (res == 0) return launch_qkv<QkvShape<192, 2, 8>>(a, s);
     return launch_qkv<QkvShape<384, 2, 8>>(a, s);
 }

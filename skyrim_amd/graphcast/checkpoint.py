@@ -88,7 +88,16 @@ def convert(params: dict, cfg: GraphcastConfig, mean, std, diff_std, static, in_
     return out
 
 
+def normalise_key(k: str) -> str:
+    """deepmind's ``checkpoint.dump`` flattens the nested haiku dict with ':' between the levels -- ``params:<module path>:<name>``
+    (e.g. ``params:mesh_gnn/~_networks_builder/encoder_edges_mesh_mlp/~/linear_0:w``) -- while a plain ``hk.data_structures`` flattening
+    joins module and parameter with '/'.  Both forms are accepted: the leading ``params:`` goes, the LAST ':' becomes '/'."""
+    k = k.replace("params:", "", 1)
+    head, sep, tail = k.rpartition(":")
+    return f"{head}/{tail}" if sep else k
+
+
 def load(npz_path, cfg: GraphcastConfig, **kw) -> dict:
     z = np.load(npz_path, allow_pickle=False)
-    params = {k.replace("params:", "", 1): z[k] for k in z.files if not k.startswith(("model_config", "task_config", "description", "license"))}
+    params = {normalise_key(k): z[k] for k in z.files if not k.startswith(("model_config", "task_config", "description", "license"))}
     return convert(params, cfg, **kw)

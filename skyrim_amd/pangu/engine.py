@@ -23,13 +23,14 @@ PREC_F16X3 = 3
 PREC_F16X3_Q = 4
 PREC_F16X3_QH = 5
 PRECISIONS = {"bf16x3": PREC_BF16X3, "f16": PREC_F16, "bf16x3h": PREC_BF16X3_H16,
-              "f16x3": PREC_F16X3, "f16x3q": PREC_F16X3_Q, "f16x3qh": PREC_F16X3_QH, "f16x2": PREC_F16X3_Q}
+              "f16x3": PREC_F16X3, "f16x3q": PREC_F16X3_Q, "f16x3qh": PREC_F16X3_QH, "f16x2": PREC_F16X3_Q, "f16x2q": PREC_F16X3_Q}
 # per-layer MFMA term plan (skpangu_config.term_plan): bit l = layer l + 1 runs proj / fc1 / fc2 with two terms (weights as ONE fp16 plane)
-TERM_PLANS = {"f16x2": 0xF}
-# default "f16x2": fp16 hi/lo ACTIVATION planes, weights as one fp16 plane in proj / fc1 / fc2 (2 MFMA terms), QKV 2 terms (stream hi plane x
-# weight hi/lo), attention single-term fp16; ~5e-4 per-channel error per step (bar 1e-3).  "f16x3q" is the same with 3 terms in proj / fc1 /
-# fc2 (~1e-4); "bf16x3" is the wide-range alternative (activations beyond fp16's 65504).
-DEFAULT_PRECISION = "f16x2"
+TERM_PLANS = {"f16x2": 0x0F, "f16x2q": 0xFF}       # bits 4-7: the layer's QKV with ONE term (stream hi plane x weight hi plane)
+# default "f16x2q": fp16 hi/lo ACTIVATION planes, every block weight as ONE fp16 plane -- proj / fc1 / fc2 with 2 MFMA terms (A_hi W + A_lo W),
+# QKV with one (stream hi plane x weight hi plane) -- attention single-term fp16; ~5e-4 per-channel error per step (bar 1e-3).  "f16x2" keeps the
+# QKV weights as hi/lo planes (2 terms, same error level: the weight rounding of the other three linears dominates), "f16x3q" is 3 terms in
+# proj / fc1 / fc2 (~1e-4); "bf16x3" is the wide-range alternative (activations beyond fp16's 65504).
+DEFAULT_PRECISION = "f16x2q"
 
 _LIB_PATH = Path(__file__).resolve().parent.parent / "lib" / "libskyrim_pangu.so"
 
@@ -116,7 +117,7 @@ def make_config(geom: PanguGeometry, precision: str = DEFAULT_PRECISION, roll_si
     if roll_sign not in (-1, 1):
         raise ValueError("roll_sign is -1 (Swin: roll by -(1,3,6) first) or +1 (pseudocode as written)")
     plan = TERM_PLANS.get(precision, 0) if term_plan is None else int(term_plan)
-    if plan and (precision not in ("f16x2", "f16x3", "f16x3q") or mlp != "fused"):
+    if plan and (precision not in ("f16x2", "f16x2q", "f16x3", "f16x3q") or mlp != "fused"):
         raise ValueError("a term plan needs fp16 planes (f16x2 / f16x3 / f16x3q) and the fused kernels")
     return SkConfig(geom.n_lat, geom.n_lon, PRECISIONS[precision], roll_sign, PAD_MODES[geom.pad], float(mask_value), MLP_MODES[mlp], plan)
 
@@ -157,7 +158,7 @@ class PanguEngine:
         self.geom = geom or PanguGeometry()
         self.precision = precision
         self.device = torch.device(device)
-        if mlp != "fused" and precision == "f16x2" and term_plan is None:
+        if mlp != "fused" and precision in ("f16x2", "f16x2q") and term_plan is None:
             term_plan = 0                                   # the tiled-GEMM path has no two-term kernels: "f16x2" + split = f16x3q + split
         self.cfg = make_config(self.geom, precision, roll_sign, mask_value, mlp, term_plan)
         self.mlp = mlp

@@ -92,12 +92,17 @@ class PanguTimeLoop:
         state24, k = state, 0
         guard = weights.FiniteGuard(f"precision {self.engine.precision!r} keeps activations as fp16 planes (|x| < 65504); "
                                     "use PanguModel(precision='bf16x3') for the wide-range mode")
-        while True:
-            k += 1
-            if self.engine24 is not None and k % 4 == 0:
-                state = state24 = self.engine24.step(state24)      # 24-h step from the state 24 h earlier
-            else:
-                state = self.engine.step(state)                    # new buffer each step: the caller keeps the yielded one
-            time = time + self.time_step
-            guard.push(state, k)
-            yield time, state.unsqueeze(0), restart
+        try:
+            while True:
+                k += 1
+                if self.engine24 is not None and k % 4 == 0:
+                    state = state24 = self.engine24.step(state24)      # 24-h step from the state 24 h earlier
+                else:
+                    state = self.engine.step(state)                    # new buffer each step: the caller keeps the yielded one
+                time = time + self.time_step
+                guard.push(state, k)
+                yield time, state.unsqueeze(0), restart
+        finally:
+            # the consumer stopped (run_basic_inference breaks at k == n and closes the generator): the flag of the LAST yielded
+            # step is still pending -- with n = 1 (predict_one_step / rollout) it is the only one there ever is
+            guard.check()

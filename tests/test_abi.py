@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     assert lib.skpangu_abi_version() == 3
 
 
-@pytest.mark.parametrize("prec", ["bf16x3", "f16", "f16x3q", "f16x3qh"])
+@pytest.mark.parametrize("prec", ["bf16x3", "f16", "f16x3q", "f16x3qh", "f16x2", "f16x2q"])
 @pytest.mark.parametrize("grid", [(49, 192), (721, 1440)])
 def test_param_table_matches_host_spec(grid, prec):
     g = PanguGeometry(*grid)
@@ -44,6 +44,27 @@ def test_param_table_matches_host_spec(grid, prec):
 def test_sizes_full_grid_fit_one_gpu():
     s = E.query_sizes(PanguGeometry(721, 1440))
     assert s.prepared_bytes + s.workspace_bytes < 16 * 2 ** 30      # a few GB of the 288 GB
+
+
+def test_term_plan_sizes_and_validation():
+    """skpangu_config.term_plan (ABI v3): the two-term layers prepare ONE weight plane in fragment order, so the prepared arena shrinks
+    with every bit; the plan is refused outside the fp16-plane modes / fused kernels and beyond its 8 bits."""
+    g = PanguGeometry(721, 1440)
+    lib = E.load_library()
+    sizes = {}
+    for prec in ("f16x3q", "f16x2", "f16x2q"):
+        sizes[prec] = E.query_sizes(g, prec, E.make_config(g, prec)).prepared_bytes
+    assert sizes["f16x2q"] < sizes["f16x2"] < sizes["f16x3q"]
+    assert E.make_config(g, "f16x2").term_plan == 0x0F and E.make_config(g, "f16x2q").term_plan == 0xFF and E.make_config(g, "f16x3q").term_plan == 0
+    assert E.make_config(g, "f16x3q", term_plan=0x3).term_plan == 3
+    with pytest.raises(ValueError):
+        E.make_config(g, "bf16x3", term_plan=1)
+    with pytest.raises(ValueError):
+        E.make_config(g, "f16x2", mlp="split")
+    out = E.SkSizes()
+    bad = E.make_config(g, "f16x2")
+    bad.term_plan = 0x100
+    assert lib.skpangu_query_sizes(ctypes.byref(bad), ctypes.byref(out)) == -1
 
 
 def test_bad_arguments_are_errors_not_crashes():

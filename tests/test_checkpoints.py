@@ -61,3 +61,25 @@ def test_graphcast_haiku_params_round_trip():
         GC.convert({k: v for k, v in hk.items() if "processor_edges_1_mesh_layer_norm/scale" not in k}, cfg, **kw)
     with pytest.raises(ValueError, match="unplaced"):
         GC.convert(dict(hk, **{"mesh_gnn/~_networks_builder/surprise/w": np.zeros(3, np.float32)}), cfg, **kw)
+
+
+def test_graphcast_npz_file_in_the_colon_key_form_of_checkpoint_dump(tmp_path):
+    """``GC.load`` on a file keyed ``params:<module path>:<name>`` (the ':'-flattened form of deepmind's checkpoint.dump) and on the
+    '/'-joined form: both must reach the same slots (a loader that only strips 'params:' misses every key of the real file)."""
+    cfg = GraphcastConfig(n_lat=9, n_lon=16, splits=1, latent=16, steps=2, n_vars=5)
+    p = gc_init(cfg, 0)
+    hk = {}
+    for mlp in sorted({s.rsplit(".", 2)[0] for s, _ in gc_spec(cfg) if s.endswith(".fc1.weight")}):
+        for part, key in GC.haiku_keys(mlp).items():
+            slot = f"{mlp}.{part}"
+            if slot in p:
+                hk[key] = (p[slot].T if (part.endswith("weight") and p[slot].dim() == 2) else p[slot]).numpy()
+    hk[GC.haiku_keys("embed.mesh")["fc1.weight"]] = np.concatenate([np.zeros((cfg.grid_in - 3, cfg.latent), np.float32), p["embed.mesh.fc1.weight"].T.numpy()])
+    kw = dict(mean=p["norm.mean"], std=p["norm.std"], diff_std=p["norm.diff_std"], static=p["static"])
+    colon = {"params:" + ":".join(k.rsplit("/", 1)): v for k, v in hk.items()}
+    assert "params:mesh_gnn/~_networks_builder/processor_edges_1_mesh_mlp/~/linear_0:w" in colon
+    assert GC.normalise_key("params:a/~/linear_0:w") == "a/~/linear_0/w" and GC.normalise_key("a/~/linear_0/w") == "a/~/linear_0/w"
+    for name, keys in (("colon.npz", colon), ("slash.npz", {"params:" + k: v for k, v in hk.items()})):
+        np.savez(tmp_path / name, model_config=np.zeros(1), **keys)
+        got = GC.load(tmp_path / name, cfg, **kw)
+        assert set(got) == set(p) and all(torch.equal(got[k], p[k]) for k in p), name

@@ -265,6 +265,57 @@ def test_missing_weights_raise_unless_opted_in(monkeypatch):
         guard.push(torch.ones(3), 3)
 
 
+class OverflowingTimeLoop(BoringTimeLoop):
+    """A TimeLoop whose step ``bad_step`` produces an inf, guarded the way PanguTimeLoop guards its states (deferred flag)."""
+
+    def __init__(self, channels, bad_step):
+        super().__init__(channels)
+        self.bad_step = bad_step
+
+    def __call__(self, time, x, restart=None):
+        from skyrim_amd import weights
+        state = x[:, 0].clone()
+        yield time, state, restart
+        guard, k = weights.FiniteGuard("fp16 planes overflowed"), 0
+        try:
+            while True:
+                k += 1
+                state = state + (float("inf") if k == self.bad_step else 1.0)
+                time = time + self.time_step
+                guard.push(state, k)
+                yield time, state, restart
+        finally:
+            guard.check()
+
+
+def test_finite_guard_fires_through_predict_one_step_rollout_and_forecast():
+    """The deferred non-finite check must reach the LAST yielded state: run_basic_inference stops the generator at k == n, and with
+    n = 1 (predict_one_step, rollout) the last state is the only one."""
+    class M(BoringGlobalModel):
+        bad = 1
+
+        def build_model(self):
+            return OverflowingTimeLoop(self.channels, self.bad)
+
+    m = M(ic_source="synthetic")
+    with pytest.raises(FloatingPointError, match="after step 1: fp16 planes overflowed"):
+        m.predict_one_step(T0)
+    with pytest.raises(FloatingPointError, match="after step 1"):
+        m.rollout(T0, n_steps=2, save=False)
+    M.bad = 3
+    m3 = M(ic_source="synthetic")
+    assert m3.forecast(T0, n_steps=2).shape[0] == 3                 # steps 1, 2 are fine
+    with pytest.raises(FloatingPointError, match="after step 3"):
+        m3.forecast(T0, n_steps=3)                                  # the final state of forecast(n) is checked too
+
+
+def test_predict_one_step_accepts_a_pathlib_path(tmp_path):
+    m = BoringGlobalModel(ic_source="synthetic")
+    first, paths = m.rollout(T0, n_steps=1, save=True, save_config={"output_dir": str(tmp_path)})
+    nxt = m.predict_one_step(T0 + datetime.timedelta(hours=6), initial_condition=Path(paths[0]))
+    assert np.allclose(nxt.values[1], first.values[1] + 1.0)
+
+
 def test_rollout_from_a_given_initial_condition_and_no_id_leak(tmp_path):
     m = BoringGlobalModel(ic_source="synthetic")
     first, paths = m.rollout(T0, n_steps=2, save=True, save_config={"output_dir": str(tmp_path)})

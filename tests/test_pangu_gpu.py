@@ -2,8 +2,9 @@
 
 Tolerances (floating point; stated per the north star): per-channel max|y - ref| / max|ref| <= 1e-3.
 Modes (skyrim_amd/pangu/engine.py PRECISIONS): hi/lo split GEMMs with fp16 single-term attention --
-"f16x2" (default: fp16 activation planes x ONE fp16 weight plane in proj / fc1 / fc2 = 2 MFMA terms, QKV 2-term; oracle emulation of
-exactly this rounding plan: 4.2e-4 after one step, 5.3e-4 after four -> asserted <= 8e-4),
+"f16x2q" (default: fp16 activation planes x ONE fp16 weight plane -- proj / fc1 / fc2 2 MFMA terms, QKV one; oracle emulation of
+exactly this rounding plan: 4.9e-4 after one step, 5.0e-4 after four; observed 5.0e-4 / 5.3e-4 -> asserted <= 8e-4), "f16x2" (the same with hi/lo QKV
+weights: 4.3e-4 / 5.3e-4),
 "f16x3q" (the same with 3 terms; observed ~1e-4 -> asserted <= 3e-4), "f16x3", "bf16x3" (3 terms
 everywhere; ~8e-5 -> <= 3e-4), "bf16x3h" / "f16x3qh" (additionally the MLP hidden as one fp16 plane; ~4e-4 ->
 asserted <= 1e-3), and "f16" (single-term speed mode, observed ~1.2e-3, does NOT meet the bar -> held to 5e-3).
@@ -19,9 +20,9 @@ from skyrim_amd.pangu.spec import PanguGeometry, init_synthetic, synthetic_state
 
 pytestmark = pytest.mark.gpu
 
-STAGE_TOL = {"f16x2": 1.5e-3, "bf16x3": 5e-4, "f16x3": 5e-4, "f16x3q": 5e-4, "bf16x3h": 2e-3, "f16x3qh": 2e-3, "f16": 4e-3}
+STAGE_TOL = {"f16x2q": 1.5e-3, "f16x2": 1.5e-3, "bf16x3": 5e-4, "f16x3": 5e-4, "f16x3q": 5e-4, "bf16x3h": 2e-3, "f16x3qh": 2e-3, "f16": 4e-3}
 DEF_TOL = 8e-4       # the default mode's asserted step error (STEP_TOL[DEFAULT_PRECISION])
-STEP_TOL = {"f16x2": 8e-4, "bf16x3": 3e-4, "f16x3": 3e-4, "f16x3q": 3e-4, "bf16x3h": 1e-3, "f16x3qh": 1e-3, "f16": 5e-3}   # 3-term modes: 3x inside the bar
+STEP_TOL = {"f16x2q": 8e-4, "f16x2": 8e-4, "bf16x3": 3e-4, "f16x3": 3e-4, "f16x3q": 3e-4, "bf16x3h": 1e-3, "f16x3qh": 1e-3, "f16": 5e-3}   # 3-term modes: 3x inside the bar
 
 
 def rel(a, b):
@@ -37,7 +38,7 @@ def ref(toy):
     return taps, y
 
 
-@pytest.fixture(scope="module", params=["f16x2", "f16x3q", "bf16x3", "f16x3", "bf16x3h", "f16x3qh", "f16"])
+@pytest.fixture(scope="module", params=["f16x2q", "f16x2", "f16x3q", "bf16x3", "f16x3", "bf16x3h", "f16x3qh", "f16"])
 def eng(request, toy):
     from skyrim_amd.pangu.engine import PanguEngine
     g, params, x = toy
@@ -166,7 +167,7 @@ def test_profile_hooks_cover_the_step(eng, toy):
     eng.profile(False)
     by = {s["name"]: s for s in stats}
     # 3-term modes: projection + MLP as one kernel per block (fused_block.hip); the others: proj, fc1, fc2 as separate launches
-    mlp = "proj_mlp_r1" if eng.precision in ("f16x2", "f16x3q", "f16x3", "bf16x3") else "fc1_r1"
+    mlp = "proj_mlp_r1" if eng.precision in ("f16x2q", "f16x2", "f16x3q", "f16x3", "bf16x3") else "fc1_r1"
     assert by[mlp]["launches"] == 12 and by["qkv_r0"]["launches"] == 4 and by["embed"]["launches"] == 1
     assert by["fc2_r1"]["launches"] == by["proj_r1"]["launches"] == (0 if mlp == "proj_mlp_r1" else 12)
     assert all(s["total_ms"] > 0 for s in stats if s["launches"])
@@ -200,6 +201,7 @@ def test_full_size_step_vs_oracle(full, full_ref):
     y = e.step(x.cuda())
     err = O.per_channel_rel_err(y.cpu(), full_ref[0])
     assert torch.isfinite(y).all()
+    print(f"full-size step: max per-channel rel err {err.max().item():.3e} ({DEFAULT_PRECISION})")
     assert err.max().item() < 1e-3, err
     assert err.max().item() < DEF_TOL, err       # what the default mode is asserted to deliver (two-term plan: ~5e-4)
 
@@ -215,6 +217,7 @@ def test_full_size_24h_rollout_vs_oracle(full, full_ref):
         e.step(state, out=state)                # in place, as bench.py times it
         errs.append(O.per_channel_rel_err(state.cpu(), full_ref[k]).max().item())
     assert torch.isfinite(state).all()
+    print("full-size 24-h rollout: max per-channel rel err per step " + " ".join(f"{e:.3e}" for e in errs) + f" ({DEFAULT_PRECISION})")
     assert max(errs) < DEF_TOL, errs
 
 
@@ -381,6 +384,28 @@ def test_fused_mlp_kernel_matches_the_two_gemm_path_and_the_oracle(toy, ref):
                 want2 = O.earth_block(O._block_params(params, 2, 0), taps["down"], O.Geometry(g.n_lat, g.n_lon).res(2), O.HEADS[1], False)
                 assert rel(eng.block(2, 0, x2).cpu(), want2) < STAGE_TOL[prec], mlp
     assert O.per_channel_rel_err(outs["fused", "f16x3q"], outs["split", "f16x3q"]).max().item() < 2e-4
+
+
+@pytest.mark.parametrize("plan", [0x00, 0x05, 0x0A, 0x0F, 0xF0, 0xFF])
+def test_per_layer_term_plan(toy, ref, plan):
+    """skpangu_config.term_plan: bit l = layer l + 1 runs proj / fc1 / fc2 with two MFMA terms (csrc/fused_block2.hip), bit 4 + l its QKV
+    with one.  Every plan stays inside the bar; a layer that keeps its lo planes is bit-identical to the three-term engine's block, a layer
+    that drops them is not; the error grows with the number of rounded weight sets."""
+    from skyrim_amd.pangu.engine import PanguEngine
+    g, params, x = toy
+    taps, y_ref = ref
+    eng = PanguEngine(g, "f16x3q", "cuda:0", term_plan=plan)
+    eng.load_params(params)
+    assert eng.term_plan == plan
+    err = O.per_channel_rel_err(eng.step(x.cuda()).cpu(), y_ref).max().item()
+    assert err < (3e-4 if plan == 0 else 8e-4), (hex(plan), err)
+    base = PanguEngine(g, "f16x3q", "cuda:0")
+    base.load_params(params)
+    for layer, tap in ((1, "embed"), (2, "down"), (3, "down"), (4, "up")):
+        xin = taps[tap].float().cuda().contiguous()
+        same = torch.equal(eng.block(layer, 0, xin), base.block(layer, 0, xin))
+        touched = bool((plan >> (layer - 1)) & 1) or bool((plan >> (3 + layer)) & 1)
+        assert same == (not touched), (hex(plan), layer)
 
 
 def test_step_as_a_captured_hip_graph(toy):

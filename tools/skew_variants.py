@@ -54,7 +54,7 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "child":
         child(sys.argv[2])
         sys.exit(0)
-    runs = [("f16x2", v) for v in sys.argv[1:] or ("0", "1", "2", "3", "4")]      # "5:40000" = variant 5 with SKP_DUO_STAGGER=40000
+    runs = [(os.environ.get("SKEW_PREC", "f16x2"), v) for v in sys.argv[1:] or ("0", "1", "2", "3", "4")]      # "5:40000" = variant 5 with SKP_DUO_STAGGER=40000
     for prec, v in runs:
         env = dict(os.environ)
         if v is not None:
