@@ -8,6 +8,12 @@ One "step" = one skpangu_step() = one 6-h forward of the Pangu network on a synt
 already resident in HBM (autoregressive, in place).  N > 1: one process per GPU, one ensemble member
 per rank (weak scaling, members are independent); the timed region ends with the RCCL reduction that
 forms the ensemble mean/spread of the final step.  Prints ONE JSON line on rank 0.
+
+At N = 1 the same line also carries, under "models", a short driver-timed run of the other two rows of the hot path (FourCastNet
+v2-small and GraphCast at 721x1440: ms per step, the roofline of the dominant stage, the committed profile it is read against);
+``--model sfno|graphcast`` makes one of them the headline line instead.  Counter-derived fields (HBM traffic, MFMA-busy) are never
+measured in this run: they are read from the committed ``profiles/r03_<model>_pmc.json`` and are dropped -- with a note -- when that
+summary holds no kernel of the name the live run's dominant stage launches.
 """
 from __future__ import annotations
 
@@ -47,31 +53,17 @@ MODE_NOTES = {
 
 
 def cpu_baseline(params, geom, x):
-    """CPU restatement (oracle/, kind 'port') timed on this box's host cores on a bounded sample of the
-    same workload: embed + layer1.block0-1 + downsample + layer2.block0-1 of one full-size step,
-    scaled to steps/s by algorithmic FLOPs."""
+    """CPU restatement (oracle/, kind 'port') timed on this box's host cores: ONE full step of the same workload, no scaling."""
     from oracle import pangu_oracle as O
-    g = O.Geometry(geom.n_lat, geom.n_lon)
-    p = {k: v for k, v in params.items()}
-    mean, std = p["norm.mean"][:, None, None], p["norm.std"][:, None, None]
     cores = torch.get_num_threads()
     t0 = time.time()
     with torch.no_grad():
-        upper, surface = O.split_state((x - mean) / std)
-        t = O.patch_embed(p, g, upper, surface)
-        for i in range(2):
-            t = O.earth_block(O._block_params(p, 1, i), t, g.res(1), O.HEADS[0], i % 2 == 1)
-        t = O.downsample(p, g, t)
-        for i in range(2):
-            t = O.earth_block(O._block_params(p, 2, i), t, g.res(2), O.HEADS[1], i % 2 == 1)
+        y = O.forward(params, x)
     dt = time.time() - t0
-    f_sample = (30.8 + 2 * 524.7 + 77.3 + 2 * 502.8) * 1e9
-    t_step = dt * F_ALG_STEP / f_sample
-    return {"value": 1.0 / t_step, "unit": "steps/s", "cores": cores, "kind": "port",
-            "sample": f"embed + layer1.block0-1 + downsample + layer2.block0-1 of one 721x1440 step "
-                      f"({100 * f_sample / F_ALG_STEP:.1f}% of its FLOPs) in {dt:.1f} s, scaled by FLOPs; "
-                      "PyTorch-CPU fp32 restatement, not the reference's ONNX graph",
-            "s_per_step_est": t_step}
+    return {"value": 1.0 / dt, "unit": "steps/s", "cores": cores, "kind": "port",
+            "sample": f"ONE full {geom.n_lat}x{geom.n_lon} 6-h step of the PyTorch-CPU fp32 restatement (oracle/pangu_oracle.py) in {dt:.1f} s on {cores} "
+                      f"threads; no scaling; not the reference's ONNX graph (onnxruntime and the weights are not obtainable here); finite={bool(torch.isfinite(y).all())}",
+            "s_per_step": dt}
 
 
 def toy_parity(precision):
@@ -88,10 +80,13 @@ def toy_parity(precision):
     return {"grid": "49x192", "max_rel_err": O.per_channel_rel_err(y, O.forward(p, x)).max().item(), "bar": 1e-3}
 
 
+PROFILE_ROUND = "r03"
+
+
 def pmc_summary(model: str):
-    """profiles/r02_<model>_pmc.json (tools/pmc_collect.sh + tools/pmc_summary.py: rocprofv3 --pmc passes, FETCH_SIZE doubled per
-    MI355X_MICROARCH.md 'HBM'), or None."""
-    f = ROOT / "profiles" / f"r02_{model}_pmc.json"
+    """profiles/r03_<model>_pmc.json (tools/pmc_collect.sh + tools/pmc_summary.py: rocprofv3 --pmc passes, FETCH_SIZE doubled per
+    MI355X_MICROARCH.md 'HBM'), or None.  A COMMITTED profile, not a measurement of this run."""
+    f = ROOT / "profiles" / f"{PROFILE_ROUND}_{model}_pmc.json"
     try:
         return json.loads(f.read_text())
     except Exception:
@@ -100,27 +95,30 @@ def pmc_summary(model: str):
 
 def pmc_kernels(model: str, *needles: str):
     """Counters of the kernels whose (demangled) name contains every needle, summed per STEP: HBM bytes, kernel time under the
-    counters, MFMA-busy share (time-weighted).  None without a committed summary."""
+    counters, MFMA-busy share (time-weighted).  When the committed summary has no such kernel (renamed or retuned since the profile
+    was taken) the counters are NOT reported: the entry says so instead of pairing stale counters with fresh timings."""
     d = pmc_summary(model)
+    src = f"profiles/{PROFILE_ROUND}_{model}_pmc.json"
     if not d:
-        return None
+        return {"note": f"no committed counter summary ({src})"}
     steps = d["total"]["steps"]
     rows = [e for k, e in d["kernels"].items() if all(n in k for n in needles)]
     if not rows:
-        return None
+        return {"note": f"{src} holds no kernel matching {list(needles)}: counters dropped (profile older than the kernel)"}
     t = sum(e["avg_us"] * e["calls"] for e in rows)
     return {"hbm_bytes_per_step": 1e9 * sum(e["hbm_GB"] * e["calls"] for e in rows) / steps,
             "hbm_bytes_per_launch": 1e9 * sum(e["hbm_GB"] * e["calls"] for e in rows) / sum(e["calls"] for e in rows),
             "ms_per_step_under_pmc": t / steps / 1e3,
             "mfma_busy_pct": sum((e["mfma_busy_pct"] or 0.0) * e["avg_us"] * e["calls"] for e in rows) / t if t else None,
-            "source": f"profiles/r02_{model}_pmc.json"}
+            "source": src, "kind": "committed profile, not measured in this run",
+            "profiled_at": d.get("stamp")}
 
 
 # bench stage -> what identifies its kernel in the counter summary
 PANGU_STAGE_KERNEL = {"mlp_r0": ("fused_mlp_kernel", "MlpShape<192"), "mlp_r1": ("fused_mlp_kernel", "MlpShape<384"),
-                      "proj_mlp_r0": ("proj_mlp_kernel", "BlockShape<192"), "proj_mlp_r1": ("proj_mlp_kernel", "BlockShape<384"),
+                      "proj_mlp_r0": ("proj_mlp", "Shape<192"), "proj_mlp_r1": ("proj_mlp", "Shape<384"),
                       "qkv_r0": ("rt_qkv_kernel", "QkvShape<192"), "qkv_r1": ("rt_qkv_kernel", "QkvShape<384"),
-                      "attn_r0": ("earth_attention_kernel",), "attn_r1": ("earth_attention_kernel",),
+                      "attn_r0": ("earth_attention",), "attn_r1": ("earth_attention",),
                       "proj_r0": ("gemm_dma_kernel", "256x192", "EpLayerNorm", "RowMapIndexed"), "proj_r1": ("gemm_dma_kernel", "128x384", "EpLayerNorm")}
 
 
@@ -162,6 +160,38 @@ def api_rollout_rate(precision, geom, params, x_host, dev, n=6):
             "note": "run_basic_inference: every 6-h state copied to the host (pinned buffer, copy stream overlapped with the next "
                     "step); includes the H2D of the initial state; the page-locked result buffer is warm; finite="
                     + str(bool(torch.isfinite(torch.from_numpy(out.values[-1])).all()))}
+
+
+def predict_inclusive(precision, geom, params, dev, n_steps=4):
+    """What ``Skyrim('pangu').predict(lead_time=24, save=...)`` costs end to end: ``GlobalModel.rollout`` (the call ``predict`` makes,
+    core/skyrim.py) of 4 six-hour steps through ``predict_one_step`` / ``run_basic_inference`` -- every step delivered to the host as a
+    (2, 69, 721, 1440) array like the reference's (573 MB), the state itself staying in HBM between steps -- once without saving and once
+    with the per-step netCDF files written to tmpfs by the save thread."""
+    import datetime
+    import shutil
+    import tempfile
+    from skyrim_amd.core.models.pangu import PanguModel
+    m = PanguModel(ic_source="gfs", geom=geom, params=params, precision=precision, device=dev)
+    t0 = datetime.datetime(2024, 1, 1)
+    base = "/dev/shm" if os.path.isdir("/dev/shm") else None
+    out = {}
+    for save in (False, True):
+        d = tempfile.mkdtemp(prefix="skyrim_bench_", dir=base)
+        try:
+            m.rollout(t0, n_steps=1, save=save, save_config={"output_dir": d})                 # warm: pinned buffers, file system
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            _, paths = m.rollout(t0, n_steps=n_steps, save=save, save_config={"output_dir": d})
+            dt = (time.perf_counter() - t) / n_steps
+            out["save" if save else "no_save"] = {"ms_per_step": 1e3 * dt, "steps_per_s": 1.0 / dt, "files": len(paths),
+                                                   "bytes_per_file": os.path.getsize(paths[0]) if paths else 0}
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    out["io_counters"] = dict(m.model.io_counters)
+    out["note"] = (f"GlobalModel.rollout(n_steps={n_steps}) through the reference-shaped API: one H2D of the initial condition, then the state stays in "
+                   "HBM (io_counters.resident_hits); every step's (t, t + 6 h) pair copied to pinned host memory on a copy stream; save: one netCDF-3 file "
+                   f"per step ({'tmpfs' if base else 'tmp dir'}) written by a worker thread while the next step runs")
+    return out
 
 
 def run_sfno(args, rank, local_rank, world, dist):
@@ -227,7 +257,7 @@ def run_sfno(args, rank, local_rank, world, dist):
         # achieved = algorithmic bytes (A operand read once + output written once + residuals, fp32) of the dominant stage / its time
         "roofline": {"bound": "hbm", "kernel": dom["name"] + f" ({dom_kernel})", "achieved": dom["bytes"] / (dom["total_ms"] * 1e-3) / 1e9,
                      "peak": PEAK_HBM / 1e9, "unit": "GB/s", "frac": dom["bytes"] / (dom["total_ms"] * 1e-3) / PEAK_HBM,
-                     "traffic": (pmc_kernels("sfno", dom_kernel) or {}).get("hbm_bytes_per_launch"),
+                     "traffic": pmc_kernels("sfno", dom_kernel).get("hbm_bytes_per_launch"),
                      "counters_all_gemm_launches": pmc_kernels("sfno", "gemm_strided_kernel"),
                      "avg_launch_ms": dom_ms, "alg_bytes_per_launch": dom["bytes"] / dom["launches"],
                      "mfma": {"achieved_tflops": achieved / 1e12, "frac": achieved / PEAK_MFMA_BF16,
@@ -256,7 +286,7 @@ def run_sfno(args, rank, local_rank, world, dist):
         te = SfnoEngine(tiny, dev)
         te.load_params(tp)
         out["parity"] = {"grid": "97x192", "max_rel_err": O.per_channel_rel_err(te.step(tx.to(dev)).cpu(), O.forward(tp, tx, tiny)).max().item(), "bar": 1e-3}
-    print(json.dumps(out), flush=True)
+    return out
 
 
 def run_graphcast(args, rank, local_rank, world, dist):
@@ -264,7 +294,7 @@ def run_graphcast(args, rank, local_rank, world, dist):
     GraphCast (M6 multi-mesh, 16 processor layers) on synthetic 83-channel states resident in HBM; N > 1 = one member per rank (the
     2-GPU mesh split of configs[3] is not built: a step fits one GPU) + the closing ensemble reduction."""
     from skyrim_amd.graphcast.engine import GraphcastEngine
-    from skyrim_amd.graphcast.spec import GraphcastConfig, flops_per_step, flops_per_step_executed, forcings, init_synthetic, synthetic_states
+    from skyrim_amd.graphcast.spec import GraphcastConfig, alg_bytes_per_step, flops_per_step, flops_per_step_executed, forcings, init_synthetic, synthetic_states
     from skyrim_amd.pangu.ensemble import ensemble_mean_spread
     cfg = GraphcastConfig(n_lat=args.n_lat, n_lon=args.n_lon)
     dev = torch.device("cuda", local_rank)
@@ -327,6 +357,9 @@ def run_graphcast(args, rank, local_rank, world, dist):
     dom = max(stats, key=lambda s: s["total_ms"])
     achieved = dom["flops"] / (dom["total_ms"] * 1e-3)
     gpu_ms = sum(s["total_ms"] for s in stats) / args.steps
+    alg = alg_bytes_per_step(cfg, cfg.n_lat * cfg.n_lon, g.n_mesh, len(g.mesh_edges), len(g.g2m_edges) * (world if sharded else 1), 3 * cfg.n_lat * cfg.n_lon)
+    dom_alg = alg.get(dom["name"], 0.0)
+    dom_step_ms = dom["total_ms"] / args.steps
     out = {
         "metric": "6-h forecast steps/sec on 721x1440 state, 1/2/4/8 MI355X; per-channel max rel-err vs ref",
         "value": (1 if sharded else world) * args.steps / elapsed, "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -339,18 +372,24 @@ def run_graphcast(args, rank, local_rank, world, dist):
                    "parallelism": (f"one forecast over {world} GPUs: latitude bands of the grid + mesh-node ranges (owner computes); per step one "
                                    f"all-reduce of the ({g.n_mesh} x {cfg.latent}) grid->mesh aggregate and {cfg.steps} all-gathers of the node latents") if sharded else
                                   (f"member-parallel x{world}" if world > 1 else "single GPU"), "finite": finite},
-        "roofline": {"bound": "mfma", "kernel": dom["name"] + " (gemm_strided_kernel + sum_linear_ln_kernel + gather_gemm_kernel + linear_ln_kernel)", "achieved": achieved / 1e12,
-                     "peak": PEAK_MFMA_BF16 / 1e12, "unit": "TFLOP/s", "frac": achieved / PEAK_MFMA_BF16,
-                     "traffic": (pmc_kernels("graphcast", "ln_kernel") or {}).get("hbm_bytes_per_launch"),
+        # GraphCast at fp32 latents is bandwidth-limited (235 GB measured per step against 15 executed TFLOP): the roofline of the line is the HBM
+        # one, on ALGORITHMIC bytes (spec.alg_bytes_per_step: every tensor of the data flow once in, once out); the MFMA figures stay alongside
+        "roofline": {"bound": "hbm", "kernel": dom["name"] + " (gemm_strided_kernel + sum_linear_ln_kernel + gather_gemm_kernel + linear_ln_kernel)",
+                     "achieved": dom_alg / (dom_step_ms * 1e-3) / 1e9, "peak": PEAK_HBM / 1e9, "unit": "GB/s", "frac": dom_alg / (dom_step_ms * 1e-3) / PEAK_HBM,
+                     "alg_bytes_per_step_of_stage": dom_alg, "stage_ms_per_step": dom_step_ms,
+                     "traffic": pmc_kernels("graphcast", "ln_kernel").get("hbm_bytes_per_step"),
+                     "mfma": {"achieved_tflops": achieved / 1e12, "frac": achieved / PEAK_MFMA_BF16, "note": "executed FLOPs of the dominant stage"},
                      "counters_linear_layer_norm_kernels": pmc_kernels("graphcast", "ln_kernel"),
                      "hbm_GB_per_step_all_kernels": ((pmc_summary("graphcast") or {}).get("total") or {}).get("hbm_GB_per_step"),
                      "avg_launch_ms": dom["total_ms"] / dom["launches"],
                      "step": {"alg_tflop": f_step / 1e12, "gpu_ms": gpu_ms, "mfma_frac": f_step / (gpu_ms * 1e-3) / PEAK_MFMA_BF16,
-                              "executed_tflop": f_exec / 1e12,
+                              "executed_tflop": f_exec / 1e12, "alg_GB": alg["total"] / 1e9, "hbm_frac": alg["total"] / (gpu_ms * 1e-3) / PEAK_HBM,
+                              "alg_GB_per_stage": {k: round(v / 1e9, 2) for k, v in alg.items() if k != "total"},
                               "note": "alg_tflop: the network as published (every edge MLP on the concatenated 1536-wide row); executed_tflop: the same "
                                       "result with the first Linear of the edge MLPs taken apart by distributivity (what the kernels run)"},
                      "stages": {s["name"]: {"ms_per_step": round(s["total_ms"] / args.steps, 3), "launches_per_step": s["launches"] // args.steps,
-                                            "dense_tflops": round(s["flops"] / (s["total_ms"] * 1e-3) / 1e12, 1)} for s in stats}},
+                                            "dense_tflops": round(s["flops"] / (s["total_ms"] * 1e-3) / 1e12, 1),
+                                            "alg_GBps": round(alg.get(s["name"], 0.0) / (s["total_ms"] / args.steps * 1e-3) / 1e9, 1)} for s in stats}},
     }
     if world == 1 and not args.no_cpu_baseline:
         # bounded sample with one piece per cost class, each timed on the host cores and scaled by its own count (not by FLOPs alone:
@@ -404,7 +443,7 @@ def run_graphcast(args, rank, local_rank, world, dist):
         ref = O.forward(sp, OG.build(small.n_lat, small.n_lon, small.splits), s0, s1, sf)
         out["parity"] = {"grid": "61x120, M3 mesh", "max_rel_err": O.per_channel_rel_err(y, ref).max().item(),
                          "max_rel_err_of_increment": O.increment_rel_err(y, ref, s1).max().item(), "bar": 1e-3}
-    print(json.dumps(out), flush=True)
+    return out
 
 
 def main():
@@ -418,6 +457,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-alt-modes", action="store_true", help="skip the short runs of the other precision modes")
+    ap.add_argument("--no-models", action="store_true", help="pangu, N = 1: skip the short SFNO / GraphCast runs reported under \"models\"")
     ap.add_argument("--members", type=int, default=0, help="pangu, --gpus > 1: ensemble members in total, sharded round-robin over the ranks "
                     "(BASELINE configs[4]: --gpus 8 --members 50 --save-every 1 --gather); default: one member per rank")
     ap.add_argument("--save-every", type=int, default=0, help="ensemble mean / spread (and --gather) every this many steps; default: once, after the last step")
@@ -455,7 +495,9 @@ def main():
             dist.init_process_group(args.backend)
 
     if args.model in ("sfno", "graphcast"):
-        (run_sfno if args.model == "sfno" else run_graphcast)(args, rank, local_rank, world, dist)
+        line = (run_sfno if args.model == "sfno" else run_graphcast)(args, rank, local_rank, world, dist)
+        if line is not None:
+            print(json.dumps(line), flush=True)
         if world > 1:
             dist.destroy_process_group()
         return
@@ -563,7 +605,7 @@ def main():
             "roofline": {
                 "bound": "mfma", "kernel": dom["name"], "achieved": achieved / 1e12, "peak": PEAK_MFMA_BF16 / 1e12,
                 "unit": "TFLOP/s", "frac": achieved / PEAK_MFMA_BF16,
-                "traffic": (pmc_kernels("pangu", *PANGU_STAGE_KERNEL.get(dom["name"], ("?",))) or {}).get("hbm_bytes_per_launch"),
+                "traffic": pmc_kernels("pangu", *PANGU_STAGE_KERNEL.get(dom["name"], ("?",))).get("hbm_bytes_per_launch"),
                 "counters": pmc_kernels("pangu", *PANGU_STAGE_KERNEL.get(dom["name"], ("?",))),
                 "hbm_bytes_per_step_all_kernels": ((pmc_summary("pangu") or {}).get("total") or {}).get("hbm_GB_per_step"),
                 "alg_bytes_per_launch": dom["bytes"],
@@ -584,12 +626,34 @@ def main():
             out["parity"] = toy_parity(args.precision)
         if world == 1 and not args.no_alt_modes:
             out["pcie_inclusive"] = api_rollout_rate(args.precision, geom, params, x_host, dev)
-            del eng
+            eng = None
+            torch.cuda.empty_cache()
+            out["predict_inclusive"] = predict_inclusive(args.precision, geom, params, dev)
             torch.cuda.empty_cache()
             out["modes"] = {m: dict(quick_mode(m, geom, params, x_host, dev), note=MODE_NOTES[m][1])
                             for m in ("f16x3q", "bf16x3", "f16") if m != args.precision}
             out["modes"][args.precision + "/split-mlp"] = dict(quick_mode(args.precision, geom, params, x_host, dev, mlp="split"),
                                                                note="same arithmetic with the MLP as two tiled GEMMs (hidden through HBM): the round-1 path")
+        if world == 1 and not args.no_models:
+            # the other two rows of the hot path, driver-timed in the same invocation: a short run each (5 steps after 2 of warm-up)
+            import copy
+            eng = x = xs = graphs = None             # release the Pangu engine's arenas and states before GraphCast's 47 GB
+            torch.cuda.empty_cache()
+            sub = copy.copy(args)
+            sub.steps, sub.warmup, sub.no_cpu_baseline, sub.no_parity, sub.shard = 5, 2, True, True, False
+            out["models"] = {}
+            for name, fn in (("sfno", run_sfno), ("graphcast", run_graphcast)):
+                try:
+                    line = fn(sub, 0, local_rank, 1, dist)
+                    out["models"][name] = {"ms_per_step": line["ms_per_step"], "steps_per_s": line["value"], "steps": line["steps"], "warmup": line["warmup"],
+                                           "workload": line["config"]["workload"], "precision": line["config"]["precision"], "finite": line["config"]["finite"],
+                                           "roofline": {k: line["roofline"][k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic") if k in line["roofline"]},
+                                           "step": line["roofline"].get("step"), "stages_ms_per_step": {k: v["ms_per_step"] for k, v in line["roofline"]["stages"].items()},
+                                           "profile": f"profiles/{PROFILE_ROUND}_{name}_kernel_stats.csv, profiles/{PROFILE_ROUND}_{name}_pmc.json "
+                                                      f"(python bench.py --model {name}, same kernels)"}
+                except Exception as e:      # a failure of a secondary row must not take the headline line with it -- but it must be visible
+                    out["models"][name] = {"error": f"{type(e).__name__}: {e}"}
+                torch.cuda.empty_cache()
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

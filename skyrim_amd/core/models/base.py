@@ -7,6 +7,7 @@ from __future__ import annotations
 import datetime
 import logging
 import time
+from concurrent.futures import ThreadPoolExecutor
 from pathlib import Path
 from typing import List
 
@@ -90,15 +91,26 @@ class GlobalModel:
         cfg.setdefault("forecast_id", generate_forecast_id())
         if save_config is not None:
             save_config["forecast_id"] = cfg["forecast_id"]
-        pred, output_paths = initial_condition, []
+        pred, pending = initial_condition, []
         source = "file" if initial_condition is not None else self.source_label
-        for n in range(n_steps):
-            pred = self.predict_one_step(start_time, initial_condition=pred)
-            pred_time = start_time + self.time_step
-            if save:
-                output_paths.append(save_forecast(pred, self.model_name, start_time, pred_time, source, config=cfg))
-            start_time, source = pred_time, "file"
-            logger.info(f"Rollout step {n + 1}/{n_steps} completed")
+        # Step k's file is written by ONE worker thread while step k + 1 runs (the reference writes 573 MB synchronously between two
+        # steps, base.py:134-143).  One worker keeps the files -- and the zarr appends -- in step order; at most two predictions wait
+        # for the disk, so a slow target throttles the rollout instead of filling host memory.  Same files, same order, same paths.
+        pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="skyrim-save") if save else None
+        try:
+            for n in range(n_steps):
+                pred = self.predict_one_step(start_time, initial_condition=pred)
+                pred_time = start_time + self.time_step
+                if save:
+                    pending.append(pool.submit(save_forecast, pred, self.model_name, start_time, pred_time, source, config=cfg))
+                    if len(pending) > 2:
+                        pending[-3].result()
+                start_time, source = pred_time, "file"
+                logger.info(f"Rollout step {n + 1}/{n_steps} completed")
+            output_paths = [f.result() for f in pending]         # re-raises a writer's exception here, in step order
+        finally:
+            if pool is not None:
+                pool.shutdown(wait=True)
         return pred, output_paths
 
 

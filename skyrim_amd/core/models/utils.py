@@ -16,20 +16,53 @@ from ...labeled import DataArray, open_dataarray
 _PINNED_LIMIT = 24 << 30     # bytes of page-locked host memory run_basic_inference may take for its result
 
 
+class ResidentState:
+    """The device copy of the state(s) a TimeLoop produced last, tied to the host array they were delivered in.
+
+    The reference feeds every prediction back through the host: ``rollout`` hands ``pred`` to ``predict_one_step``, which uploads
+    ``pred.values[-n_history_levels:]`` again (/root/reference/skyrim/core/models/base.py:131-132, utils.py:24-31: 286 MB from pageable
+    memory per step).  When the array that comes back IS the one this model delivered -- same ndarray object, still read-only -- the
+    states are already in HBM and the upload is skipped.  The delivered array is marked read-only for exactly that reason: an in-place
+    edit would go unnoticed; ``DataArray.copy()`` (or ``perturb_initial_conditions``, which copies on demand) gives a writable array, and
+    a copy takes the ordinary upload path."""
+
+    def __init__(self, host: np.ndarray, states: list):
+        import weakref
+        host.flags.writeable = False
+        self._host = weakref.ref(host)
+        self.states = states                       # the last n_history_levels yielded tensors, (B, C, lat, lon) each, oldest first
+
+    def tensor_for(self, x, n_hist: int):
+        """(1, n_hist, C, lat, lon) device tensor if ``x`` carries the array these states were delivered in, else None."""
+        vals = getattr(x, "values", None)
+        if vals is None or vals is not self._host() or vals.flags.writeable or len(self.states) < n_hist:
+            return None
+        return torch.stack([t[0] if t.dim() == 4 else t for t in self.states[-n_hist:]], dim=0).unsqueeze(0)
+
+
 def run_basic_inference(model, n: int, data_source: Any, time: datetime, x=None):
     """Run a basic inference: returns DataArray(time = n + 1, channel, lat, lon); entry 0 is the state at ``time``."""
+    counters = model.__dict__.setdefault("io_counters", {"state_uploads": 0, "resident_hits": 0}) if hasattr(model, "__dict__") else {}
     if x is None:
         x = get_initial_condition_for_model(model, data_source, time)     # comes with the batch dimension
+        counters["state_uploads"] = counters.get("state_uploads", 0) + 1
     else:
         if isinstance(x, (str, os.PathLike)):
             x = open_dataarray(os.fspath(x))
-        x = torch.as_tensor(np.asarray(x.values[-model.n_history_levels:]), dtype=torch.float32).to(model.device)
-        x = x.unsqueeze(0)
+        resident = getattr(model, "_resident_state", None)
+        dev = resident.tensor_for(x, model.n_history_levels) if resident is not None else None
+        if dev is not None:
+            x = dev                                                        # fed straight back: the states never left HBM
+            counters["resident_hits"] = counters.get("resident_hits", 0) + 1
+        else:
+            x = torch.as_tensor(np.asarray(x.values[-model.n_history_levels:]), dtype=torch.float32).to(model.device)
+            x = x.unsqueeze(0)
+            counters["state_uploads"] = counters.get("state_uploads", 0) + 1
 
     # The reference copies every yielded state to the host synchronously (`.cpu().numpy()`, utils.py:36): 286 MB per
     # step through pageable memory, the sync point of its loop.  Here the n + 1 states land in ONE pinned host buffer
     # through a copy stream, so the D2H of step k overlaps the forward of step k + 1; the result is the same array.
-    times, stacked, arrays, side = [], None, [], None
+    times, stacked, arrays, side, last = [], None, [], None, []
     loop = model(time, x)
     for k, (time, output, _) in enumerate(loop):
         out = output.squeeze(0) if output.dim() == 4 and output.shape[0] == 1 else output
@@ -42,6 +75,7 @@ def run_basic_inference(model, n: int, data_source: Any, time: datetime, x=None)
             with torch.cuda.stream(side):
                 stacked[k].copy_(out, non_blocking=True)
             out.record_stream(side)
+            last = (last + [output if output.dim() == 4 else output.unsqueeze(0)])[-model.n_history_levels:]
         else:
             arrays.append(out.detach().cpu().numpy())
         times.append(time)
@@ -52,6 +86,8 @@ def run_basic_inference(model, n: int, data_source: Any, time: datetime, x=None)
     if stacked is not None:
         side.synchronize()
         stacked = stacked[:len(times)].numpy()
+        if hasattr(model, "__dict__"):
+            model._resident_state = ResidentState(stacked, last)
     else:
         stacked = np.stack(arrays)
     coords = dict(time=times, channel=model.out_channel_names, lat=np.asarray(model.grid.lat), lon=np.asarray(model.grid.lon))
@@ -68,5 +104,7 @@ def perturb_initial_conditions(initial_conditions: DataArray, channel, lat, lon,
     ax = initial_conditions.dims
     sl = [slice(None)] * len(ax)
     sl[ax.index("channel")], sl[ax.index("lat")], sl[ax.index("lon")] = c, i, j
+    if not initial_conditions.values.flags.writeable:      # a prediction as delivered by run_basic_inference (ResidentState): edit a copy
+        initial_conditions.values = initial_conditions.values.copy()
     initial_conditions.values[tuple(sl)] = value
     return initial_conditions

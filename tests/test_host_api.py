@@ -309,6 +309,22 @@ def test_finite_guard_fires_through_predict_one_step_rollout_and_forecast():
         m3.forecast(T0, n_steps=3)                                  # the final state of forecast(n) is checked too
 
 
+def test_resident_state_is_tied_to_the_delivered_array():
+    """core/models/utils.py ResidentState (CPU tensors stand in for the device copies): only the very array that was delivered, still
+    read-only, maps back to the resident states; a copy, a writable array or too short a history do not."""
+    from skyrim_amd.core.models.utils import ResidentState, perturb_initial_conditions
+    host = np.zeros((2, 3, 4, 5), np.float32)
+    s0, s1 = torch.zeros(1, 3, 4, 5), torch.ones(1, 3, 4, 5)
+    rs = ResidentState(host, [s0, s1])
+    da = DataArray(host, ["time", "channel", "lat", "lon"], dict(channel=["a", "b", "c"], lat=np.arange(4.0), lon=np.arange(5.0)))
+    assert not host.flags.writeable and da.values is host
+    assert rs.tensor_for(da, 1).shape == (1, 1, 3, 4, 5) and torch.equal(rs.tensor_for(da, 1)[0, 0], s1[0])
+    assert torch.equal(rs.tensor_for(da, 2)[0, 0], s0[0]) and rs.tensor_for(da, 3) is None
+    assert rs.tensor_for(da.copy(), 1) is None
+    edited = perturb_initial_conditions(da, "b", 2.0, 3.0, 9.0)          # copies on demand instead of writing through the read-only array
+    assert edited.values is not host and edited.values[-1, 1, 2, 3] == 9.0 and host.sum() == 0.0 and rs.tensor_for(edited, 1) is None
+
+
 def test_predict_one_step_accepts_a_pathlib_path(tmp_path):
     m = BoringGlobalModel(ic_source="synthetic")
     first, paths = m.rollout(T0, n_steps=1, save=True, save_config={"output_dir": str(tmp_path)})

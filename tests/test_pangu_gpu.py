@@ -10,6 +10,8 @@ everywhere; ~8e-5 -> <= 3e-4), "bf16x3h" / "f16x3qh" (additionally the MLP hidde
 asserted <= 1e-3), and "f16" (single-term speed mode, observed ~1.2e-3, does NOT meet the bar -> held to 5e-3).
 Stage-level tests use max-abs / max-abs-ref.
 """
+from pathlib import Path
+
 import numpy as np
 import pytest
 import torch
@@ -266,6 +268,41 @@ def test_pangu_model_rollout_through_reference_api(toy, tmp_path):
     fc = m.forecast(t0, n_steps=2, channels=["t2m", "z500"])
     assert fc.shape == (3, 2, g.n_lat, g.n_lon)
     assert np.allclose(fc.values[2, 0], pred.values[1, 68], rtol=1e-4, atol=1e-3)
+
+
+def test_rollout_keeps_the_state_in_hbm_and_saves_the_same_files(toy, tmp_path):
+    """``rollout`` feeds ``pred`` straight back -- the state must not be uploaded again after step 0
+    (core/models/utils.py: ResidentState), the per-step files are written by a worker thread while the next step runs, and both must be
+    invisible: same values as the upload path, files byte-identical to a synchronous ``save_forecast`` of the same predictions."""
+    import datetime
+    import filecmp
+    from skyrim_amd.common import save_forecast
+    from skyrim_amd.core.models.pangu import PanguModel
+    from skyrim_amd.core.models.utils import perturb_initial_conditions
+    g, params, x = toy
+    t0 = datetime.datetime(2024, 5, 13, 18, 0)
+    m = PanguModel(ic_source="gfs", geom=g, params=params)
+    cfg = {"output_dir": str(tmp_path / "async"), "file_type": "netcdf"}
+    pred, paths = m.rollout(t0, n_steps=3, save=True, save_config=cfg)
+    assert m.model.io_counters == {"state_uploads": 1, "resident_hits": 2}        # one H2D (the initial condition), then HBM-resident
+    assert not pred.values.flags.writeable
+    # the upload path: every prediction handed back as a COPY (a different array: it must be uploaded), saved synchronously
+    m2 = PanguModel(ic_source="gfs", geom=g, params=params)
+    p2, t, src = None, t0, m2.source_label
+    for k in range(3):
+        p2 = m2.predict_one_step(t, initial_condition=None if p2 is None else p2.copy())
+        sync = save_forecast(p2, "pangu", t, t + m2.time_step, src, config={"output_dir": str(tmp_path / "sync"), "file_type": "netcdf", "forecast_id": cfg["forecast_id"]})
+        assert Path(sync).name == Path(paths[k]).name and filecmp.cmp(sync, paths[k], shallow=False), k
+        t, src = t + m2.time_step, "file"
+    assert m2.model.io_counters == {"state_uploads": 3, "resident_hits": 0}
+    assert np.array_equal(p2.values, pred.values)
+    # an edited prediction is a copy (the delivered array is read-only), and a copy is uploaded
+    with pytest.raises(ValueError):
+        pred.values[1, 0, 0, 0] = 0.0
+    edited = perturb_initial_conditions(pred, "t2m", 48.0, 11.5, 250.0)
+    assert edited.values.flags.writeable and edited.values[1, 68].min() <= 250.0
+    nxt = m.predict_one_step(t, initial_condition=edited)
+    assert m.model.io_counters["state_uploads"] == 2 and np.array_equal(nxt.values[0], edited.values[1])
 
 
 def test_forecast_interleaves_6h_and_24h_networks(toy):

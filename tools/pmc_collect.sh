@@ -17,7 +17,7 @@ run() {   # <pass name> <counters...> --
   timeout 600 rocprofv3 --pmc "${ctrs[@]}" --kernel-trace --output-format csv -d "$out" -o p -- python bench.py "$@" > "$out.log" 2>&1
   echo "pass $name rc=$? $(ls $out 2>/dev/null | tr '\n' ' ')"
 }
-ARGS=("$@" --steps 2 --warmup 1 --no-cpu-baseline --no-parity --no-alt-modes)
+ARGS=("$@" --steps 2 --warmup 1 --no-cpu-baseline --no-parity --no-alt-modes --no-models)
 run sq1 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE -- "${ARGS[@]}"
 run sq2 SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INSTS_VALU SQ_INSTS_LDS SQ_INST_CYCLES_VMEM GRBM_GUI_ACTIVE -- "${ARGS[@]}"
 run fetch FETCH_SIZE -- "${ARGS[@]}"

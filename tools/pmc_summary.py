@@ -87,7 +87,8 @@ def main(prefix, out, *rest):
     total = {"hbm_GB_per_step": round(sum(e["hbm_GB"] * e["calls"] for e in res.values()) / steps, 2),
              "write_GB_per_step": round(sum(e["write_GB"] * e["calls"] for e in res.values()) / steps, 2),
              "kernel_ms_per_step_under_pmc": round(sum(e["avg_us"] * e["calls"] for e in res.values()) / steps / 1e3, 2), "steps": steps}
-    json.dump({"total": total, "kernels": res}, open(out, "w"), indent=1)
+    stamp = rest[rest.index("--stamp") + 1] if "--stamp" in rest else None      # e.g. sha256 of the profiled .so, so that bench.py can say what was profiled
+    json.dump({"total": total, "stamp": stamp, "kernels": res}, open(out, "w"), indent=1)
     print(json.dumps(total))
     for k, e in res.items():
         print(f"{e['avg_us']:9.1f} us x{e['calls']:4d}  mfma {e['mfma_busy_pct']}%  wait {e['wait_pct']} stall {e['stall_pct']} issue {e['issue_pct']}  "
