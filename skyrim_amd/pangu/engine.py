@@ -23,14 +23,17 @@ PREC_F16X3 = 3
 PREC_F16X3_Q = 4
 PREC_F16X3_QH = 5
 PRECISIONS = {"bf16x3": PREC_BF16X3, "f16": PREC_F16, "bf16x3h": PREC_BF16X3_H16,
-              "f16x3": PREC_F16X3, "f16x3q": PREC_F16X3_Q, "f16x3qh": PREC_F16X3_QH, "f16x2": PREC_F16X3_Q, "f16x2q": PREC_F16X3_Q}
+              "f16x3": PREC_F16X3, "f16x3q": PREC_F16X3_Q, "f16x3qh": PREC_F16X3_QH, "f16x2": PREC_F16X3_Q, "f16x2q": PREC_F16X3_Q, "f16x2m": PREC_F16X3_Q}
 # per-layer MFMA term plan (skpangu_config.term_plan): bit l = layer l + 1 runs proj / fc1 / fc2 with two terms (weights as ONE fp16 plane)
-TERM_PLANS = {"f16x2": 0x0F, "f16x2q": 0xFF}       # bits 4-7: the layer's QKV with ONE term (stream hi plane x weight hi plane)
-# default "f16x2q": fp16 hi/lo ACTIVATION planes, every block weight as ONE fp16 plane -- proj / fc1 / fc2 with 2 MFMA terms (A_hi W + A_lo W),
-# QKV with one (stream hi plane x weight hi plane) -- attention single-term fp16; ~5e-4 per-channel error per step (bar 1e-3).  "f16x2" keeps the
-# QKV weights as hi/lo planes (2 terms, same error level: the weight rounding of the other three linears dominates), "f16x3q" is 3 terms in
-# proj / fc1 / fc2 (~1e-4); "bf16x3" is the wide-range alternative (activations beyond fp16's 65504).
-DEFAULT_PRECISION = "f16x2q"
+TERM_PLANS = {"f16x2m": 0x66, "f16x2": 0x0F, "f16x2q": 0xFF}       # bits 4-7: the layer's QKV with ONE term (stream hi plane x weight hi plane)
+# default "f16x2m" (mixed plan 0x66): fp16 hi/lo ACTIVATION planes everywhere; in layers 2 and 3 (C = 384: 12 of the 16 blocks, three quarters
+# of the step's FLOPs) every block weight is ONE fp16 plane -- proj / fc1 / fc2 with 2 MFMA terms (A_hi W + A_lo W), QKV with one -- while layers
+# 1 and 4 (full resolution, next to the input / output) keep hi/lo weights (3 terms, QKV 2).  Rounding the weights of layers 1 / 4 is what costs
+# accuracy (oracle emulation, per-channel error of one step on three grids: layers 2 + 3 rounded 1.7e-4 .. 3.2e-4, layer 1 alone 3.3e-4 .. 5.8e-4,
+# layer 4 alone 3.1e-4 .. 3.8e-4, all four + QKV 4.9e-4 .. 9.2e-4; at 721x1440 the all-layers plan reaches 8.4e-4 after four steps -- inside the
+# 1e-3 bar, without margin).  "f16x2q" / "f16x2" are the all-layers plans (0xFF / 0x0F), "f16x3q" is three terms everywhere (~1e-4),
+# "bf16x3" the wide-range alternative (activations beyond fp16's 65504).
+DEFAULT_PRECISION = "f16x2m"
 
 _LIB_PATH = Path(__file__).resolve().parent.parent / "lib" / "libskyrim_pangu.so"
 
@@ -117,7 +120,7 @@ def make_config(geom: PanguGeometry, precision: str = DEFAULT_PRECISION, roll_si
     if roll_sign not in (-1, 1):
         raise ValueError("roll_sign is -1 (Swin: roll by -(1,3,6) first) or +1 (pseudocode as written)")
     plan = TERM_PLANS.get(precision, 0) if term_plan is None else int(term_plan)
-    if plan and (precision not in ("f16x2", "f16x2q", "f16x3", "f16x3q") or mlp != "fused"):
+    if plan and (precision not in ("f16x2m", "f16x2", "f16x2q", "f16x3", "f16x3q") or mlp != "fused"):
         raise ValueError("a term plan needs fp16 planes (f16x2 / f16x3 / f16x3q) and the fused kernels")
     return SkConfig(geom.n_lat, geom.n_lon, PRECISIONS[precision], roll_sign, PAD_MODES[geom.pad], float(mask_value), MLP_MODES[mlp], plan)
 
@@ -158,7 +161,7 @@ class PanguEngine:
         self.geom = geom or PanguGeometry()
         self.precision = precision
         self.device = torch.device(device)
-        if mlp != "fused" and precision in ("f16x2", "f16x2q") and term_plan is None:
+        if mlp != "fused" and precision in TERM_PLANS and term_plan is None:
             term_plan = 0                                   # the tiled-GEMM path has no two-term kernels: "f16x2" + split = f16x3q + split
         self.cfg = make_config(self.geom, precision, roll_sign, mask_value, mlp, term_plan)
         self.mlp = mlp

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     assert lib.skpangu_abi_version() == 3
 
 
-@pytest.mark.parametrize("prec", ["bf16x3", "f16", "f16x3q", "f16x3qh", "f16x2", "f16x2q"])
+@pytest.mark.parametrize("prec", ["bf16x3", "f16", "f16x3q", "f16x3qh", "f16x2", "f16x2q", "f16x2m"])
 @pytest.mark.parametrize("grid", [(49, 192), (721, 1440)])
 def test_param_table_matches_host_spec(grid, prec):
     g = PanguGeometry(*grid)

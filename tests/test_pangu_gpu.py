@@ -2,9 +2,9 @@
 
 Tolerances (floating point; stated per the north star): per-channel max|y - ref| / max|ref| <= 1e-3.
 Modes (skyrim_amd/pangu/engine.py PRECISIONS): hi/lo split GEMMs with fp16 single-term attention --
-"f16x2q" (default: fp16 activation planes x ONE fp16 weight plane -- proj / fc1 / fc2 2 MFMA terms, QKV one; oracle emulation of
-exactly this rounding plan: 4.9e-4 after one step, 5.0e-4 after four; observed 5.0e-4 / 5.3e-4 -> asserted <= 8e-4), "f16x2" (the same with hi/lo QKV
-weights: 4.3e-4 / 5.3e-4),
+"f16x2m" (default: term plan 0x66 -- layers 2 / 3 with ONE fp16 weight plane: proj / fc1 / fc2 2 MFMA terms, QKV one; layers 1 / 4 three terms;
+oracle emulation 1.8e-4 .. 2.8e-4 per step on the small grids, 3.9e-4 .. 5.0e-4 measured over four full-size steps -> asserted <= 7e-4), "f16x2q" / "f16x2" (the all-layers plans 0xFF / 0x0F: 4e-4 .. 9e-4 on the
+small grids, 8.4e-4 after four full-size steps -> held to the 1e-3 bar only),
 "f16x3q" (the same with 3 terms; observed ~1e-4 -> asserted <= 3e-4), "f16x3", "bf16x3" (3 terms
 everywhere; ~8e-5 -> <= 3e-4), "bf16x3h" / "f16x3qh" (additionally the MLP hidden as one fp16 plane; ~4e-4 ->
 asserted <= 1e-3), and "f16" (single-term speed mode, observed ~1.2e-3, does NOT meet the bar -> held to 5e-3).
@@ -22,9 +22,9 @@ from skyrim_amd.pangu.spec import PanguGeometry, init_synthetic, synthetic_state
 
 pytestmark = pytest.mark.gpu
 
-STAGE_TOL = {"f16x2q": 1.5e-3, "f16x2": 1.5e-3, "bf16x3": 5e-4, "f16x3": 5e-4, "f16x3q": 5e-4, "bf16x3h": 2e-3, "f16x3qh": 2e-3, "f16": 4e-3}
-DEF_TOL = 8e-4       # the default mode's asserted step error (STEP_TOL[DEFAULT_PRECISION])
-STEP_TOL = {"f16x2q": 8e-4, "f16x2": 8e-4, "bf16x3": 3e-4, "f16x3": 3e-4, "f16x3q": 3e-4, "bf16x3h": 1e-3, "f16x3qh": 1e-3, "f16": 5e-3}   # 3-term modes: 3x inside the bar
+STAGE_TOL = {"f16x2m": 1.5e-3, "f16x2q": 1.5e-3, "f16x2": 1.5e-3, "bf16x3": 5e-4, "f16x3": 5e-4, "f16x3q": 5e-4, "bf16x3h": 2e-3, "f16x3qh": 2e-3, "f16": 4e-3}
+DEF_TOL = 7e-4       # the default mode's asserted step error (STEP_TOL[DEFAULT_PRECISION]); measured at 721x1440: 3.9e-4 (1 step) .. 5.0e-4 (4 steps)
+STEP_TOL = {"f16x2m": 7e-4, "f16x2q": 1e-3, "f16x2": 1e-3, "bf16x3": 3e-4, "f16x3": 3e-4, "f16x3q": 3e-4, "bf16x3h": 1e-3, "f16x3qh": 1e-3, "f16": 5e-3}   # 3-term modes: 3x inside the bar
 
 
 def rel(a, b):
@@ -40,7 +40,7 @@ def ref(toy):
     return taps, y
 
 
-@pytest.fixture(scope="module", params=["f16x2q", "f16x2", "f16x3q", "bf16x3", "f16x3", "bf16x3h", "f16x3qh", "f16"])
+@pytest.fixture(scope="module", params=["f16x2m", "f16x2q", "f16x2", "f16x3q", "bf16x3", "f16x3", "bf16x3h", "f16x3qh", "f16"])
 def eng(request, toy):
     from skyrim_amd.pangu.engine import PanguEngine
     g, params, x = toy
@@ -169,7 +169,7 @@ def test_profile_hooks_cover_the_step(eng, toy):
     eng.profile(False)
     by = {s["name"]: s for s in stats}
     # 3-term modes: projection + MLP as one kernel per block (fused_block.hip); the others: proj, fc1, fc2 as separate launches
-    mlp = "proj_mlp_r1" if eng.precision in ("f16x2q", "f16x2", "f16x3q", "f16x3", "bf16x3") else "fc1_r1"
+    mlp = "proj_mlp_r1" if eng.precision in ("f16x2m", "f16x2q", "f16x2", "f16x3q", "f16x3", "bf16x3") else "fc1_r1"
     assert by[mlp]["launches"] == 12 and by["qkv_r0"]["launches"] == 4 and by["embed"]["launches"] == 1
     assert by["fc2_r1"]["launches"] == by["proj_r1"]["launches"] == (0 if mlp == "proj_mlp_r1" else 12)
     assert all(s["total_ms"] > 0 for s in stats if s["launches"])
@@ -221,6 +221,26 @@ def test_full_size_24h_rollout_vs_oracle(full, full_ref):
     assert torch.isfinite(state).all()
     print("full-size 24-h rollout: max per-channel rel err per step " + " ".join(f"{e:.3e}" for e in errs) + f" ({DEFAULT_PRECISION})")
     assert max(errs) < DEF_TOL, errs
+
+
+@pytest.mark.timeout(1500)
+def test_full_size_term_plans_vs_oracle(full, full_ref):
+    """The per-layer term plans at 721x1440 over the 24-h rollout (one oracle run serves all): every plan inside the 1e-3 bar at every
+    step; printed so that the choice of the default plan rests on full-size numbers."""
+    from skyrim_amd.pangu.engine import PanguEngine
+    g, params, x, _ = full
+    for plan in (0xFF, 0x6F, 0x66, 0x0F, 0x00):
+        e = PanguEngine(g, "f16x3q", "cuda:0", term_plan=plan)
+        e.load_params(params)
+        state = x.cuda().clone()
+        errs = []
+        for k in range(4):
+            e.step(state, out=state)
+            errs.append(O.per_channel_rel_err(state.cpu(), full_ref[k]).max().item())
+        print(f"full-size term plan {plan:#04x}: max per-channel rel err per step " + " ".join(f"{v:.3e}" for v in errs))
+        assert max(errs) < 1e-3, (hex(plan), errs)
+        del e
+        torch.cuda.empty_cache()
 
 
 @pytest.mark.timeout(900)
@@ -435,7 +455,7 @@ def test_per_layer_term_plan(toy, ref, plan):
     eng.load_params(params)
     assert eng.term_plan == plan
     err = O.per_channel_rel_err(eng.step(x.cuda()).cpu(), y_ref).max().item()
-    assert err < (3e-4 if plan == 0 else 8e-4), (hex(plan), err)
+    assert err < (3e-4 if plan == 0 else 1e-3), (hex(plan), err)
     base = PanguEngine(g, "f16x3q", "cuda:0")
     base.load_params(params)
     for layer, tap in ((1, "embed"), (2, "down"), (3, "down"), (4, "up")):
