@@ -95,8 +95,7 @@ class GraphcastTimeLoop:
         self.cfg = cfg or GraphcastConfig()
         self.engine = GraphcastEngine(self.cfg, device)
         if params is None:
-            params = weights.resolve("SKYRIM_GRAPHCAST_WEIGHTS", lambda p: torch.load(p, map_location="cpu"),
-                                     lambda: init_synthetic(self.cfg, seed), "graphcast")
+            params = weights.resolve("SKYRIM_GRAPHCAST_WEIGHTS", self._load, lambda: init_synthetic(self.cfg, seed), "graphcast")
         self.engine.load_params(params)
         names = CHANNELS if self.cfg.n_vars == len(CHANNELS) else [f"c{i}" for i in range(self.cfg.n_vars)]
         self.in_channel_names = list(names)
@@ -107,6 +106,19 @@ class GraphcastTimeLoop:
         lat = torch.deg2rad(torch.linspace(90.0, -90.0, self.cfg.n_lat, dtype=torch.float64, device=self.device))[:, None]
         lon = torch.deg2rad(torch.arange(self.cfg.n_lon, dtype=torch.float64, device=self.device) * (360.0 / self.cfg.n_lon))[None, :]
         self._sin_lat, self._cos_lat, self._lon = torch.sin(lat), torch.cos(lat), lon
+
+    def _load(self, path: str) -> dict:
+        """A torch file of the slot dict (``spec.param_spec``), or a directory in the shape of deepmind's release: ``params.npz`` -- the
+        haiku parameters as ``checkpoint.dump`` flattens them (``params:<module path>:<name>``; '/'-joined keys are accepted too) -- and
+        ``stats.npz`` with ``mean``, ``std``, ``diff_std`` (per variable, the engine's channel order) and ``static`` (2, n_lat, n_lon:
+        normalised surface geopotential and land-sea mask), optionally ``in_perm`` / ``out_perm``; mapped by ``checkpoint.load``."""
+        import os
+        if os.path.isdir(path):
+            from . import checkpoint
+            st = np.load(os.path.join(path, "stats.npz"))
+            kw = {k: st[k] for k in ("mean", "std", "diff_std", "static", "in_perm", "out_perm") if k in st.files}
+            return checkpoint.load(os.path.join(path, "params.npz"), self.cfg, **kw)
+        return torch.load(path, map_location="cpu")
 
     @property
     def device(self):
