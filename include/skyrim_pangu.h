@@ -65,7 +65,13 @@ typedef struct skpangu_config {
                       activations still hi/lo pairs (a third fewer MFMAs, half the LDS and LDS-DMA bytes; 2^-12 relative weight rounding:
                       ~5e-4 per-channel error per step with all four bits set against ~1e-4 with none).  Bit 4 + l (F16X3_Q only): the
                       layer's QKV linear runs with ONE term, stream hi plane x weight hi plane.  0: three terms everywhere (QKV two).
-                      Host modes: "f16x2" = F16X3_Q with term_plan 0x0F, "f16x2q" = 0xFF. */
+                      Host modes: "f16x2m" (default) = F16X3_Q with term_plan 0x66, "f16x2" = 0x0F, "f16x2q" = 0xFF. */
+    /* three more conventions the pseudocode leaves open; each is applied once, in skpangu_prepare (no kernel depends on them) */
+    int surface_last;    /* 0 (default): the surface slab is token level 0 (PatchRecovery reads it at index 0); 1: it is the LAST level
+                            (PatchEmbedding's concatenate((input, input_surface)) as written).  The stream keeps its storage order; the window
+                            tables pair the levels in the logical order */
+    int qkv_order;       /* packing of the qkv Linear's 3C output rows in the MASTER weights: 0 (default) (3, heads, head_dim); 1 (heads, 3, head_dim) */
+    int bias_transposed; /* 0 (default): bias gathered as [query][key] from position_index; 1: [key][query] */
 } skpangu_config;
 
 typedef struct skpangu_sizes {

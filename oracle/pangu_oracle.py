@@ -66,6 +66,12 @@ class Conventions:
     pad: str = "centre"          # "centre" | "back"
     roll_sign: int = -1          # -1: torch.roll(x, -half) first (Swin);  +1: torch.roll(x, +half) first (pseudocode as written)
     mask_value: float = MASK_VALUE
+    # three more points the public pseudocode does not settle (each a prepare-time permutation in the engine, skpangu_config):
+    surface: str = "first"       # token level of the surface slab: "first" (PatchRecovery reads the surface at index 0) | "last"
+                                 # (PatchEmbedding's concatenate((input, input_surface)) taken literally: upper-air levels first)
+    qkv_order: str = "3hd"       # packing of the qkv Linear's 3C outputs: (3, heads, head_dim) | "h3d" = (heads, 3, head_dim)
+    bias_index: str = "qk"       # the (144 x 144) earth-specific bias gathered as [query][key] | "kq" = [key][query] (the transposed reading
+                                 # of position_index: which of its two meshgrid axes is the query)
 
 
 DEFAULT = Conventions()
@@ -183,18 +189,22 @@ def shifted_window_mask(Z: int, Hp: int, Wp: int, dtype, conv: Conventions = DEF
     return mask[:, :1]
 
 
-def earth_attention(p, x_win, n_types, heads, mask, emu=None):
+def earth_attention(p, x_win, n_types, heads, mask, emu=None, conv: Conventions = DEFAULT):
     """x_win: (types, nW, 144, C) -> same shape.  EarthAttention3D.forward."""
     T, nW, L, C = x_win.shape
     hd = C // heads
     scale = hd ** -0.5
     qkv = _linear(x_win, p["attn.qkv.weight"], p["attn.qkv.bias"], emu)
-    qkv = qkv.reshape(T, nW, L, 3, heads, hd).permute(3, 0, 1, 4, 2, 5)
+    if conv.qkv_order == "3hd":
+        qkv = qkv.reshape(T, nW, L, 3, heads, hd).permute(3, 0, 1, 4, 2, 5)
+    else:                                                             # "h3d": (heads, 3, head_dim)
+        qkv = qkv.reshape(T, nW, L, heads, 3, hd).permute(4, 0, 1, 3, 2, 5)
     q, k, v = qkv[0] * scale, qkv[1], qkv[2]
     att = _emulate(q, emu) @ _emulate(k, emu).transpose(-1, -2)      # (T, nW, heads, L, L)
     idx = position_index().reshape(-1)
     bias = p["attn.bias_table"][idx]                                  # (L*L, T, heads)
-    bias = bias.reshape(L, L, n_types, heads).permute(2, 3, 0, 1)      # (T, heads, L, L)
+    bias = bias.reshape(L, L, n_types, heads)
+    bias = bias.permute(2, 3, 0, 1) if conv.bias_index == "qk" else bias.permute(2, 3, 1, 0)      # (T, heads, query, key)
     att = att + bias[:, None]
     if mask is not None:
         att = att + mask[:, :, None]
@@ -222,7 +232,7 @@ def earth_block(p, x, res, heads, roll, emu=None, conv: Conventions = DEFAULT):
     nZ, nH, nW = Z // wz, Hp // wh, W // ww
     xw = x.reshape(nZ, wz, nH, wh, nW, ww, C).permute(0, 2, 4, 1, 3, 5, 6)
     xw = xw.reshape(nZ * nH, nW, wz * wh * ww, C)
-    xw = earth_attention(p, xw, nZ * nH, heads, mask, emu)
+    xw = earth_attention(p, xw, nZ * nH, heads, mask, emu, conv)
     x = xw.reshape(nZ, nH, nW, wz, wh, ww, C).permute(0, 3, 1, 4, 2, 5, 6).reshape(Z, Hp, W, C)
     if roll:
         x = torch.roll(x, shifts=(-sg * (wz // 2), -sg * (wh // 2), -sg * (ww // 2)), dims=(0, 1, 2))
@@ -234,7 +244,7 @@ def earth_block(p, x, res, heads, roll, emu=None, conv: Conventions = DEFAULT):
     return x + F.layer_norm(h, (C,), p["norm2.weight"], p["norm2.bias"], LN_EPS)
 
 
-def patch_embed(p, g: Geometry, upper, surface, emu=None):
+def patch_embed(p, g: Geometry, upper, surface, emu=None, conv: Conventions = DEFAULT):
     """upper (5,13,H,W), surface (4,H,W), both already normalised -> (Z*H1*W1, 192)."""
     _, lt, lb = g.lat_pad
     _, zf, zb = g.lev_pad
@@ -245,7 +255,7 @@ def patch_embed(p, g: Geometry, upper, surface, emu=None):
                   p["embed.conv.bias"], stride=PATCH)[0]              # (C, 7, H1, W1)
     xs = F.conv2d(_emulate(surf, emu)[None], _emulate(p["embed.conv_surface.weight"], emu),
                   p["embed.conv_surface.bias"], stride=PATCH[1:])[0]   # (C, H1, W1)
-    x = torch.cat([xs[:, None], xu], 1)                                # surface slab first
+    x = torch.cat([xs[:, None], xu], 1) if conv.surface == "first" else torch.cat([xu, xs[:, None]], 1)      # where the surface slab sits
     return x.permute(1, 2, 3, 0).reshape(-1, x.shape[0])
 
 
@@ -272,14 +282,15 @@ def upsample(p, g: Geometry, x, emu=None):
     return _linear(x, p["up.linear2.weight"], None, emu)
 
 
-def patch_recover(p, g: Geometry, x, emu=None):
+def patch_recover(p, g: Geometry, x, emu=None, conv: Conventions = DEFAULT):
     """x (Z*H1*W1, 384) -> upper (5,13,H,W), surface (4,H,W) (still normalised)."""
     Z, H1, W1 = g.res(1)
     C = x.shape[-1]
     x = x.reshape(Z, H1, W1, C).permute(3, 0, 1, 2)
-    up = F.conv_transpose3d(_emulate(x[:, 1:], emu)[None], _emulate(p["recover.conv.weight"], emu),
+    xu, xs = (x[:, 1:], x[:, 0]) if conv.surface == "first" else (x[:, :-1], x[:, -1])
+    up = F.conv_transpose3d(_emulate(xu, emu)[None], _emulate(p["recover.conv.weight"], emu),
                             p["recover.conv.bias"], stride=PATCH)[0]
-    sf = F.conv_transpose2d(_emulate(x[:, 0], emu)[None], _emulate(p["recover.conv_surface.weight"], emu),
+    sf = F.conv_transpose2d(_emulate(xs, emu)[None], _emulate(p["recover.conv_surface.weight"], emu),
                             p["recover.conv_surface.bias"], stride=PATCH[1:])[0]
     _, lt, _ = g.lat_pad
     _, zf, _ = g.lev_pad
@@ -311,7 +322,7 @@ def forward(params: dict, x: torch.Tensor, emu=None, taps: dict | None = None, c
     std = params["norm.std"][:, None, None]
     xn = (x - mean) / std
     upper, surface = split_state(xn)
-    t = patch_embed(params, g, upper, surface, emu)
+    t = patch_embed(params, g, upper, surface, emu, conv)
     if taps is not None:
         taps["embed"] = t
     for i in range(DEPTHS[0]):
@@ -335,7 +346,7 @@ def forward(params: dict, x: torch.Tensor, emu=None, taps: dict | None = None, c
     if taps is not None:
         taps["layer4"] = t
     t = torch.cat([skip, t], -1)
-    up, sf = patch_recover(params, g, t, emu)
+    up, sf = patch_recover(params, g, t, emu, conv)
     y = torch.cat([up.reshape(-1, *up.shape[2:]), sf], 0)
     return y * std + mean
 

@@ -17,10 +17,10 @@ class PanguModel(GlobalModel):
 
     model_name = "pangu"
 
-    def __init__(self, *args, geom=None, precision: str = DEFAULT_PRECISION, device="cuda:0", params=None, **kwargs):
-        # extras beyond the reference's signature (all optional): grid geometry (default 721x1440),
-        # MFMA precision mode, device, and a parameter dict (default: SKYRIM_PANGU_WEIGHTS or seeded random init)
-        self._engine_kw = dict(geom=geom, precision=precision, device=device, params=params)
+    def __init__(self, *args, geom=None, precision: str = DEFAULT_PRECISION, device="cuda:0", params=None, conventions=None, **kwargs):
+        # extras beyond the reference's signature (all optional): grid geometry (default 721x1440), MFMA precision mode, device, a
+        # parameter dict (default: SKYRIM_PANGU_WEIGHTS or seeded random init) and the open conventions (PanguTimeLoop)
+        self._engine_kw = dict(geom=geom, precision=precision, device=device, params=params, conventions=conventions)
         super().__init__(self.model_name, *args, **kwargs)
 
     def build_model(self):

@@ -29,6 +29,8 @@ bool make_geom(const skpangu_config& c, Geom& g) {
     if (c.mask_value > 0.f || c.mask_value < -60000.f) return false;      // the mask lives in the fp16 bias tiles
     if (c.mlp_mode != 0 && c.mlp_mode != 1) return false;
     if (c.term_plan < 0 || c.term_plan > 0xFF) return false;
+    if ((c.surface_last | c.qkv_order | c.bias_transposed) & ~1) return false;
+    g.surface_last = c.surface_last; g.qkv_order = c.qkv_order; g.bias_transposed = c.bias_transposed;
     g.roll_sign = c.roll_sign > 0 ? 1 : -1;
     g.mask_value = c.mask_value == 0.f ? -100.f : c.mask_value;
     g.n_lat = c.n_lat; g.n_lon = c.n_lon; g.n_levels = 13; g.n_channels = 69; g.surf0 = 65;
@@ -133,6 +135,7 @@ struct Engine : IEngine {
     bool two_term(int layer) const { return (plan2 >> layer) & 1; }
     bool qkv_one(int layer) const { return rt_qkv && ((plan2 >> (4 + layer)) & 1); }   // QKV with ONE term (stream hi plane x weight hi plane)
     T* zrow = nullptr;
+    float *qkv_w_tmp = nullptr, *qkv_b_tmp = nullptr;
 
     // ---- per-stage timing with HIP events on the launch stream (bench.py roofline leg) ---- //
     enum Cat { C_EMBED, C_QKV0, C_ATTN0, C_PROJ0, C_FC1_0, C_FC2_0, C_QKV1, C_ATTN1, C_PROJ1, C_FC1_1, C_FC2_1, C_DOWN, C_UP, C_RECOVER, C_COUNT };
@@ -258,6 +261,7 @@ struct Engine : IEngine {
         for (int r = 0; r < 2; ++r)
             for (int roll = 0; roll < 2; ++roll) { w.widx[r][roll] = a.take<int>(g.mwin[r]); w.winv[r][roll] = a.take<int>(g.ntok[r]); }
         zrow = a.take<T>(4096);
+        qkv_w_tmp = a.take<float>((size_t)3 * 384 * 384); qkv_b_tmp = a.take<float>(3 * 384);      // canonical-order copy of a qkv Linear (qkv_order = 1)
         prep_bytes = (a.off + 255) / 256 * 256;
     }
 
@@ -335,22 +339,27 @@ struct Engine : IEngine {
             for (int i = 0; i < kDepths[layer]; ++i, ++b) {
                 const std::string p = "layer" + std::to_string(layer + 1) + ".block" + std::to_string(i) + ".";
                 const BlockW<T>& bw = w.blk[b];
-                CK(lin(bw.qkv, P_(m, p + "attn.qkv.weight"), 3 * c, c, c, 1, s));
+                const float *qkv_w = P_(m, p + "attn.qkv.weight"), *qkv_bias = P_(m, p + "attn.qkv.bias");
+                if (g.qkv_order) {              // master rows packed (heads, 3, head_dim): one canonical copy, consumed by the preps below (stream order)
+                    CK(prep_qkv_rows(qkv_w, qkv_bias, qkv_w_tmp, qkv_b_tmp, c, heads, s));
+                    qkv_w = qkv_w_tmp; qkv_bias = qkv_b_tmp;
+                }
+                CK(lin(bw.qkv, qkv_w, 3 * c, c, c, 1, s));
                 CK(lin(bw.proj, P_(m, p + "attn.proj.weight"), c, c, c, 1, s));
                 CK(lin(bw.fc1, P_(m, p + "mlp.fc1.weight"), 4 * c, c, c, 1, s));
                 CK(lin(bw.fc2, P_(m, p + "mlp.fc2.weight"), c, 4 * c, 4 * c, 1, s));
                 if (hid16 && !std::is_same<T, f16>::value) CK((prep_weight<f16, 2>(P_(m, p + "mlp.fc2.weight"), const_cast<f16*>(bw.fc2h.w), bw.fc2h.plane, c, 4 * c, 4 * c, 4 * c, 1, 1, 1, s)));
                 if constexpr (P::NA == 2 && P::NW == 2) {
                     if (bw.projf) CK(prep_rowtile_weights<T>(P_(m, p + "attn.proj.weight"), const_cast<T*>(bw.projf), c, c, s));
-                    if (bw.qkvf) CK(prep_rowtile_weights<T>(P_(m, p + "attn.qkv.weight"), const_cast<T*>(bw.qkvf), 3 * c, c, s));
-                    if (bw.qkvh) CK(prep_rowtile_weights<T>(P_(m, p + "attn.qkv.weight"), const_cast<T*>(bw.qkvh), 3 * c, c, s, 1));
+                    if (bw.qkvf) CK(prep_rowtile_weights<T>(qkv_w, const_cast<T*>(bw.qkvf), 3 * c, c, s));
+                    if (bw.qkvh) CK(prep_rowtile_weights<T>(qkv_w, const_cast<T*>(bw.qkvh), 3 * c, c, s, 1));
                     if (bw.w1f) CK(prep_mlp_weights<T>(P_(m, p + "mlp.fc1.weight"), P_(m, p + "mlp.fc2.weight"), const_cast<T*>(bw.w1f), const_cast<T*>(bw.w2f), c, s));
                     if (bw.projh) {
                         CK(prep_rowtile_weights<T>(P_(m, p + "attn.proj.weight"), const_cast<T*>(bw.projh), c, c, s, 1));
                         CK(prep_mlp_weights<T>(P_(m, p + "mlp.fc1.weight"), P_(m, p + "mlp.fc2.weight"), const_cast<T*>(bw.w1h), const_cast<T*>(bw.w2h), c, s, 1));
                     }
                 }
-                CK(copyf(bw.qkv_b, P_(m, p + "attn.qkv.bias"), 3 * c, s));
+                CK(copyf(bw.qkv_b, qkv_bias, 3 * c, s));
                 CK(copyf(bw.proj_b, P_(m, p + "attn.proj.bias"), c, s));
                 CK(copyf(bw.fc1_b, P_(m, p + "mlp.fc1.bias"), 4 * c, s));
                 CK(copyf(bw.fc2_b, P_(m, p + "mlp.fc2.bias"), c, s));
@@ -358,8 +367,8 @@ struct Engine : IEngine {
                 CK(copyf(bw.n1_b, P_(m, p + "norm1.bias"), c, s));
                 CK(copyf(bw.n2_g, P_(m, p + "norm2.weight"), c, s));
                 CK(copyf(bw.n2_b, P_(m, p + "norm2.bias"), c, s));
-                if (attn2) CK(prep_bias_compact(P_(m, p + "attn.bias_table"), const_cast<f16*>(bw.bias_cmp), g.types[res], heads, g.nH[res], (i & 1) ? g.roll_sign : 0, g.mask_value, s));
-                else CK(prep_bias_expand(P_(m, p + "attn.bias_table"), const_cast<f16*>(bw.bias_exp), g.types[res], heads, g.nH[res], (i & 1) ? g.roll_sign : 0, g.mask_value, s));
+                if (attn2) CK(prep_bias_compact(P_(m, p + "attn.bias_table"), const_cast<f16*>(bw.bias_cmp), g.types[res], heads, g.nH[res], (i & 1) ? g.roll_sign : 0, g.mask_value, s, g.bias_transposed));
+                else CK(prep_bias_expand(P_(m, p + "attn.bias_table"), const_cast<f16*>(bw.bias_exp), g.types[res], heads, g.nH[res], (i & 1) ? g.roll_sign : 0, g.mask_value, s, g.bias_transposed));
             }
         }
         CK(copyf(w.down_g, P_(m, "down.norm.weight"), 768, s));
@@ -378,7 +387,7 @@ struct Engine : IEngine {
         for (int r = 0; r < 2; ++r)
             for (int roll = 0; roll < 2; ++roll)
             {
-                CK(prep_window_index(const_cast<int*>(w.widx[r][roll]), g.Z, H[r], W[r], g.Hp[r], g.top[r], roll ? g.roll_sign : 0, s));
+                CK(prep_window_index(const_cast<int*>(w.widx[r][roll]), g.Z, H[r], W[r], g.Hp[r], g.top[r], roll ? g.roll_sign : 0, s, g.surface_last));
                 CK(prep_window_inverse(w.widx[r][roll], g.mwin[r], const_cast<int*>(w.winv[r][roll]), s));
             }
         return hipSuccess;

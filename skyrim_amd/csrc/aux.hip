@@ -42,7 +42,7 @@ template hipError_t prep_weight<f16, 2>(const float*, f16*, long long, int, int,
 // regions of the Z window / latitude window that mixes wrapped and unwrapped rows -- the LAST one when the block
 // rolls by -(1,3,6) first (roll = -1), the FIRST one when it rolls by +(1,3,6) first (roll = +1); longitude is
 // periodic -> never masked.
-__global__ void prep_bias_expand_kernel(const float* __restrict__ table, f16* __restrict__ out, int types, int heads, int nH, int roll, float mask_value) {
+__global__ void prep_bias_expand_kernel(const float* __restrict__ table, f16* __restrict__ out, int types, int heads, int nH, int roll, float mask_value, int transposed) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long total = (long long)types * heads * 81 * 256;
     if (i >= total) return;
@@ -57,7 +57,8 @@ __global__ void prep_bias_expand_kernel(const float* __restrict__ table, f16* __
     const int q = qf * 16 + (lane & 15);
     const int zq = q / 72, hq = (q / 12) % 6, wq = q % 12;
     const int zk = key / 72, hk = (key / 12) % 6, wk = key % 12;
-    const int idx = (zq + 2 * zk) * (23 * 36) + (hq + 6 * hk) * 23 + (wq - wk + 11);
+    // transposed: the table is read as [key][query] -- the two meshgrid axes of position_index change roles
+    const int idx = transposed ? (zk + 2 * zq) * (23 * 36) + (hk + 6 * hq) * 23 + (wk - wq + 11) : (zq + 2 * zk) * (23 * 36) + (hq + 6 * hk) * 23 + (wq - wk + 11);
     float v = table[((long long)idx * types + type) * heads + head];
     if (roll) {
         const int zi = type / nH, hi = type % nH;
@@ -69,9 +70,9 @@ __global__ void prep_bias_expand_kernel(const float* __restrict__ table, f16* __
     out[i] = (f16)v;
 }
 
-hipError_t prep_bias_expand(const float* table, f16* out, int types, int heads, int nH, int roll, float mask_value, hipStream_t s) {
+hipError_t prep_bias_expand(const float* table, f16* out, int types, int heads, int nH, int roll, float mask_value, hipStream_t s, int transposed) {
     const long long total = (long long)types * heads * 81 * 256;
-    hipLaunchKernelGGL(prep_bias_expand_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, table, out, types, heads, nH, roll, mask_value);
+    hipLaunchKernelGGL(prep_bias_expand_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, table, out, types, heads, nH, roll, mask_value, transposed);
     return hipGetLastError();
 }
 
@@ -80,7 +81,7 @@ hipError_t prep_bias_expand(const float* table, f16* out, int types, int heads, 
 // four consecutive keys w_k .. w_k + 3 of one query are four consecutive ASCENDING entries), column 23 zero.  The shifted-window
 // mask depends on (type, z_q, z_k, h_q, h_k) only -- exactly a row -- and is folded into the row.  6.9 KB per (type, head) where the
 // expanded form takes 41 KB.
-__global__ void prep_bias_compact_kernel(const float* __restrict__ table, f16* __restrict__ out, int types, int heads, int nH, int roll, float mask_value) {
+__global__ void prep_bias_compact_kernel(const float* __restrict__ table, f16* __restrict__ out, int types, int heads, int nH, int roll, float mask_value, int transposed) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long total = (long long)types * heads * 3456;
     if (i >= total) return;
@@ -90,7 +91,10 @@ __global__ void prep_bias_compact_kernel(const float* __restrict__ table, f16* _
     if (e == 23) { out[i] = (f16)0.f; return; }
     const int rz = r / 36, rh = r % 36;
     const int zq = rz & 1, zk = rz >> 1, hq = rh % 6, hk = rh / 6;
-    float v = table[((long long)(r * 23 + (22 - e)) * types + type) * heads + head];
+    // row r, column e hold the bias of (z_q, z_k, h_q, h_k) and w_q - w_k + 11 = 22 - e; transposed: the table entry with the roles of
+    // query and key exchanged, i.e. (z_k + 2 z_q, h_k + 6 h_q, w_k - w_q + 11 = e)
+    const int src = transposed ? ((zk + 2 * zq) * 36 + (hk + 6 * hq)) * 23 + e : r * 23 + (22 - e);
+    float v = table[((long long)src * types + type) * heads + head];
     if (roll) {
         const int zi = type / nH, hi = type % nH;
         const int nZ = types / nH;
@@ -101,15 +105,15 @@ __global__ void prep_bias_compact_kernel(const float* __restrict__ table, f16* _
     out[i] = (f16)v;
 }
 
-hipError_t prep_bias_compact(const float* table, f16* out, int types, int heads, int nH, int roll, float mask_value, hipStream_t s) {
+hipError_t prep_bias_compact(const float* table, f16* out, int types, int heads, int nH, int roll, float mask_value, hipStream_t s, int transposed) {
     const long long total = (long long)types * heads * 3456;
-    hipLaunchKernelGGL(prep_bias_compact_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, table, out, types, heads, nH, roll, mask_value);
+    hipLaunchKernelGGL(prep_bias_compact_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, table, out, types, heads, nH, roll, mask_value, transposed);
     return hipGetLastError();
 }
 
 // Window gather table: row m = win*144 + t of the (padded, rolled, window-partitioned) token grid
 // -> source token row, or -1 for latitude padding.  win = (zi*nH + hi)*nW + wi, t = (tz*6 + th)*12 + tw.
-__global__ void prep_window_index_kernel(int* __restrict__ idx, int Z, int H, int W, int Hp, int top, int roll) {
+__global__ void prep_window_index_kernel(int* __restrict__ idx, int Z, int H, int W, int Hp, int top, int roll, int surface_last) {
     const int nH = Hp / 6, nW = W / 12;
     const long long total = (long long)(Z / 2) * nH * nW * WIN_TOKENS;
     const long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -122,12 +126,32 @@ __global__ void prep_window_index_kernel(int* __restrict__ idx, int Z, int H, in
     if (roll < 0) { pz = (pz + 1) % Z; ph = (ph + 3) % Hp; pw = (pw + 6) % W; }
     if (roll > 0) { pz = (pz + Z - 1) % Z; ph = (ph + Hp - 3) % Hp; pw = (pw + W - 6) % W; }
     const int h = ph - top;
-    idx[m] = (h >= 0 && h < H) ? (pz * H + h) * W + pw : -1;
+    // pz is the LOGICAL level (windows, roll and mask act on it); the stream stores the surface slab at level 0 in either convention:
+    // with the surface as the last logical level, logical k < Z - 1 is upper-air slab k = storage k + 1, logical Z - 1 is storage 0
+    const int sz = surface_last ? (pz + 1) % Z : pz;
+    idx[m] = (h >= 0 && h < H) ? (sz * H + h) * W + pw : -1;
 }
 
-hipError_t prep_window_index(int* idx, int Z, int H, int W, int Hp, int top, int roll, hipStream_t s) {
+hipError_t prep_window_index(int* idx, int Z, int H, int W, int Hp, int top, int roll, hipStream_t s, int surface_last) {
     const long long total = (long long)(Z / 2) * (Hp / 6) * (W / 12) * WIN_TOKENS;
-    hipLaunchKernelGGL(prep_window_index_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, idx, Z, H, W, Hp, top, roll);
+    hipLaunchKernelGGL(prep_window_index_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, idx, Z, H, W, Hp, top, roll, surface_last);
+    return hipGetLastError();
+}
+
+// qkv Linear stored with its 3C output rows packed (heads, 3, head_dim): rewritten in the (3, heads, head_dim) order every kernel assumes
+__global__ void prep_qkv_rows_kernel(const float* __restrict__ w, const float* __restrict__ b, float* __restrict__ wo, float* __restrict__ bo, int C, int heads) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = 3LL * C * C;
+    if (i >= total) return;
+    const int k = (int)(i % C), row = (int)(i / C);                // canonical row = which * C + head * hd + d
+    const int hd = C / heads, which = row / C, head = (row % C) / hd, d = row % hd;
+    const int src = (head * 3 + which) * hd + d;
+    wo[i] = w[(long long)src * C + k];
+    if (k == 0) bo[row] = b[src];
+}
+hipError_t prep_qkv_rows(const float* w, const float* b, float* w_out, float* b_out, int C, int heads, hipStream_t s) {
+    const long long total = 3LL * C * C;
+    hipLaunchKernelGGL(prep_qkv_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, b, w_out, b_out, C, heads);
     return hipGetLastError();
 }
 

@@ -14,6 +14,7 @@ struct Geom {
     int ntok[2], mwin[2];                                 // tokens, padded window tokens (nwin*144)
     int roll_sign;                                        // shifted-window blocks roll by roll_sign * (1, 3, 6) first (-1: Swin, +1: pseudocode as written)
     float mask_value;                                     // additive shifted-window mask (-100)
+    int surface_last, qkv_order, bias_transposed;         // prepare-time conventions (skyrim_pangu.h)
 };
 
 template <class T>
@@ -108,9 +109,10 @@ template <class T> hipError_t merge_planes(const T* planes, long long plane, flo
 // prepare-time helpers (aux.hip)
 template <class T, int NW>
 hipError_t prep_weight(const float* src, T* dst, long long plane, int N, int K, int ldd, long long sn, long long sk, int blocked, int perm, hipStream_t);
-hipError_t prep_bias_expand(const float* table, f16* out, int types, int heads, int nH, int roll, float mask_value, hipStream_t);   // roll: 0 | -1 | +1
-hipError_t prep_bias_compact(const float* table, f16* out, int types, int heads, int nH, int roll, float mask_value, hipStream_t);
-hipError_t prep_window_index(int* idx, int Z, int H, int W, int Hp, int top, int roll, hipStream_t);
+hipError_t prep_bias_expand(const float* table, f16* out, int types, int heads, int nH, int roll, float mask_value, hipStream_t, int transposed = 0);   // roll: 0 | -1 | +1
+hipError_t prep_bias_compact(const float* table, f16* out, int types, int heads, int nH, int roll, float mask_value, hipStream_t, int transposed = 0);
+hipError_t prep_qkv_rows(const float* w, const float* b, float* w_out, float* b_out, int C, int heads, hipStream_t);   // (heads, 3, hd) -> (3, heads, hd) rows
+hipError_t prep_window_index(int* idx, int Z, int H, int W, int Hp, int top, int roll, hipStream_t, int surface_last = 0);
 hipError_t prep_window_inverse(const int* idx, int n, int* inv, hipStream_t);
 hipError_t prep_reciprocal(const float* src, float* dst, int n, hipStream_t);
 template <class T> hipError_t merge_stats(const T* x, long long plane, float2* stats, int Z, int H1, int W1, int H2, int W2, int C, float eps, hipStream_t);

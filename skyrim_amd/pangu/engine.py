@@ -40,7 +40,8 @@ _LIB_PATH = Path(__file__).resolve().parent.parent / "lib" / "libskyrim_pangu.so
 
 class SkConfig(ctypes.Structure):
     _fields_ = [("n_lat", ctypes.c_int), ("n_lon", ctypes.c_int), ("precision", ctypes.c_int),
-                ("roll_sign", ctypes.c_int), ("pad_mode", ctypes.c_int), ("mask_value", ctypes.c_float), ("mlp_mode", ctypes.c_int), ("term_plan", ctypes.c_int)]
+                ("roll_sign", ctypes.c_int), ("pad_mode", ctypes.c_int), ("mask_value", ctypes.c_float), ("mlp_mode", ctypes.c_int), ("term_plan", ctypes.c_int),
+                ("surface_last", ctypes.c_int), ("qkv_order", ctypes.c_int), ("bias_transposed", ctypes.c_int)]
 
 
 class SkSizes(ctypes.Structure):
@@ -113,8 +114,11 @@ PAD_MODES = {"centre": 0, "back": 1}
 MLP_MODES = {"fused": 0, "split": 1}
 
 
+SURFACE, QKV_ORDERS, BIAS_INDEX = {"first": 0, "last": 1}, {"3hd": 0, "h3d": 1}, {"qk": 0, "kq": 1}
+
+
 def make_config(geom: PanguGeometry, precision: str = DEFAULT_PRECISION, roll_sign: int = -1, mask_value: float = -100.0, mlp: str = "fused",
-                term_plan: int | None = None) -> SkConfig:
+                term_plan: int | None = None, surface: str = "first", qkv_order: str = "3hd", bias_index: str = "qk") -> SkConfig:
     """``skpangu_config`` of a geometry + the switchable conventions (include/skyrim_pangu.h; oracle: pangu_oracle.Conventions).
     ``term_plan`` overrides the precision name's per-layer term plan (bit l: layer l + 1 runs proj / fc1 / fc2 with two MFMA terms)."""
     if roll_sign not in (-1, 1):
@@ -122,7 +126,8 @@ def make_config(geom: PanguGeometry, precision: str = DEFAULT_PRECISION, roll_si
     plan = TERM_PLANS.get(precision, 0) if term_plan is None else int(term_plan)
     if plan and (precision not in ("f16x2m", "f16x2", "f16x2q", "f16x3", "f16x3q") or mlp != "fused"):
         raise ValueError("a term plan needs fp16 planes (f16x2 / f16x3 / f16x3q) and the fused kernels")
-    return SkConfig(geom.n_lat, geom.n_lon, PRECISIONS[precision], roll_sign, PAD_MODES[geom.pad], float(mask_value), MLP_MODES[mlp], plan)
+    return SkConfig(geom.n_lat, geom.n_lon, PRECISIONS[precision], roll_sign, PAD_MODES[geom.pad], float(mask_value), MLP_MODES[mlp], plan,
+                    SURFACE[surface], QKV_ORDERS[qkv_order], BIAS_INDEX[bias_index])
 
 
 def query_sizes(geom: PanguGeometry, precision: str = DEFAULT_PRECISION, cfg: SkConfig | None = None) -> SkSizes:
@@ -151,10 +156,12 @@ class PanguEngine:
     """Device-resident Pangu 6-h step.  ``step`` maps a (69, n_lat, n_lon) fp32 CUDA tensor to the next state."""
 
     def __init__(self, geom: PanguGeometry | None = None, precision: str = DEFAULT_PRECISION, device: str | torch.device = "cuda:0",
-                 roll_sign: int = -1, mask_value: float = -100.0, mlp: str = "fused", term_plan: int | None = None):
+                 roll_sign: int = -1, mask_value: float = -100.0, mlp: str = "fused", term_plan: int | None = None,
+                 surface: str = "first", qkv_order: str = "3hd", bias_index: str = "qk"):
         """``roll_sign`` / ``mask_value`` / ``geom.pad``: the conventions the public pseudocode leaves open.
         ``mlp``: "fused" (default; one kernel per MLP in the 3-term modes, csrc/fused_mlp.hip) or "split" (two tiled GEMMs).
-        ``term_plan``: per-layer two-term mask (include/skyrim_pangu.h); None = the precision name's own ("f16x2": all four layers)."""
+        ``term_plan``: per-layer two-term mask (include/skyrim_pangu.h); None = the precision name's own ("f16x2": all four layers).
+        ``surface`` / ``qkv_order`` / ``bias_index``: three more open conventions (oracle: Conventions of the same names), prepare-time only."""
         self.lib = load_library()
         if not torch.cuda.is_available():
             raise RuntimeError("PanguEngine needs a ROCm GPU (gfx950); there is no CPU fallback")
@@ -163,7 +170,7 @@ class PanguEngine:
         self.device = torch.device(device)
         if mlp != "fused" and precision in TERM_PLANS and term_plan is None:
             term_plan = 0                                   # the tiled-GEMM path has no two-term kernels: "f16x2" + split = f16x3q + split
-        self.cfg = make_config(self.geom, precision, roll_sign, mask_value, mlp, term_plan)
+        self.cfg = make_config(self.geom, precision, roll_sign, mask_value, mlp, term_plan, surface, qkv_order, bias_index)
         self.mlp = mlp
         self.term_plan = self.cfg.term_plan
         self.sizes = query_sizes(self.geom, precision, self.cfg)

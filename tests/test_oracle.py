@@ -123,6 +123,26 @@ def test_switchable_conventions_roll_sign_mask_value_pad(toy):
         assert torch.isfinite(y).all() and O.per_channel_rel_err(y, base).max() > 1e-3, conv
     # -100 vs -1000 is numerically the same mask (exp underflows either way)
     assert O.per_channel_rel_err(O.forward(params, x, conv=O.Conventions(mask_value=-1000.0)), base).max() < 1e-5
+    # surface slab position, qkv packing, bias index reading: each changes the result ...
+    for conv in (O.Conventions(surface="last"), O.Conventions(qkv_order="h3d"), O.Conventions(bias_index="kq")):
+        y = O.forward(params, x, conv=conv)
+        assert torch.isfinite(y).all() and O.per_channel_rel_err(y, base).max() > 1e-3, conv
+    # ... and the two that are pure re-labellings of parameters are EXACTLY the default network on re-labelled parameters:
+    # qkv rows (3, heads, hd) -> (heads, 3, hd); bias table entries with query and key exchanged
+    ph, pk = dict(params), dict(params)
+    idx_qk = O.position_index()                                           # [q, k]
+    swap = torch.empty(3312, dtype=torch.long)
+    swap[idx_qk.reshape(-1)] = idx_qk.T.reshape(-1)                       # entry for (q, k) <- entry for (k, q); consistent: idx depends on the pair only
+    assert torch.equal(swap[swap], torch.arange(3312))
+    for name, w in params.items():
+        if name.endswith("attn.qkv.weight") or name.endswith("attn.qkv.bias"):
+            C3 = w.shape[0]
+            heads = C3 // 3 // 32
+            ph[name] = w.reshape(3, heads, 32, *w.shape[1:]).transpose(0, 1).reshape(w.shape)
+        if name.endswith("attn.bias_table"):
+            pk[name] = w[swap]
+    assert torch.equal(O.forward(ph, x, conv=O.Conventions(qkv_order="h3d")), base)
+    assert torch.allclose(O.forward(pk, x, conv=O.Conventions(bias_index="kq")), base, rtol=0, atol=0)
     gb = O.Geometry(721, 1440, "back")
     assert gb.lat_pad == (724, 0, 3) and gb.res(1) == (8, 181, 360) and spec.PanguGeometry(721, 1440, "back").pad_top(1) == 0
     assert spec.PanguGeometry(721, 1440).pad_top(1) == 2 and spec.PanguGeometry(721, 1440).lat_pad_top == 1

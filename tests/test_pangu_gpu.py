@@ -401,14 +401,18 @@ def test_step_through_the_custom_op_boundary(toy):
         torch.ops.skyrim_hip.pangu_step(eng._ctx.value, xd.double(), out)
 
 
-@pytest.mark.parametrize("conv", [dict(roll_sign=+1), dict(pad="back"), dict(roll_sign=+1, pad="back", mask_value=-1000.0)])
+@pytest.mark.parametrize("conv", [dict(roll_sign=+1), dict(pad="back"), dict(roll_sign=+1, pad="back", mask_value=-1000.0),
+                                  dict(surface="last"), dict(qkv_order="h3d"), dict(bias_index="kq"),
+                                  dict(surface="last", qkv_order="h3d", bias_index="kq", roll_sign=+1)])
 def test_switchable_conventions_match_the_oracle(toy, conv):
-    """roll_sign / pad / mask_value (include/skyrim_pangu.h skpangu_config <-> oracle Conventions): the engine follows the oracle
-    under each setting, and does NOT match the oracle of the other setting -- the test that flips the convention."""
+    """roll_sign / pad / mask_value / surface / qkv_order / bias_index (include/skyrim_pangu.h skpangu_config <-> oracle Conventions): the
+    engine follows the oracle under each setting, and does NOT match the oracle of the other setting -- the test that flips the
+    convention.  The last three are applied in skpangu_prepare only (window tables, a row permutation, the bias gather)."""
     from skyrim_amd.pangu.engine import PanguEngine
     g0, params, x = toy
     g = PanguGeometry(g0.n_lat, g0.n_lon, conv.get("pad", "centre"))
-    eng = PanguEngine(g, device="cuda:0", roll_sign=conv.get("roll_sign", -1), mask_value=conv.get("mask_value", -100.0))
+    eng = PanguEngine(g, device="cuda:0", roll_sign=conv.get("roll_sign", -1), mask_value=conv.get("mask_value", -100.0),
+                      surface=conv.get("surface", "first"), qkv_order=conv.get("qkv_order", "3hd"), bias_index=conv.get("bias_index", "qk"))
     eng.load_params(params)
     y = eng.step(x.cuda()).cpu()
     want = O.forward(params, x, conv=O.Conventions(**conv))
