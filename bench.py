@@ -163,6 +163,41 @@ def api_rollout_rate(precision, geom, params, x_host, dev, n=6):
                     + str(bool(torch.isfinite(torch.from_numpy(out.values[-1])).all()))}
 
 
+def members_on_streams(precision, geom, params, x_host, dev, n_members=2, steps=6):
+    """Ensemble throughput on ONE GPU (BASELINE configs[4] runs 6-7 members per GPU): ``n_members`` members, each with its own engine
+    workspace, advanced on separate HIP streams so that one member's bandwidth-bound kernels (QKV, attention, row gathers / stores) can
+    run beside the other's MFMA-bound ones -- against the same members advanced back to back on one stream."""
+    from skyrim_amd.pangu.engine import PanguEngine
+    engs, xs = [], []
+    for m in range(n_members):
+        e = PanguEngine(geom, precision, dev)
+        e.load_params(params)
+        engs.append(e)
+        xs.append(x_host.to(dev) + 1e-3 * m)
+    streams = [torch.cuda.Stream(dev) for _ in range(n_members)]
+
+    def run(concurrent):
+        for e, x in zip(engs, xs):
+            e.step(x, x)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            for m in range(n_members):
+                if concurrent:
+                    with torch.cuda.stream(streams[m]):
+                        engs[m].step(xs[m], xs[m])
+                else:
+                    engs[m].step(xs[m], xs[m])
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / (steps * n_members)
+    for st in streams:
+        st.wait_stream(torch.cuda.current_stream(dev))
+    serial, conc = run(False), run(True)
+    return {"members": n_members, "member_steps_per_s_one_stream": 1.0 / serial, "member_steps_per_s_streams": 1.0 / conc,
+            "ms_per_member_step_one_stream": 1e3 * serial, "ms_per_member_step_streams": 1e3 * conc, "gain": serial / conc,
+            "finite": bool(all(torch.isfinite(x).all() for x in xs))}
+
+
 def predict_inclusive(precision, geom, params, dev, n_steps=4):
     """What ``Skyrim('pangu').predict(lead_time=24, save=...)`` costs end to end: ``GlobalModel.rollout`` (the call ``predict`` makes,
     core/skyrim.py) of 4 six-hour steps through ``predict_one_step`` / ``run_basic_inference`` -- every step delivered to the host as a
@@ -458,6 +493,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-alt-modes", action="store_true", help="skip the short runs of the other precision modes")
+    ap.add_argument("--members-per-gpu", type=int, default=2, help="pangu, N = 1: members advanced on separate streams in the members_per_gpu entry")
     ap.add_argument("--no-models", action="store_true", help="pangu, N = 1: skip the short SFNO / GraphCast runs reported under \"models\"")
     ap.add_argument("--members", type=int, default=0, help="pangu, --gpus > 1: ensemble members in total, sharded round-robin over the ranks "
                     "(BASELINE configs[4]: --gpus 8 --members 50 --save-every 1 --gather); default: one member per rank")
@@ -630,6 +666,7 @@ def main():
             eng = None
             torch.cuda.empty_cache()
             out["predict_inclusive"] = predict_inclusive(args.precision, geom, params, dev)
+            out["members_per_gpu"] = members_on_streams(args.precision, geom, params, x_host, dev, args.members_per_gpu)
             torch.cuda.empty_cache()
             out["modes"] = {m: dict(quick_mode(m, geom, params, x_host, dev), note=MODE_NOTES[m][1])
                             for m in ("f16x2q", "f16x3q", "bf16x3", "f16") if m != args.precision}

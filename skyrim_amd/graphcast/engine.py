@@ -91,7 +91,10 @@ class GraphcastEngine:
             raise ValueError("shard = (rank, world) with 0 <= rank < world <= n_lat")
         self.reduce_fn = reduce_fn
         self.gather_fn = gather_fn
-        self.shard_mesh = self.world > 1 and not os.environ.get("SKGC_REPLICATED_MESH")
+        # SKGC_EXERCISE_COLLECTIVES=1: run the two exchanges of the sharded step even with ONE rank (the collectives then copy a rank's data onto
+        # itself): the cheapest proof that the default torch.distributed / RCCL branch loads and runs on a 1-GPU box (tests/test_rccl_gpu.py)
+        self.exercise = bool(os.environ.get("SKGC_EXERCISE_COLLECTIVES")) and self.world == 1
+        self.shard_mesh = (self.world > 1 or self.exercise) and not os.environ.get("SKGC_REPLICATED_MESH")
         if not torch.cuda.is_available():
             raise RuntimeError("GraphcastEngine needs an MI355X: the GraphCast path has no CPU fallback")
         if self.cfg.latent % 8 != 0:
@@ -345,7 +348,7 @@ class GraphcastEngine:
             else:
                 self._mlp("g2m.edge", [(self.e1_0, None, L), (self.vg, self.g2m_s, L), (self.vm0, self.g2m_r, L)], self.E1, self.e1, label="encoder")
             self._segsum(self.e1, self.g2m_off, self.agg_m, self.graph.n_mesh)
-            if self.world > 1:                       # the one exchange of a grid-sharded step: sum the partial aggregates over ranks
+            if self.world > 1 or self.exercise:      # the one exchange of a grid-sharded step: sum the partial aggregates over ranks
                 self._mark("exchange")
                 if self.reduce_fn is not None:
                     self.reduce_fn(self.agg_m)

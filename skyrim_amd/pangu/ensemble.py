@@ -32,11 +32,17 @@ def _world():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
+def _group_is_up():
+    """A process group exists -- possibly of ONE rank: the collectives are then issued all the same (a rank's data lands on itself),
+    which is how the RCCL path is exercised on a 1-GPU box (tests/test_rccl_gpu.py).  Without a group nothing is communicated."""
+    return dist.is_available() and dist.is_initialized()
+
+
 def sum_over_ranks(t: torch.Tensor, how: str = "allgather") -> torch.Tensor:
     """Sum of one tensor per rank, on every rank, in place.  "allgather": all_gather of the partials + local sum in rank order
     (direct exchange over the xGMI full mesh; identical bits on every rank); "allreduce": ring all-reduce."""
     w = _world()
-    if w == 1:
+    if not _group_is_up():
         return t
     if how == "allreduce":
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
@@ -70,7 +76,7 @@ def gather_members(local_states: list[torch.Tensor], n_members: int) -> torch.Te
     w = _world()
     per = (n_members + w - 1) // w
     local = torch.stack(local_states + [torch.zeros_like(local_states[0])] * (per - len(local_states)))
-    if w > 1:
+    if _group_is_up():
         buf = torch.empty((w * per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
         dist.all_gather_into_tensor(buf, local)
         buf = buf.view((w, per) + tuple(local.shape[1:]))
