@@ -135,7 +135,7 @@ def test_forecast_cli_on_the_hip_path_and_restart_from_its_file(tmp_path, monkey
     monkeypatch.setitem(MODELS, "pangu", ToyPangu)
     res = CliRunner().invoke(cli.main, ["-m", "pangu", "-ic", "gfs", "-d", "20240513", "-t", "1800", "-l", "12", "-o", str(tmp_path)])
     assert res.exit_code == 0, res.output + repr(res.exception)
-    files = sorted(tmp_path.rglob("*.nc"))
+    files = sorted(tmp_path.rglob("*.nc"), key=lambda f: f.name.split("__")[2])          # by start time ("file" sorts before "synthetic")
     assert [f.name.split("__")[0] for f in files] == ["pangu", "pangu"] and files[0].name.endswith("20240513_18:00__20240514_00:00.nc")
     first, second = open_dataarray(str(files[0])), open_dataarray(str(files[1]))
     ic = torch.from_numpy(np.array(first.values[0]))
@@ -188,4 +188,4 @@ def test_multi_model_mean_on_real_engines_and_device_wind_speed():
     gp = GlobalPrediction(a, model_name="pangu")
     host = gp.wind_speed_field(1000, n_step=1)
     dev = gp.wind_speed_field(1000, n_step=1, device="cuda:0")
-    assert np.allclose(np.asarray(host), np.asarray(dev), rtol=1e-6)
+    assert dev.is_cuda and np.allclose(np.asarray(host), dev.cpu().numpy(), rtol=1e-6)
