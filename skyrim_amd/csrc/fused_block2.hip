@@ -7,7 +7,7 @@
 // error after one step, 5.3e-4 after four, bar 1e-3).  It removes a third of the MFMAs, HALF of the bytes that cross LDS
 // (the token tile lives in registers, only weights stream through LDS) and half of the LDS-DMA traffic.
 //
-// Two launch shapes (DESIGN.md 5.5 has the measurements, including what did NOT help):
+// Two launch shapes (DESIGN.md 5.4 has the measurements, including what did NOT help):
 //   DUO (default)   4-wave workgroups, TWO per CU (one wave of each on every SIMD), two LDS slots of one chunk each and two barriers per
 //                   32-unit chunk, exactly fused_block.hip's loop:  | fc1(j) | GELU(j) | fc2(j) |.  The hi-only chunk is 24 KB at C = 384,
 //                   so two workgroups fit a CU where the three-term kernel fits one; the two run free of each other.
