@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SKPANGU_ABI_VERSION 3
+#define SKPANGU_ABI_VERSION 4
 
 /* precision modes: how each matrix product is formed on the MFMA pipe */
 #define SKPANGU_PREC_BF16X3 0 /* bf16 hi/lo split, 3 MFMA terms, fp32 range (wide-range mode; ~8e-5 per-channel error per step) */
@@ -103,6 +103,14 @@ void skpangu_destroy(skpangu_ctx* ctx);
  * earth-specific bias expanded per window type with the shifted-window mask folded in, window
  * gather tables).  Replaces the ONNX-session construction of earth2mip.networks.pangu.load. */
 int skpangu_prepare(skpangu_ctx* ctx, const float* master_dev, void* stream);
+
+/* Calibration of a term plan (config.term_plan != 0; a no-op otherwise), after skpangu_prepare and with the same master blob.
+ * A Linear run with its weights as ONE fp16 plane drops A x (W - fp16(W)); over the tokens of a state that term has a mean, which is a
+ * constant row and belongs in the bias.  This runs one step on ``state_in_dev`` through the three-term kernels, takes the column means
+ * of the operand of every Linear the plan runs short, and adds (W - fp16(W)) x mean to that Linear's prepared bias (the master blob is
+ * not changed; calling again starts over from the master biases).  Measured on the CPU restatement with a calibration state different
+ * from the forecast's: the plan's error falls 2-3x.  No counterpart in the reference: it belongs to the operand format. */
+int skpangu_calibrate(skpangu_ctx* ctx, const float* master_dev, const float* state_in_dev, void* stream);
 
 /* One 6-h forecast step: state_out = Pangu6(state_in).  In-place (state_out == state_in) is allowed.
  * Replaces one iteration of the reference's TimeLoop generator (models/utils.py:34). */

@@ -100,6 +100,7 @@ struct IEngine {
     virtual ~IEngine() {}
     virtual hipError_t prepare(const float* master, hipStream_t s) = 0;
     virtual hipError_t step(const float* in, float* out, hipStream_t s) = 0;
+    virtual hipError_t calibrate(const float* master, const float* in, hipStream_t s) = 0;
     virtual hipError_t embed(const float* in, float* x1, hipStream_t s) = 0;
     virtual hipError_t block(int layer, int blk, float* x, hipStream_t s) = 0;
     virtual hipError_t down(const float* x1, float* x2, hipStream_t s) = 0;
@@ -136,6 +137,7 @@ struct Engine : IEngine {
     bool qkv_one(int layer) const { return rt_qkv && ((plan2 >> (4 + layer)) & 1); }   // QKV with ONE term (stream hi plane x weight hi plane)
     T* zrow = nullptr;
     float *qkv_w_tmp = nullptr, *qkv_b_tmp = nullptr;
+    float* cal_sum = nullptr;               // column sums of one GEMM operand (calibrate)
 
     // ---- per-stage timing with HIP events on the launch stream (bench.py roofline leg) ---- //
     enum Cat { C_EMBED, C_QKV0, C_ATTN0, C_PROJ0, C_FC1_0, C_FC2_0, C_QKV1, C_ATTN1, C_PROJ1, C_FC1_1, C_FC2_1, C_DOWN, C_UP, C_RECOVER, C_COUNT };
@@ -262,6 +264,7 @@ struct Engine : IEngine {
             for (int roll = 0; roll < 2; ++roll) { w.widx[r][roll] = a.take<int>(g.mwin[r]); w.winv[r][roll] = a.take<int>(g.ntok[r]); }
         zrow = a.take<T>(4096);
         qkv_w_tmp = a.take<float>((size_t)3 * 384 * 384); qkv_b_tmp = a.take<float>(3 * 384);      // canonical-order copy of a qkv Linear (qkv_order = 1)
+        cal_sum = a.take<float>(4 * 384);
         prep_bytes = (a.off + 255) / 256 * 256;
     }
 
@@ -487,6 +490,62 @@ struct Engine : IEngine {
         return op_recover<P>(g, w, wk.X1s, wk.X4s, out, wk, s);
     }
 
+    // ---- calibration of the term plan ---- //
+    // A GEMM that runs with its weights as ONE fp16 plane drops A x (W - fp16(W)).  Over the tokens of a state that term has a mean and a
+    // spread; the mean is a constant row vector and belongs in the bias.  calibrate() runs one step on `in` through the three-term kernels
+    // (the tiled path: every operand reaches HBM there), takes the column means of the operand of each GEMM that the plan runs short, and
+    // adds (W - fp16(W)) x mean to that Linear's bias.  Idempotent: the biases are re-read from the master first.
+    hipError_t calib_block(const float* m, int layer0, int i, T* xs, hipStream_t s) {
+        const int res = layer_res(layer0), C = layer_dim(layer0), heads = layer_heads(layer0);
+        const BlockW<T>& bw = w.blk[block_index(layer0, i)];
+        const int* widx = w.widx[res][i & 1];
+        const int ntok = g.ntok[res];
+        const float inv = 1.0f / (float)ntok;
+        // per-workgroup partial sums: Q / K / V are dead at every point a column sum is taken (before the QKV GEMM, after the attention)
+        float* scratch = reinterpret_cast<float*>(wk.q);
+        if (colsum_scratch_floats(ntok, 4 * C) * sizeof(float) > 3 * q_elems * sizeof(f16)) return hipErrorInvalidValue;
+        const std::string p = "layer" + std::to_string(layer0 + 1) + ".block" + std::to_string(i) + ".";
+        const bool t2 = two_term(layer0), q1 = qkv_one(layer0);
+        const float *qkv_w = P_(m, p + "attn.qkv.weight"), *qkv_bias = P_(m, p + "attn.qkv.bias");
+        if (g.qkv_order) { CK(prep_qkv_rows(qkv_w, qkv_bias, qkv_w_tmp, qkv_b_tmp, C, heads, s)); qkv_w = qkv_w_tmp; qkv_bias = qkv_b_tmp; }
+        CK(copyf(bw.qkv_b, qkv_bias, 3 * C, s));
+        CK(copyf(bw.proj_b, P_(m, p + "attn.proj.bias"), C, s));
+        CK(copyf(bw.fc1_b, P_(m, p + "mlp.fc1.bias"), 4 * C, s));
+        CK(copyf(bw.fc2_b, P_(m, p + "mlp.fc2.bias"), C, s));
+        if (q1) CK(colsum_planes<T>(xs, 0, 1, nullptr, ntok, C, scratch, cal_sum, s));                       // one-term QKV reads the stream's hi plane
+        CK((op_qkv<P>(g, bw, widx, res, xs, wk, s)));
+        if (q1) CK(bias_fold(qkv_w, cal_sum, inv, const_cast<float*>(bw.qkv_b), 3 * C, C, s));
+        AttnArgs<P> a{wk.q, wk.k, wk.vt, wk.qkv_plane, bw.bias_exp, bw.bias_cmp, wk.ao, wk.ao_plane, C, g.nwin[res], g.nW[res], heads};
+        CK(launch_attention<P>(a, s));
+        if (t2) CK(colsum_planes<T>(wk.ao, wk.ao_plane, 2, w.winv[res][i & 1], ntok, C, scratch, cal_sum, s));   // window rows of the real tokens
+        CK((op_proj<P>(g, bw, widx, res, xs, wk, s)));
+        if (t2) {
+            CK(bias_fold(P_(m, p + "attn.proj.weight"), cal_sum, inv, const_cast<float*>(bw.proj_b), C, C, s));
+            CK(colsum_planes<T>(xs, wk.xs_plane[res], 2, nullptr, ntok, C, scratch, cal_sum, s));             // the mid-block stream
+        }
+        CK((op_fc1<P>(g, bw, res, xs, wk, s)));
+        if (t2) {
+            CK(bias_fold(P_(m, p + "mlp.fc1.weight"), cal_sum, inv, const_cast<float*>(bw.fc1_b), 4 * C, C, s));
+            CK(colsum_planes<T>(wk.hid, wk.hid_plane, 2, nullptr, ntok, 4 * C, scratch, cal_sum, s));
+        }
+        CK((op_fc2<P>(g, bw, res, xs, wk, s)));
+        if (t2) CK(bias_fold(P_(m, p + "mlp.fc2.weight"), cal_sum, inv, const_cast<float*>(bw.fc2_b), C, 4 * C, s));
+        return hipSuccess;
+    }
+    hipError_t calibrate(const float* m, const float* in, hipStream_t s) override {
+        if (plan2 == 0) return hipSuccess;               // nothing runs short
+        if constexpr (std::is_same<P, PrecF16x3>::value) {
+            CK((op_embed<P>(g, w, in, wk.X1s, wk, s)));
+            for (int i = 0; i < kDepths[0]; ++i) CK(calib_block(m, 0, i, wk.X1s, s));
+            CK((op_down<P>(g, w, wk.X1s, wk.X2s, wk, s)));
+            for (int i = 0; i < kDepths[1]; ++i) CK(calib_block(m, 1, i, wk.X2s, s));
+            for (int i = 0; i < kDepths[2]; ++i) CK(calib_block(m, 2, i, wk.X2s, s));
+            CK((op_up<P>(g, w, wk.X2s, wk.X4s, wk, s)));
+            for (int i = 0; i < kDepths[3]; ++i) CK(calib_block(m, 3, i, wk.X4s, s));
+        }
+        return hipSuccess;
+    }
+
     hipError_t step(const float* in, float* out, hipStream_t s) override {
         mark(C_EMBED, s);
         CK((op_embed<P>(g, w, in, wk.X1s, wk, s)));
@@ -625,6 +684,12 @@ int skpangu_prepare(skpangu_ctx* ctx, const float* master_dev, void* stream) {
 }
 
 #define NEED_PREPARED() do { if (!ctx) return SKPANGU_E_ARG; if (!ctx->prepared) return SKPANGU_E_STATE; } while (0)
+
+int skpangu_calibrate(skpangu_ctx* ctx, const float* master_dev, const float* state_in, void* stream) {
+    NEED_PREPARED();
+    if (!master_dev || !state_in) return SKPANGU_E_ARG;
+    return (int)ctx->eng->calibrate(master_dev, state_in, (hipStream_t)stream);
+}
 
 int skpangu_step(skpangu_ctx* ctx, const float* in, float* out, void* stream) {
     NEED_PREPARED();

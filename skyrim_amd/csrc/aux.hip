@@ -174,6 +174,59 @@ hipError_t prep_reciprocal(const float* src, float* dst, int n, hipStream_t s) {
     return hipGetLastError();
 }
 
+// ---- calibration of a two-term plan (api.hip Engine::calibrate) ---- //
+// column sums of one GEMM operand in the blocked plane layout (hi, or hi + lo), over `rows` rows taken through `rowmap` when given:
+// per-workgroup partial sums, then one thread per column adds them in workgroup order (no atomics: the same state gives the same bits)
+template <class T>
+__global__ void colsum_planes_kernel(const T* __restrict__ x, long long plane, int nplanes, const int* __restrict__ rowmap, int rows, int K,
+                                     int rows_per_wg, float* __restrict__ partial) {
+    const int r0 = blockIdx.x * rows_per_wg, r1 = min(rows, r0 + rows_per_wg);
+    for (int c = threadIdx.x; c < K; c += blockDim.x) {
+        float acc = 0.f;
+        for (int r = r0; r < r1; ++r) {
+            const long long row = rowmap ? rowmap[r] : r;
+            const T* p = x + blk_off(row, c, K);
+            acc += (float)p[0];
+            if (nplanes == 2) acc += (float)p[plane];
+        }
+        partial[(long long)blockIdx.x * K + c] = acc;
+    }
+}
+__global__ void colsum_reduce_kernel(const float* __restrict__ partial, int nwg, int K, float* __restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= K) return;
+    float acc = 0.f;
+    for (int i = 0; i < nwg; ++i) acc += partial[(long long)i * K + c];
+    out[c] = acc;
+}
+size_t colsum_scratch_floats(int rows, int K) { return (size_t)((rows + 127) / 128) * K; }
+template <class T>
+hipError_t colsum_planes(const T* x, long long plane, int nplanes, const int* rowmap, int rows, int K, float* scratch, float* out, hipStream_t s) {
+    const int per = 128, nwg = (rows + per - 1) / per;
+    hipLaunchKernelGGL((colsum_planes_kernel<T>), dim3((unsigned)nwg), dim3(256), 0, s, x, plane, nplanes, rowmap, rows, K, per, scratch);
+    hipLaunchKernelGGL(colsum_reduce_kernel, dim3((K + 63) / 64), dim3(64), 0, s, scratch, nwg, K, out);
+    return hipGetLastError();
+}
+template hipError_t colsum_planes<f16>(const f16*, long long, int, const int*, int, int, float*, float*, hipStream_t);
+template hipError_t colsum_planes<bf16>(const bf16*, long long, int, const int*, int, int, float*, float*, hipStream_t);
+
+// bias[n] += sum_k (w[n][k] - fp16(w[n][k])) * colsum[k] * scale: the mean over the calibration rows of the term a one-plane weight drops
+__global__ void bias_fold_kernel(const float* __restrict__ w, const float* __restrict__ colsum, float scale, float* __restrict__ bias, int N, int K) {
+    const int n = blockIdx.x, lane = threadIdx.x;
+    float acc = 0.f;
+    for (int k = lane; k < K; k += 64) {
+        const float v = w[(long long)n * K + k];
+        acc += (v - (float)(f16)v) * colsum[k];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0) bias[n] += acc * scale;
+}
+hipError_t bias_fold(const float* w, const float* colsum, float scale, float* bias, int N, int K, hipStream_t s) {
+    hipLaunchKernelGGL(bias_fold_kernel, dim3(N), dim3(64), 0, s, w, colsum, scale, bias, N, K);
+    return hipGetLastError();
+}
+
 // fp32 -> 16-bit hi/lo planes (shadow of a residual stream handed in through the stage-level API)
 template <class T, int NPL>
 __global__ void split_planes_kernel(const float* __restrict__ x, T* __restrict__ planes, long long plane, long long n4, int C) {

@@ -115,6 +115,10 @@ hipError_t prep_qkv_rows(const float* w, const float* b, float* w_out, float* b_
 hipError_t prep_window_index(int* idx, int Z, int H, int W, int Hp, int top, int roll, hipStream_t, int surface_last = 0);
 hipError_t prep_window_inverse(const int* idx, int n, int* inv, hipStream_t);
 hipError_t prep_reciprocal(const float* src, float* dst, int n, hipStream_t);
+// calibration of a two-term plan: column sums of an operand in plane layout; the dropped weight residue times their mean folded into a bias
+template <class T> hipError_t colsum_planes(const T* x, long long plane, int nplanes, const int* rowmap, int rows, int K, float* scratch, float* out, hipStream_t);
+size_t colsum_scratch_floats(int rows, int K);
+hipError_t bias_fold(const float* w, const float* colsum, float scale, float* bias, int N, int K, hipStream_t);
 template <class T> hipError_t merge_stats(const T* x, long long plane, float2* stats, int Z, int H1, int W1, int H2, int W2, int C, float eps, hipStream_t);
 
 }  // namespace skp

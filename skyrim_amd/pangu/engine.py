@@ -22,17 +22,18 @@ PREC_BF16X3_H16 = 2
 PREC_F16X3 = 3
 PREC_F16X3_Q = 4
 PREC_F16X3_QH = 5
+# per-layer MFMA term plan (skpangu_config.term_plan): bit l = layer l + 1 runs proj / fc1 / fc2 with two terms (weights as ONE fp16 plane);
+# bits 4-7: the layer's QKV with ONE term (stream hi plane x weight hi plane)
+TERM_PLANS = {"f16x2m": 0x6F, "f16x2c": 0x66, "f16x2": 0x0F, "f16x2q": 0xFF}
 PRECISIONS = {"bf16x3": PREC_BF16X3, "f16": PREC_F16, "bf16x3h": PREC_BF16X3_H16,
-              "f16x3": PREC_F16X3, "f16x3q": PREC_F16X3_Q, "f16x3qh": PREC_F16X3_QH, "f16x2": PREC_F16X3_Q, "f16x2q": PREC_F16X3_Q, "f16x2m": PREC_F16X3_Q}
-# per-layer MFMA term plan (skpangu_config.term_plan): bit l = layer l + 1 runs proj / fc1 / fc2 with two terms (weights as ONE fp16 plane)
-TERM_PLANS = {"f16x2m": 0x66, "f16x2": 0x0F, "f16x2q": 0xFF}       # bits 4-7: the layer's QKV with ONE term (stream hi plane x weight hi plane)
-# default "f16x2m" (mixed plan 0x66): fp16 hi/lo ACTIVATION planes everywhere; in layers 2 and 3 (C = 384: 12 of the 16 blocks, three quarters
-# of the step's FLOPs) every block weight is ONE fp16 plane -- proj / fc1 / fc2 with 2 MFMA terms (A_hi W + A_lo W), QKV with one -- while layers
-# 1 and 4 (full resolution, next to the input / output) keep hi/lo weights (3 terms, QKV 2).  Rounding the weights of layers 1 / 4 is what costs
-# accuracy (oracle emulation, per-channel error of one step on three grids: layers 2 + 3 rounded 1.7e-4 .. 3.2e-4, layer 1 alone 3.3e-4 .. 5.8e-4,
-# layer 4 alone 3.1e-4 .. 3.8e-4, all four + QKV 4.9e-4 .. 9.2e-4; at 721x1440 the all-layers plan reaches 8.4e-4 after four steps -- inside the
-# 1e-3 bar, without margin).  "f16x2q" / "f16x2" are the all-layers plans (0xFF / 0x0F), "f16x3q" is three terms everywhere (~1e-4),
-# "bf16x3" the wide-range alternative (activations beyond fp16's 65504).
+              "f16x3": PREC_F16X3, "f16x3q": PREC_F16X3_Q, "f16x3qh": PREC_F16X3_QH, **{m: PREC_F16X3_Q for m in TERM_PLANS}}
+# default "f16x2m" (plan 0x6F): fp16 hi/lo ACTIVATION planes everywhere; proj / fc1 / fc2 of EVERY block with their weights as ONE fp16 plane
+# (2 MFMA terms, A_hi W + A_lo W); QKV with one term in layers 2 / 3 (C = 384: 12 of the 16 blocks) and two (hi/lo weights) in the
+# full-resolution layers 1 / 4, whose QKV rounding is what costs accuracy at 721x1440.  The term a one-plane Linear drops,
+# A x (W - fp16(W)), has its mean over a calibration state folded into the bias at load time (``PanguEngine.calibrate``): measured at
+# 721x1440 over four steps, plan 0xFF 8.4e-4 -> 7.4e-4, 0x66 5.0e-4 -> 2.9e-4, 0x0F 5.0e-4 (calibrated).  "f16x2c" keeps layers 1 / 4 at three
+# terms (0x66, round 3's first default), "f16x2q" / "f16x2" are the all-layers plans 0xFF / 0x0F, "f16x3q" is three terms everywhere
+# (~1e-4), "bf16x3" the wide-range alternative (activations beyond fp16's 65504).
 DEFAULT_PRECISION = "f16x2m"
 
 _LIB_PATH = Path(__file__).resolve().parent.parent / "lib" / "libskyrim_pangu.so"
@@ -57,7 +58,7 @@ class SkStageStat(ctypes.Structure):
 
 EXPORTS = [
     "skpangu_abi_version", "skpangu_error_string", "skpangu_query_sizes", "skpangu_param_info",
-    "skpangu_create", "skpangu_destroy", "skpangu_prepare", "skpangu_step", "skpangu_patch_embed",
+    "skpangu_create", "skpangu_destroy", "skpangu_prepare", "skpangu_calibrate", "skpangu_step", "skpangu_patch_embed",
     "skpangu_block", "skpangu_downsample", "skpangu_upsample", "skpangu_patch_recover",
     "skpangu_debug_buffer", "skpangu_profile", "skpangu_profile_read",
 ]
@@ -87,6 +88,7 @@ def load_library() -> ctypes.CDLL:
     lib.skpangu_destroy.argtypes = [vp]
     lib.skpangu_destroy.restype = None
     lib.skpangu_prepare.argtypes = [vp, vp, vp]
+    lib.skpangu_calibrate.argtypes = [vp, vp, vp, vp]
     lib.skpangu_step.argtypes = [vp, vp, vp, vp]
     lib.skpangu_patch_embed.argtypes = [vp, vp, vp, vp]
     lib.skpangu_block.argtypes = [vp, ci, ci, vp, vp]
@@ -124,7 +126,7 @@ def make_config(geom: PanguGeometry, precision: str = DEFAULT_PRECISION, roll_si
     if roll_sign not in (-1, 1):
         raise ValueError("roll_sign is -1 (Swin: roll by -(1,3,6) first) or +1 (pseudocode as written)")
     plan = TERM_PLANS.get(precision, 0) if term_plan is None else int(term_plan)
-    if plan and (precision not in ("f16x2m", "f16x2", "f16x2q", "f16x3", "f16x3q") or mlp != "fused"):
+    if plan and (precision not in (*TERM_PLANS, "f16x3", "f16x3q") or mlp != "fused"):
         raise ValueError("a term plan needs fp16 planes (f16x2 / f16x3 / f16x3q) and the fused kernels")
     return SkConfig(geom.n_lat, geom.n_lon, PRECISIONS[precision], roll_sign, PAD_MODES[geom.pad], float(mask_value), MLP_MODES[mlp], plan,
                     SURFACE[surface], QKV_ORDERS[qkv_order], BIAS_INDEX[bias_index])
@@ -150,6 +152,17 @@ def param_table(geom: PanguGeometry, precision: str = DEFAULT_PRECISION) -> list
                "skpangu_param_info")
         out.append((name.value.decode(), off.value, tuple(shape[j] for j in range(nd.value))))
     return out
+
+
+CALIBRATION_SEED = 20240
+
+
+def calibration_state(geom: PanguGeometry, mean: torch.Tensor, std: torch.Tensor, seed: int = CALIBRATION_SEED) -> torch.Tensor:
+    """The built-in calibration state of a term plan: mean_c + std_c x unit-variance smooth noise, from the model's OWN normalisation
+    constants and a fixed seed, so that a set of weights is always prepared the same way whatever it forecasts first."""
+    from .spec import smooth_noise
+    n = smooth_noise(geom, seed)
+    return (mean.reshape(-1, 1, 1).float().cpu() + std.reshape(-1, 1, 1).float().cpu() * n).contiguous()
 
 
 class PanguEngine:
@@ -200,8 +213,12 @@ class PanguEngine:
             raise ValueError(f"expected shape {tuple(shape)}, got {tuple(t.shape)}")
         return ctypes.c_void_p(t.data_ptr())
 
-    def load_params(self, params: dict[str, torch.Tensor]):
-        """Pack fp32 master parameters into the library's blob layout, upload and prepare."""
+    def load_params(self, params: dict[str, torch.Tensor], calibration: "torch.Tensor | str | None" = "synthetic"):
+        """Pack fp32 master parameters into the library's blob layout, upload and prepare.
+
+        ``calibration`` (engines with a term plan only): the state the short Linears' biases are calibrated on (``calibrate``) --
+        "synthetic" (default): ``calibration_state`` built from the parameters' own normalisation constants, the same for every
+        forecast; a (69, n_lat, n_lon) tensor: that state (e.g. a real analysis); None / "off": no calibration."""
         table = param_table(self.geom, self.precision)
         with torch.cuda.device(self.device):
             master = torch.zeros(self.sizes.master_floats, dtype=torch.float32, device=self.device)
@@ -212,7 +229,32 @@ class PanguEngine:
                 master[off:off + t.numel()] = t.reshape(-1).to(self.device, torch.float32)
             _check(self.lib.skpangu_prepare(self._ctx, master.data_ptr(), self._stream()), "skpangu_prepare")
             torch.cuda.current_stream(self.device).synchronize()
+        self._master = master if self.term_plan else None       # calibrate() re-reads weights and biases from it
+        self.calibrated_on = None
+        if self.term_plan and calibration is not None and not (isinstance(calibration, str) and calibration == "off"):
+            if isinstance(calibration, str):
+                if calibration != "synthetic":
+                    raise ValueError(f"calibration = {calibration!r}: expected 'synthetic', 'off', None or a state tensor")
+                state = calibration_state(self.geom, params["norm.mean"], params["norm.std"])
+            else:
+                state = calibration
+            self.calibrate(state)
+            self.calibrated_on = "synthetic" if isinstance(calibration, str) else "state"
         del master
+
+    def calibrate(self, state: torch.Tensor):
+        """Fold the mean of the term each one-plane Linear drops, A x (W - fp16(W)), into its bias: one step on ``state`` through the
+        three-term kernels, column means of every short Linear's operand, bias += (W - fp16(W)) x mean (include/skyrim_pangu.h:
+        skpangu_calibrate).  A no-op for engines without a term plan.  Calling again starts over from the master biases."""
+        if not self.term_plan:
+            return
+        if self._master is None:
+            raise RuntimeError("load_params() first")
+        with torch.cuda.device(self.device):
+            x = state.to(self.device, torch.float32).contiguous()
+            _check(self.lib.skpangu_calibrate(self._ctx, self._master.data_ptr(), self._chk_dev(x, self.state_shape), self._stream()),
+                   "skpangu_calibrate")
+            torch.cuda.current_stream(self.device).synchronize()
 
     def step(self, x: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
         if out is None:

@@ -206,17 +206,22 @@ def init_synthetic(g: PanguGeometry, seed: int = 0) -> dict[str, torch.Tensor]:
     return params
 
 
-def synthetic_state(g: PanguGeometry, seed: int = 0, member: int | None = None) -> torch.Tensor:
-    """(69, n_lat, n_lon) fp32 state: mean_c + std_c * (9x9 box-smoothed N(0,1), unit variance).
-    ``member`` adds the ensemble perturbation 1e-3 * std_c * N(0,1; seed 1000+member)."""
+def smooth_noise(g: PanguGeometry, seed: int) -> torch.Tensor:
+    """(69, n_lat, n_lon) unit-variance fields: 9x9 box-smoothed N(0,1), periodic in longitude."""
     gen = torch.Generator().manual_seed(seed)
-    mean, std = channel_stats()
     n = torch.randn(g.n_channels, g.n_lat, g.n_lon, generator=gen)
     k = 9
     n = torch.nn.functional.pad(n[None], (k // 2, k // 2, 0, 0), mode="circular")
     n = torch.nn.functional.pad(n, (0, 0, k // 2, k // 2), mode="replicate")
     n = torch.nn.functional.avg_pool2d(n, k, stride=1)[0]
-    n = n / n.flatten(1).std(1)[:, None, None]
+    return n / n.flatten(1).std(1)[:, None, None]
+
+
+def synthetic_state(g: PanguGeometry, seed: int = 0, member: int | None = None) -> torch.Tensor:
+    """(69, n_lat, n_lon) fp32 state: mean_c + std_c * (9x9 box-smoothed N(0,1), unit variance).
+    ``member`` adds the ensemble perturbation 1e-3 * std_c * N(0,1; seed 1000+member)."""
+    mean, std = channel_stats()
+    n = smooth_noise(g, seed)
     x = mean[:, None, None] + std[:, None, None] * n
     if member is not None:
         g2 = torch.Generator().manual_seed(1000 + member)

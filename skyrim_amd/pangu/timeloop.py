@@ -56,7 +56,8 @@ class PanguTimeLoop:
     out_channel_names = list(CHANNELS)
 
     def __init__(self, params: dict | None = None, geom: PanguGeometry | None = None, precision: str = DEFAULT_PRECISION,
-                 device: str | torch.device = "cuda:0", seed: int = 0, params24: dict | None = None, conventions: dict | None = None):
+                 device: str | torch.device = "cuda:0", seed: int = 0, params24: dict | None = None, conventions: dict | None = None,
+                 calibration: "torch.Tensor | str | None" = None):
         """``params``: 6-h network (default: ``SKYRIM_PANGU_WEIGHTS`` state dict or seeded random init).
         ``params24`` (optional, or ``SKYRIM_PANGU_WEIGHTS_24``): the 24-h network; when present a multi-step
         generator interleaves the two like earth2mip's Pangu loop does (every 4th step is a 24-h step from the state
@@ -64,18 +65,23 @@ class PanguTimeLoop:
         (base.py:105-107); ``rollout`` re-creates the loop every step and therefore only ever uses the 6-h network."""
         # ``conventions``: the points the public pseudocode leaves open and a real pangu_weather_6.onnx settles -- roll_sign, mask_value,
         # surface, qkv_order, bias_index (PanguEngine; DESIGN.md 2); padding placement is ``geom.pad``
+        # ``calibration``: the state a term plan's biases are calibrated on (PanguEngine.load_params): "synthetic" (default; the
+        # built-in state from the weights' own normalisation constants), "off", or a (69, n_lat, n_lon) state such as a real analysis;
+        # ``SKYRIM_PANGU_CALIBRATION=off|synthetic`` sets it from the environment
         self.geom = geom or PanguGeometry()
+        if calibration is None:
+            calibration = os.environ.get("SKYRIM_PANGU_CALIBRATION", "synthetic")
         conventions = dict(conventions or {})
         self.engine = PanguEngine(self.geom, precision, device, **conventions)
         if params is None:
             params = weights.resolve("SKYRIM_PANGU_WEIGHTS", lambda p: _load_weights(p, self.geom), lambda: init_synthetic(self.geom, seed), "pangu")
-        self.engine.load_params(params)
+        self.engine.load_params(params, calibration=calibration)
         if params24 is None and os.environ.get("SKYRIM_PANGU_WEIGHTS_24"):
             params24 = _load_weights(os.environ["SKYRIM_PANGU_WEIGHTS_24"], self.geom)
         self.engine24 = None
         if params24 is not None:
             self.engine24 = PanguEngine(self.geom, precision, device, **conventions)
-            self.engine24.load_params(params24)
+            self.engine24.load_params(params24, calibration=calibration)
         self.grid = Grid(self.geom.lat, self.geom.lon)
 
     @property

@@ -25,10 +25,10 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in skyrim_pangu.h but not exported"
     assert set(syms) == set(E.EXPORTS)
-    assert lib.skpangu_abi_version() == 3
+    assert lib.skpangu_abi_version() == 4
 
 
-@pytest.mark.parametrize("prec", ["bf16x3", "f16", "f16x3q", "f16x3qh", "f16x2", "f16x2q", "f16x2m"])
+@pytest.mark.parametrize("prec", ["bf16x3", "f16", "f16x3q", "f16x3qh", "f16x2", "f16x2q", "f16x2m", "f16x2c"])
 @pytest.mark.parametrize("grid", [(49, 192), (721, 1440)])
 def test_param_table_matches_host_spec(grid, prec):
     g = PanguGeometry(*grid)
@@ -56,6 +56,7 @@ def test_term_plan_sizes_and_validation():
         sizes[prec] = E.query_sizes(g, prec, E.make_config(g, prec)).prepared_bytes
     assert sizes["f16x2q"] < sizes["f16x2"] < sizes["f16x3q"]
     assert E.make_config(g, "f16x2").term_plan == 0x0F and E.make_config(g, "f16x2q").term_plan == 0xFF and E.make_config(g, "f16x3q").term_plan == 0
+    assert E.make_config(g).term_plan == 0x6F and E.make_config(g, "f16x2c").term_plan == 0x66
     assert E.make_config(g, "f16x3q", term_plan=0x3).term_plan == 3
     with pytest.raises(ValueError):
         E.make_config(g, "bf16x3", term_plan=1)
