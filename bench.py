@@ -644,6 +644,7 @@ def main():
                                 f"every {save_every} step(s) by {args.reduce}" + (", member states all-gathered at every saved step" if args.gather else ""))
                                if world > 1 else "single GPU",
                 "members": n_members, "finite": finite,
+                "calibration": eng.calibrated_on,       # the term plan's biases: "synthetic" = fitted on the engine's built-in state, not on this run's
             },
             "roofline": {
                 "bound": "mfma", "kernel": dom["name"], "achieved": achieved / 1e12, "peak": PEAK_MFMA_BF16 / 1e12,

@@ -109,7 +109,9 @@ int skpangu_prepare(skpangu_ctx* ctx, const float* master_dev, void* stream);
  * constant row and belongs in the bias.  This runs one step on ``state_in_dev`` through the three-term kernels, takes the column means
  * of the operand of every Linear the plan runs short, and adds (W - fp16(W)) x mean to that Linear's prepared bias (the master blob is
  * not changed; calling again starts over from the master biases).  Measured on the CPU restatement with a calibration state different
- * from the forecast's: the plan's error falls 2-3x.  No counterpart in the reference: it belongs to the operand format. */
+ * from the forecast's: the plan's error falls 2-3x.  ``state_in_dev`` NULL: only the master biases are restored (the
+ * uncalibrated plan).  The fitted biases belong to the activation statistics of the calibration state: calibrate on a state of the kind
+ * the forecasts start from.  No counterpart in the reference: it belongs to the operand format. */
 int skpangu_calibrate(skpangu_ctx* ctx, const float* master_dev, const float* state_in_dev, void* stream);
 
 /* One 6-h forecast step: state_out = Pangu6(state_in).  In-place (state_out == state_in) is allowed.

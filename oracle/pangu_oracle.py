@@ -336,6 +336,8 @@ def forward(params: dict, x: torch.Tensor, emu=None, taps: dict | None = None, c
     for layer in (2, 3):
         for i in range(DEPTHS[layer - 1]):
             t = earth_block(_block_params(params, layer, i), t, g.res(layer), HEADS[layer - 1], i % 2 == 1, emu, conv)
+            if taps is not None:
+                taps[f"layer{layer}.block{i}"] = t
     if taps is not None:
         taps["layer3"] = t
     t = upsample(params, g, t, emu)
@@ -343,6 +345,8 @@ def forward(params: dict, x: torch.Tensor, emu=None, taps: dict | None = None, c
         taps["up"] = t
     for i in range(DEPTHS[3]):
         t = earth_block(_block_params(params, 4, i), t, g.res(4), HEADS[3], i % 2 == 1, emu, conv)
+        if taps is not None:
+            taps[f"layer4.block{i}"] = t
     if taps is not None:
         taps["layer4"] = t
     t = torch.cat([skip, t], -1)

@@ -532,8 +532,25 @@ struct Engine : IEngine {
         if (t2) CK(bias_fold(P_(m, p + "mlp.fc2.weight"), cal_sum, inv, const_cast<float*>(bw.fc2_b), C, 4 * C, s));
         return hipSuccess;
     }
+    hipError_t master_biases(const float* m, hipStream_t s) {
+        int b = 0;
+        for (int layer = 0; layer < 4; ++layer)
+            for (int i = 0; i < kDepths[layer]; ++i, ++b) {
+                const int C = layer_dim(layer), heads = layer_heads(layer);
+                const std::string p = "layer" + std::to_string(layer + 1) + ".block" + std::to_string(i) + ".";
+                const BlockW<T>& bw = w.blk[b];
+                const float *qkv_w = P_(m, p + "attn.qkv.weight"), *qkv_bias = P_(m, p + "attn.qkv.bias");
+                if (g.qkv_order) { CK(prep_qkv_rows(qkv_w, qkv_bias, qkv_w_tmp, qkv_b_tmp, C, heads, s)); qkv_bias = qkv_b_tmp; }
+                CK(copyf(bw.qkv_b, qkv_bias, 3 * C, s));
+                CK(copyf(bw.proj_b, P_(m, p + "attn.proj.bias"), C, s));
+                CK(copyf(bw.fc1_b, P_(m, p + "mlp.fc1.bias"), 4 * C, s));
+                CK(copyf(bw.fc2_b, P_(m, p + "mlp.fc2.bias"), C, s));
+            }
+        return hipSuccess;
+    }
     hipError_t calibrate(const float* m, const float* in, hipStream_t s) override {
         if (plan2 == 0) return hipSuccess;               // nothing runs short
+        if (!in) return master_biases(m, s);             // no state: back to the uncalibrated plan
         if constexpr (std::is_same<P, PrecF16x3>::value) {
             CK((op_embed<P>(g, w, in, wk.X1s, wk, s)));
             for (int i = 0; i < kDepths[0]; ++i) CK(calib_block(m, 0, i, wk.X1s, s));
@@ -687,7 +704,7 @@ int skpangu_prepare(skpangu_ctx* ctx, const float* master_dev, void* stream) {
 
 int skpangu_calibrate(skpangu_ctx* ctx, const float* master_dev, const float* state_in, void* stream) {
     NEED_PREPARED();
-    if (!master_dev || !state_in) return SKPANGU_E_ARG;
+    if (!master_dev) return SKPANGU_E_ARG;
     return (int)ctx->eng->calibrate(master_dev, state_in, (hipStream_t)stream);
 }
 

@@ -213,12 +213,18 @@ class PanguEngine:
             raise ValueError(f"expected shape {tuple(shape)}, got {tuple(t.shape)}")
         return ctypes.c_void_p(t.data_ptr())
 
-    def load_params(self, params: dict[str, torch.Tensor], calibration: "torch.Tensor | str | None" = "synthetic"):
+    def load_params(self, params: dict[str, torch.Tensor], calibration: "torch.Tensor | str | None" = "default"):
         """Pack fp32 master parameters into the library's blob layout, upload and prepare.
 
         ``calibration`` (engines with a term plan only): the state the short Linears' biases are calibrated on (``calibrate``) --
         "synthetic" (default): ``calibration_state`` built from the parameters' own normalisation constants, the same for every
-        forecast; a (69, n_lat, n_lon) tensor: that state (e.g. a real analysis); None / "off": no calibration."""
+        forecast; a (69, n_lat, n_lon) tensor: that state (e.g. a real analysis); None / "off": no calibration.  "default" is
+        "synthetic" unless SKYRIM_PANGU_CALIBRATION says otherwise (the counter profiles run with "off": calibration launches ~130
+        kernels once and would otherwise be summed into their per-step totals; it changes biases, not timings)."""
+        if isinstance(calibration, str) and calibration == "default":
+            calibration = os.environ.get("SKYRIM_PANGU_CALIBRATION", "synthetic")
+            if calibration == "first":                          # the time loop's mode: it calls calibrate() itself
+                calibration = "off"
         table = param_table(self.geom, self.precision)
         with torch.cuda.device(self.device):
             master = torch.zeros(self.sizes.master_floats, dtype=torch.float32, device=self.device)
@@ -242,7 +248,7 @@ class PanguEngine:
             self.calibrated_on = "synthetic" if isinstance(calibration, str) else "state"
         del master
 
-    def calibrate(self, state: torch.Tensor):
+    def calibrate(self, state: "torch.Tensor | None"):
         """Fold the mean of the term each one-plane Linear drops, A x (W - fp16(W)), into its bias: one step on ``state`` through the
         three-term kernels, column means of every short Linear's operand, bias += (W - fp16(W)) x mean (include/skyrim_pangu.h:
         skpangu_calibrate).  A no-op for engines without a term plan.  Calling again starts over from the master biases."""
@@ -251,10 +257,11 @@ class PanguEngine:
         if self._master is None:
             raise RuntimeError("load_params() first")
         with torch.cuda.device(self.device):
-            x = state.to(self.device, torch.float32).contiguous()
-            _check(self.lib.skpangu_calibrate(self._ctx, self._master.data_ptr(), self._chk_dev(x, self.state_shape), self._stream()),
-                   "skpangu_calibrate")
+            x = None if state is None else state.to(self.device, torch.float32).contiguous()       # None: back to the master biases
+            _check(self.lib.skpangu_calibrate(self._ctx, self._master.data_ptr(), None if x is None else self._chk_dev(x, self.state_shape),
+                                              self._stream()), "skpangu_calibrate")
             torch.cuda.current_stream(self.device).synchronize()
+        self.calibrated_on = None if state is None else "state"
 
     def step(self, x: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
         if out is None:

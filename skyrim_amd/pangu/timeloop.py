@@ -65,12 +65,19 @@ class PanguTimeLoop:
         (base.py:105-107); ``rollout`` re-creates the loop every step and therefore only ever uses the 6-h network."""
         # ``conventions``: the points the public pseudocode leaves open and a real pangu_weather_6.onnx settles -- roll_sign, mask_value,
         # surface, qkv_order, bias_index (PanguEngine; DESIGN.md 2); padding placement is ``geom.pad``
-        # ``calibration``: the state a term plan's biases are calibrated on (PanguEngine.load_params): "synthetic" (default; the
-        # built-in state from the weights' own normalisation constants), "off", or a (69, n_lat, n_lon) state such as a real analysis;
-        # ``SKYRIM_PANGU_CALIBRATION=off|synthetic`` sets it from the environment
+        # ``calibration``: the state a term plan's biases are calibrated on (PanguEngine.load_params / calibrate): "synthetic" (the
+        # built-in state from the weights' own normalisation constants), "first" (the first initial condition this loop is called
+        # with -- a real analysis when the weights are real), "off", or a (69, n_lat, n_lon) state.  The fitted biases belong to the
+        # activation statistics of the calibration state (a block fed a very different distribution is worse off than uncalibrated,
+        # tests/test_pangu_gpu.py test_earth_specific_block), so the default is "first" for weights loaded from a file and
+        # "synthetic" for seeded random weights, whose forecasts start from synthetic states; SKYRIM_PANGU_CALIBRATION overrides.
         self.geom = geom or PanguGeometry()
         if calibration is None:
-            calibration = os.environ.get("SKYRIM_PANGU_CALIBRATION", "synthetic")
+            from_file = params is None and bool(os.environ.get("SKYRIM_PANGU_WEIGHTS"))
+            calibration = os.environ.get("SKYRIM_PANGU_CALIBRATION", "first" if from_file else "synthetic")
+        self._calibrate_on_first = isinstance(calibration, str) and calibration == "first"
+        if self._calibrate_on_first:
+            calibration = "off"
         conventions = dict(conventions or {})
         self.engine = PanguEngine(self.geom, precision, device, **conventions)
         if params is None:
@@ -97,6 +104,12 @@ class PanguTimeLoop:
         if x.dim() != 5 or x.shape[0] != 1 or x.shape[1] != self.n_history_levels or tuple(x.shape[2:]) != self.engine.state_shape:
             raise ValueError(f"expected x of shape (1, 1, {', '.join(map(str, self.engine.state_shape))}), got {tuple(x.shape)}")
         state = x[0, 0].to(self.device, torch.float32).contiguous()
+        if self._calibrate_on_first:                       # once per loop object: rollout / forecast calls after it reuse the biases
+            self._calibrate_on_first = False
+            for e in (self.engine, self.engine24):
+                if e is not None:
+                    e.calibrate(state)
+                    e.calibrated_on = "first"
         yield time, state.unsqueeze(0).clone(), restart
         state24, k = state, 0
         guard = weights.FiniteGuard(f"precision {self.engine.precision!r} keeps activations as fp16 planes (|x| < 65504); "

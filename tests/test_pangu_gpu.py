@@ -68,7 +68,10 @@ def test_earth_specific_block(eng, toy, ref, layer, i):
     LayerNorm, window reverse + crop, residual, MLP -- one block, plain and rolled, both resolutions."""
     g, params, x = toy
     torch.manual_seed(layer * 10 + i)
-    xin = {1: ref[0]["embed"], 2: ref[0]["down"], 3: ref[0]["down"], 4: ref[0]["up"]}[layer].contiguous()
+    # the block's TRUE input (the oracle's tap of the stage before it): a calibrated term plan carries biases fitted to the activations each
+    # block sees in the network, so a block is tested on those (block 5 of a layer fed the layer's entry state is a different distribution)
+    before = {(1, 0): "embed", (2, 0): "down", (3, 0): "layer2.block5", (4, 0): "up"}
+    xin = ref[0][before.get((layer, i), f"layer{layer}.block{i - 1}")].contiguous()
     want = O.earth_block(O._block_params(params, layer, i), xin, O.Geometry(g.n_lat, g.n_lon).res(layer), O.HEADS[layer - 1], i % 2 == 1)
     got = eng.block(layer, i, xin.cuda())
     assert rel(got, want) < STAGE_TOL[eng.precision]
@@ -495,6 +498,8 @@ def test_calibration_folds_the_dropped_weight_term_into_the_biases(toy, ref):
     y_in = eng.step(x.cuda()).cpu()
     assert not torch.equal(y_in, outs["synthetic"])
     assert O.per_channel_rel_err(y_in, y_ref).max().item() < 0.85 * errs["off"]
+    eng.calibrate(None)                                             # no state: the master biases, i.e. the uncalibrated plan
+    assert eng.calibrated_on is None and torch.equal(eng.step(x.cuda()).cpu(), outs["off"])
     e3 = PanguEngine(g, "f16x3q", "cuda:0")
     e3.load_params(params)
     y3 = e3.step(x.cuda())
@@ -502,6 +507,34 @@ def test_calibration_folds_the_dropped_weight_term_into_the_biases(toy, ref):
     assert e3.calibrated_on is None and torch.equal(e3.step(x.cuda()), y3)
     with pytest.raises(ValueError):
         PanguEngine(g, "f16x2q", "cuda:0").load_params(params, calibration="era5")
+
+
+def test_time_loop_calibrates_on_the_first_initial_condition(toy, ref):
+    """PanguTimeLoop(calibration="first") -- the default for weights loaded from a file: the biases are fitted on the first state the loop
+    is called with, once; later calls reuse them."""
+    import datetime
+    from skyrim_amd.pangu.timeloop import PanguTimeLoop
+    g, params, x = toy
+    _, y_ref = ref
+    loop = PanguTimeLoop(params, g, calibration="first")
+    assert loop.engine.calibrated_on is None
+    t0 = datetime.datetime(2024, 1, 1)
+    it = loop(t0, x[None, None].cuda())
+    next(it)
+    _, y, _ = next(it)
+    it.close()
+    assert loop.engine.calibrated_on == "first"
+    assert O.per_channel_rel_err(y[0].cpu(), y_ref).max().item() < DEF_TOL
+    it = loop(t0, synthetic_state(g, 9)[None, None].cuda())         # a second forecast: same biases
+    next(it)
+    it.close()
+    it = loop(t0, x[None, None].cuda())
+    next(it)
+    _, y2, _ = next(it)
+    it.close()
+    assert torch.equal(y2, y)
+    off = PanguTimeLoop(params, g, calibration="off")
+    assert off.engine.calibrated_on is None and PanguTimeLoop(params, g).engine.calibrated_on == "synthetic"
 
 
 def test_step_as_a_captured_hip_graph(toy):

@@ -33,7 +33,7 @@ def test_counter_summary_matches_the_bench_kernels(model):
     p = json.loads((PROFILES / f"r03_{model}_pmc.json").read_text())
     assert p["total"]["hbm_GB_per_step"] > 0 and p["total"]["steps"] >= 1 and p["stamp"] and f"libskyrim_{model}.so" in p["stamp"]
     names = " ".join(p["kernels"])
-    want = {"pangu": ["proj_mlp2_kernel", "proj_mlp_kernel", "rt_qkv_kernel", "earth_attention2_kernel"], "sfno": ["sfno_chain_kernel", "gemm_strided_kernel"],
+    want = {"pangu": ["proj_mlp2_kernel", "rt_qkv_kernel", "earth_attention2_kernel"], "sfno": ["sfno_chain_kernel", "gemm_strided_kernel"],
             "graphcast": ["sum3_linear_ln_kernel", "sum_linear_ln_kernel", "segment_sum_kernel"]}[model]
     for k in want:
         assert k in names, k

@@ -7,6 +7,7 @@ set -u
 tag=$1; shift
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
+export SKYRIM_PANGU_CALIBRATION=off   # the one-time calibration launches (PanguEngine.load_params) stay out of the per-step totals; timings do not depend on it
 run() {   # <pass name> <counters...> --
   local name=$1; shift
   local ctrs=()
