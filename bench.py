@@ -645,6 +645,7 @@ def main():
                                if world > 1 else "single GPU",
                 "members": n_members, "finite": finite,
                 "calibration": eng.calibrated_on,       # the term plan's biases: "synthetic" = fitted on the engine's built-in state, not on this run's
+                "rounding": eng.rounding,               # of the one-plane weights: "nearest" | "compensated" (pangu/calibration.py)
             },
             "roofline": {
                 "bound": "mfma", "kernel": dom["name"], "achieved": achieved / 1e12, "peak": PEAK_MFMA_BF16 / 1e12,

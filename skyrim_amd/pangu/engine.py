@@ -35,6 +35,7 @@ PRECISIONS = {"bf16x3": PREC_BF16X3, "f16": PREC_F16, "bf16x3h": PREC_BF16X3_H16
 # terms (0x66, round 3's first default), "f16x2q" / "f16x2" are the all-layers plans 0xFF / 0x0F, "f16x3q" is three terms everywhere
 # (~1e-4), "bf16x3" the wide-range alternative (activations beyond fp16's 65504).
 DEFAULT_PRECISION = "f16x2m"
+DEFAULT_ROUNDING = "nearest"       # of the one-plane weights (PanguEngine.load_params); "compensated": pangu/calibration.py
 
 _LIB_PATH = Path(__file__).resolve().parent.parent / "lib" / "libskyrim_pangu.so"
 
@@ -184,6 +185,7 @@ class PanguEngine:
         if mlp != "fused" and precision in TERM_PLANS and term_plan is None:
             term_plan = 0                                   # the tiled-GEMM path has no two-term kernels: "f16x2" + split = f16x3q + split
         self.cfg = make_config(self.geom, precision, roll_sign, mask_value, mlp, term_plan, surface, qkv_order, bias_index)
+        self._conventions = dict(roll_sign=roll_sign, mask_value=mask_value, surface=surface, qkv_order=qkv_order, bias_index=bias_index)
         self.mlp = mlp
         self.term_plan = self.cfg.term_plan
         self.sizes = query_sizes(self.geom, precision, self.cfg)
@@ -213,18 +215,37 @@ class PanguEngine:
             raise ValueError(f"expected shape {tuple(shape)}, got {tuple(t.shape)}")
         return ctypes.c_void_p(t.data_ptr())
 
-    def load_params(self, params: dict[str, torch.Tensor], calibration: "torch.Tensor | str | None" = "default"):
+    def load_params(self, params: dict[str, torch.Tensor], calibration: "torch.Tensor | str | None" = "default", rounding: str = "default"):
         """Pack fp32 master parameters into the library's blob layout, upload and prepare.
 
-        ``calibration`` (engines with a term plan only): the state the short Linears' biases are calibrated on (``calibrate``) --
-        "synthetic" (default): ``calibration_state`` built from the parameters' own normalisation constants, the same for every
-        forecast; a (69, n_lat, n_lon) tensor: that state (e.g. a real analysis); None / "off": no calibration.  "default" is
-        "synthetic" unless SKYRIM_PANGU_CALIBRATION says otherwise (the counter profiles run with "off": calibration launches ~130
-        kernels once and would otherwise be summed into their per-step totals; it changes biases, not timings)."""
+        Engines with a term plan only (one-plane Linears; both are load-time choices that cost nothing per step):
+        ``calibration``: the state their biases (and, with compensated rounding, their weights) are fitted on -- "synthetic":
+        ``calibration_state`` built from the parameters' own normalisation constants, the same for every forecast; a (69, n_lat, n_lon)
+        tensor: that state (e.g. a real analysis); None / "off": none.  "default" is "synthetic" unless SKYRIM_PANGU_CALIBRATION says
+        otherwise (the counter profiles run with "off": calibration launches kernels once that would otherwise be summed into their
+        per-step totals; it changes weights' last bits and biases, not timings).
+        ``rounding``: how their weights reach the fp16 grid -- "nearest" (the C ABI's own; the bias fold is ``skpangu_calibrate``) or
+        "compensated" (pangu/calibration.py: column-by-column error feedback against the operand covariance of the calibration state,
+        computed here and handed to the library as the master weights); "default": SKYRIM_PANGU_ROUNDING or DEFAULT_ROUNDING."""
         if isinstance(calibration, str) and calibration == "default":
             calibration = os.environ.get("SKYRIM_PANGU_CALIBRATION", "synthetic")
             if calibration == "first":                          # the time loop's mode: it calls calibrate() itself
                 calibration = "off"
+        if rounding == "default":
+            rounding = os.environ.get("SKYRIM_PANGU_ROUNDING", DEFAULT_ROUNDING)
+        if rounding not in ("nearest", "compensated"):
+            raise ValueError(f"rounding = {rounding!r}: 'nearest' or 'compensated'")
+        if isinstance(calibration, str) and calibration not in ("synthetic", "off"):
+            raise ValueError(f"calibration = {calibration!r}: expected 'synthetic', 'off', None or a state tensor")
+        off = calibration is None or (isinstance(calibration, str) and calibration == "off")
+        self._params, self.rounding = params, rounding          # calibrate() starts over from these
+        self.calibrated_on = None
+        self._prepare(params)
+        if self.term_plan and not off:
+            self.calibrate(calibration_state(self.geom, params["norm.mean"], params["norm.std"]) if isinstance(calibration, str) else calibration)
+            self.calibrated_on = "synthetic" if isinstance(calibration, str) else "state"
+
+    def _prepare(self, params: dict[str, torch.Tensor]):
         table = param_table(self.geom, self.precision)
         with torch.cuda.device(self.device):
             master = torch.zeros(self.sizes.master_floats, dtype=torch.float32, device=self.device)
@@ -235,32 +256,37 @@ class PanguEngine:
                 master[off:off + t.numel()] = t.reshape(-1).to(self.device, torch.float32)
             _check(self.lib.skpangu_prepare(self._ctx, master.data_ptr(), self._stream()), "skpangu_prepare")
             torch.cuda.current_stream(self.device).synchronize()
-        self._master = master if self.term_plan else None       # calibrate() re-reads weights and biases from it
-        self.calibrated_on = None
-        if self.term_plan and calibration is not None and not (isinstance(calibration, str) and calibration == "off"):
-            if isinstance(calibration, str):
-                if calibration != "synthetic":
-                    raise ValueError(f"calibration = {calibration!r}: expected 'synthetic', 'off', None or a state tensor")
-                state = calibration_state(self.geom, params["norm.mean"], params["norm.std"])
-            else:
-                state = calibration
-            self.calibrate(state)
-            self.calibrated_on = "synthetic" if isinstance(calibration, str) else "state"
-        del master
+        self._master = master if self.term_plan else None       # skpangu_calibrate re-reads weights and biases from it
 
     def calibrate(self, state: "torch.Tensor | None"):
-        """Fold the mean of the term each one-plane Linear drops, A x (W - fp16(W)), into its bias: one step on ``state`` through the
-        three-term kernels, column means of every short Linear's operand, bias += (W - fp16(W)) x mean (include/skyrim_pangu.h:
-        skpangu_calibrate).  A no-op for engines without a term plan.  Calling again starts over from the master biases."""
+        """Fit the one-plane Linears of the term plan to ``state`` (None: back to nearest rounding and the master biases); a no-op for
+        engines without a plan.  Calling again starts over from the parameters handed to ``load_params``.
+        rounding "nearest": fold the mean of the dropped term, A x (W - fp16(W)), into each bias -- one step on ``state`` through the
+        three-term kernels, column means of every short Linear's operand (include/skyrim_pangu.h: skpangu_calibrate).
+        rounding "compensated": the operands of one three-term step on ``state`` (a second, tiled-form engine that lives for the
+        duration of this call), their covariances, error-compensated fp16 weights + folded biases (pangu/calibration.py), prepared
+        again."""
         if not self.term_plan:
             return
-        if self._master is None:
+        if getattr(self, "_params", None) is None:
             raise RuntimeError("load_params() first")
-        with torch.cuda.device(self.device):
-            x = None if state is None else state.to(self.device, torch.float32).contiguous()       # None: back to the master biases
-            _check(self.lib.skpangu_calibrate(self._ctx, self._master.data_ptr(), None if x is None else self._chk_dev(x, self.state_shape),
-                                              self._stream()), "skpangu_calibrate")
-            torch.cuda.current_stream(self.device).synchronize()
+        if self.rounding == "compensated":
+            params = self._params
+            if state is not None:
+                from .calibration import calibrated_params, engine_taps
+                tap = PanguEngine(self.geom, "f16x3q", self.device, mlp="split", **self._conventions)
+                tap.load_params(self._params, calibration="off")
+                with torch.no_grad():
+                    params = calibrated_params(self._params, self.term_plan, engine_taps(tap, self._params, state))
+                del tap
+            self._prepare(params)                               # fp16-grid weights: the library's own rounding leaves them as they are
+            torch.cuda.empty_cache()
+        else:
+            with torch.cuda.device(self.device):
+                x = None if state is None else state.to(self.device, torch.float32).contiguous()   # None: back to the master biases
+                _check(self.lib.skpangu_calibrate(self._ctx, self._master.data_ptr(), None if x is None else self._chk_dev(x, self.state_shape),
+                                                  self._stream()), "skpangu_calibrate")
+                torch.cuda.current_stream(self.device).synchronize()
         self.calibrated_on = None if state is None else "state"
 
     def step(self, x: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:

@@ -57,7 +57,7 @@ class PanguTimeLoop:
 
     def __init__(self, params: dict | None = None, geom: PanguGeometry | None = None, precision: str = DEFAULT_PRECISION,
                  device: str | torch.device = "cuda:0", seed: int = 0, params24: dict | None = None, conventions: dict | None = None,
-                 calibration: "torch.Tensor | str | None" = None):
+                 calibration: "torch.Tensor | str | None" = None, rounding: str = "default"):
         """``params``: 6-h network (default: ``SKYRIM_PANGU_WEIGHTS`` state dict or seeded random init).
         ``params24`` (optional, or ``SKYRIM_PANGU_WEIGHTS_24``): the 24-h network; when present a multi-step
         generator interleaves the two like earth2mip's Pangu loop does (every 4th step is a 24-h step from the state
@@ -82,13 +82,13 @@ class PanguTimeLoop:
         self.engine = PanguEngine(self.geom, precision, device, **conventions)
         if params is None:
             params = weights.resolve("SKYRIM_PANGU_WEIGHTS", lambda p: _load_weights(p, self.geom), lambda: init_synthetic(self.geom, seed), "pangu")
-        self.engine.load_params(params, calibration=calibration)
+        self.engine.load_params(params, calibration=calibration, rounding=rounding)
         if params24 is None and os.environ.get("SKYRIM_PANGU_WEIGHTS_24"):
             params24 = _load_weights(os.environ["SKYRIM_PANGU_WEIGHTS_24"], self.geom)
         self.engine24 = None
         if params24 is not None:
             self.engine24 = PanguEngine(self.geom, precision, device, **conventions)
-            self.engine24.load_params(params24, calibration=calibration)
+            self.engine24.load_params(params24, calibration=calibration, rounding=rounding)
         self.grid = Grid(self.geom.lat, self.geom.lon)
 
     @property

@@ -509,6 +509,52 @@ def test_calibration_folds_the_dropped_weight_term_into_the_biases(toy, ref):
         PanguEngine(g, "f16x2q", "cuda:0").load_params(params, calibration="era5")
 
 
+def test_compensated_rounding_of_the_one_plane_weights(toy, ref):
+    """pangu/calibration.py through PanguEngine.load_params(rounding="compensated"): the operands come from the engine's own buffers (one
+    step of the tiled three-term engine on the built-in calibration state), the weights of the short Linears are rounded with error
+    feedback against the operand covariances, the biases take the mean of the rest.  Same kernels, same step time; against nearest
+    rounding + bias fold the step error falls towards the three-term engine's (CPU statement: tests/test_term_plan_calibration.py)."""
+    from skyrim_amd.pangu.engine import PanguEngine
+    from skyrim_amd.pangu.calibration import engine_taps
+    g, params, x = toy
+    taps, y_ref = ref
+    errs = {}
+    for rounding in ("nearest", "compensated"):
+        eng = PanguEngine(g, "f16x2q", "cuda:0")
+        eng.load_params(params, rounding=rounding)
+        assert eng.rounding == rounding and eng.calibrated_on == "synthetic"
+        state = x.cuda().clone()
+        e = []
+        for _ in range(2):
+            state = eng.step(state)
+            e.append(state.cpu())
+        errs[rounding] = O.per_channel_rel_err(e[0], y_ref).max().item()
+    e3 = PanguEngine(g, "f16x3q", "cuda:0")
+    e3.load_params(params)
+    errs["three terms"] = O.per_channel_rel_err(e3.step(x.cuda()).cpu(), y_ref).max().item()
+    print("f16x2q one step: " + ", ".join(f"{k} {v:.2e}" for k, v in errs.items()))
+    assert errs["compensated"] < 0.6 * errs["nearest"] and errs["compensated"] < 3 * errs["three terms"], errs
+    eng.calibrate(None)                                             # back to nearest rounding, master biases
+    off = PanguEngine(g, "f16x2q", "cuda:0")
+    off.load_params(params, calibration="off")
+    assert torch.equal(eng.step(x.cuda()), off.step(x.cuda()))
+    # the operands the statistics are taken from are the oracle's (attention output, mid-block stream, hidden activation of block 0)
+    tap = PanguEngine(g, "f16x3q", "cuda:0", mlp="split")
+    tap.load_params(params)
+    layer, i, ops = next(engine_taps(tap, params, x))
+    assert (layer, i) == (1, 0) and set(ops) == {"attn.qkv", "attn.proj", "mlp.fc1", "mlp.fc2"}
+    bp = O._block_params(params, 1, 0)
+    x1 = taps["embed"]
+    assert rel(ops["attn.qkv"], x1) < 1e-3
+    want_mid_to_out = O.earth_block(bp, x1, O.Geometry(g.n_lat, g.n_lon).res(1), O.HEADS[0], False)
+    mid = ops["mlp.fc1"].cpu()
+    hid = torch.nn.functional.gelu(torch.nn.functional.linear(mid, bp["mlp.fc1.weight"], bp["mlp.fc1.bias"]))
+    assert rel(ops["mlp.fc2"], hid) < 2e-3
+    out = mid + torch.nn.functional.layer_norm(torch.nn.functional.linear(hid, bp["mlp.fc2.weight"], bp["mlp.fc2.bias"]), (192,), bp["norm2.weight"], bp["norm2.bias"], 1e-5)
+    assert rel(out, want_mid_to_out) < 1e-3                          # mid-block stream and hidden are the block's own
+    assert ops["attn.proj"].shape == x1.shape and torch.isfinite(ops["attn.proj"]).all()
+
+
 def test_time_loop_calibrates_on_the_first_initial_condition(toy, ref):
     """PanguTimeLoop(calibration="first") -- the default for weights loaded from a file: the biases are fitted on the first state the loop
     is called with, once; later calls reuse them."""

@@ -2,6 +2,7 @@
 to ONE fp16 plane drops x @ (W - fp16(W)).T; the mean of that term over the tokens of a DIFFERENT state, folded into the bias, removes
 most of the error the rounding adds to one 6-h step.  The GPU engine's own calibration is measured against the oracle in
 tests/test_pangu_gpu.py; this is the statement it implements."""
+import pytest
 import torch
 import torch.nn.functional as F
 
@@ -49,3 +50,74 @@ def test_bias_fold_removes_most_of_the_weight_rounding_error(monkeypatch):
     monkeypatch.setattr(O, "_linear", plain)
     assert 1e-5 < e_plain < 2e-3                          # the rounding is visible ...
     assert e_fold < 0.7 * e_plain                         # ... and its mean was most of it (measured 0.4-0.5x at 49x192 and 73x288)
+
+
+def test_builtin_calibration_state_is_fixed_and_is_not_a_test_state():
+    """``calibration_state``: built from the weights' own normalisation constants and a fixed seed -- the same for every load of a set of
+    weights, and none of the synthetic states the parity tests or bench.py forecast from (seeds 0..11)."""
+    from skyrim_amd.pangu.engine import CALIBRATION_SEED, calibration_state
+    g = PanguGeometry(25, 96)
+    p = init_synthetic(g, 0)
+    a = calibration_state(g, p["norm.mean"], p["norm.std"])
+    b = calibration_state(g, p["norm.mean"], p["norm.std"])
+    assert a.shape == (69, 25, 96) and a.dtype == torch.float32 and torch.equal(a, b)
+    assert CALIBRATION_SEED not in range(0, 100)
+    for seed in range(12):
+        assert not torch.allclose(a, synthetic_state(g, seed))
+    # its statistics are the normalisation constants' (what makes it a stand-in for an analysis of that climate)
+    z = (a - p["norm.mean"].reshape(-1, 1, 1)) / p["norm.std"].reshape(-1, 1, 1)
+    assert z.mean().abs() < 0.2 and abs(z.flatten(1).std(1).mean().item() - 1.0) < 0.05
+
+
+def _oracle_taps(monkeypatch, p, x_cal):
+    """(layer, block, {kind: operand rows}) of the oracle's three-term network on ``x_cal`` -- what calibration.engine_taps reads from the
+    GPU engine's buffers (window-ordered rows here, padding rows included: statistics do not care about the order)."""
+    names = {id(v): k for k, v in p.items()}
+    got = {}
+    plain = O._linear
+
+    def linear(xx, w, b=None, *a, **kw):
+        key = names.get(id(w), "")
+        for kind in ("attn.qkv", "attn.proj", "mlp.fc1", "mlp.fc2"):
+            if key.endswith(kind + ".weight"):
+                layer, blk = int(key[5]), int(key.split(".")[1][5:])
+                rows = xx.reshape(-1, xx.shape[-1])
+                got.setdefault((layer, blk), {})[kind] = _fp16(rows) if kind == "attn.qkv" else rows
+        return plain(xx, w, b, *a, **kw)
+
+    monkeypatch.setattr(O, "_linear", linear)
+    O.forward(p, x_cal)
+    monkeypatch.setattr(O, "_linear", plain)
+    return [(layer, blk, ops) for (layer, blk), ops in sorted(got.items())]
+
+
+def test_compensated_rounding_beats_nearest_rounding(monkeypatch):
+    """skyrim_amd/pangu/calibration.py: the weights of the full-resolution layers 1 / 4 (the sensitive ones) on the fp16 grid
+    -- nearest, nearest + mean fold, error-compensated + mean fold -- against the unrounded network, statistics from another state."""
+    from skyrim_amd.pangu.calibration import calibrated_params, compensated_round, short_kinds
+    assert short_kinds(0x6F, 1) == ("attn.proj", "mlp.fc1", "mlp.fc2") and short_kinds(0x6F, 2)[-1] == "attn.qkv" and short_kinds(0x00, 3) == ()
+    g = PanguGeometry(49, 192)
+    p = init_synthetic(g, 3)
+    x, x_cal = synthetic_state(g, 3), synthetic_state(g, 11)
+    plan = 0x09
+    taps = [t for t in _oracle_taps(monkeypatch, p, x_cal) if t[0] in (1, 4)]
+    ref = O.forward(p, x)
+    errs = {}
+    nearest = calibrated_params(p, plan, taps, rounding="nearest")
+    plain = dict(nearest)
+    for k in p:
+        if k.endswith(".bias"):
+            plain[k] = p[k]                                        # nearest rounding with the ORIGINAL biases
+    for tag, q in (("nearest", plain), ("nearest + fold", nearest), ("compensated + fold", calibrated_params(p, plan, taps))):
+        for k, v in q.items():
+            if k.endswith("weight") and k.startswith(("layer1", "layer4")) and any(s in k for s in SHORT):
+                assert torch.equal(v, _fp16(v)) and not torch.equal(v, p[k])          # on the fp16 grid, and it is a different matrix
+        errs[tag] = O.per_channel_rel_err(O.forward(q, x), ref).max().item()
+    print(errs)
+    assert errs["nearest + fold"] < 0.8 * errs["nearest"]
+    assert errs["compensated + fold"] < 0.5 * errs["nearest + fold"]
+    # the routine itself: with an isotropic covariance there is nothing to exploit and it IS nearest rounding
+    w = torch.randn(8, 64)
+    assert torch.equal(compensated_round(w, torch.eye(64, dtype=torch.float64)), _fp16(w))
+    with pytest.raises(RuntimeError):
+        calibrated_params(p, 0x0F, taps)                              # the plan names layers the taps did not cover
