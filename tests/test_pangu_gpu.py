@@ -509,6 +509,43 @@ def test_calibration_folds_the_dropped_weight_term_into_the_biases(toy, ref):
         PanguEngine(g, "f16x2q", "cuda:0").load_params(params, calibration="era5")
 
 
+def test_calibration_taps_are_the_oracles_operands(toy, monkeypatch):
+    """pangu/calibration.py engine_taps: what it reads back from the tiled three-term engine, block by block, against the operands the
+    oracle's Linears see on the same state (stream, mid-block stream, hidden activation: token order on both sides)."""
+    from skyrim_amd.pangu.engine import PanguEngine
+    from skyrim_amd.pangu.calibration import engine_taps
+    g, params, x = toy
+    names = {id(v): k for k, v in params.items()}
+    seen = {}
+    plain = O._linear
+
+    def linear(xx, w, b=None, *a, **kw):
+        key = names.get(id(w), "")
+        if key.endswith(("attn.qkv.weight", "mlp.fc1.weight", "mlp.fc2.weight")):
+            seen[key[:-len(".weight")]] = xx
+        return plain(xx, w, b, *a, **kw)
+
+    monkeypatch.setattr(O, "_linear", linear)
+    taps = {}
+    O.forward(params, x, taps=taps)
+    monkeypatch.setattr(O, "_linear", plain)
+    tap = PanguEngine(g, "f16x3q", "cuda:0", mlp="split")
+    tap.load_params(params)
+    before = {(1, 0): "embed", (2, 0): "down", (3, 0): "layer2.block5", (4, 0): "up"}
+    worst = {}
+    n = 0
+    for layer, i, ops in engine_taps(tap, params, x):
+        pre = f"layer{layer}.block{i}."
+        xin = taps[before.get((layer, i), f"layer{layer}.block{i - 1}")]
+        e = {"attn.qkv": rel(ops["attn.qkv"], xin), "mlp.fc1": rel(ops["mlp.fc1"], seen[pre + "mlp.fc1"]), "mlp.fc2": rel(ops["mlp.fc2"], seen[pre + "mlp.fc2"])}
+        print(pre, " ".join(f"{k} {v:.1e}" for k, v in e.items()), tuple(ops["attn.proj"].shape))
+        assert ops["attn.proj"].shape == xin.shape and torch.isfinite(ops["attn.proj"]).all()
+        for k, v in e.items():
+            worst[k] = max(worst.get(k, 0.0), v)
+        n += 1
+    assert n == 16 and max(worst.values()) < 3e-3, worst
+
+
 def test_compensated_rounding_of_the_one_plane_weights(toy, ref):
     """pangu/calibration.py through PanguEngine.load_params(rounding="compensated"): the operands come from the engine's own buffers (one
     step of the tiled three-term engine on the built-in calibration state), the weights of the short Linears are rounded with error

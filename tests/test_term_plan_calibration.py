@@ -82,7 +82,9 @@ def _oracle_taps(monkeypatch, p, x_cal):
             if key.endswith(kind + ".weight"):
                 layer, blk = int(key[5]), int(key.split(".")[1][5:])
                 rows = xx.reshape(-1, xx.shape[-1])
-                got.setdefault((layer, blk), {})[kind] = _fp16(rows) if kind == "attn.qkv" else rows
+                if kind == "attn.qkv":
+                    rows = _fp16(rows[rows.abs().sum(1) > 0])                 # the stream's hi plane, padding rows out
+                got.setdefault((layer, blk), {})[kind] = rows
         return plain(xx, w, b, *a, **kw)
 
     monkeypatch.setattr(O, "_linear", linear)
@@ -99,7 +101,7 @@ def test_compensated_rounding_beats_nearest_rounding(monkeypatch):
     g = PanguGeometry(49, 192)
     p = init_synthetic(g, 3)
     x, x_cal = synthetic_state(g, 3), synthetic_state(g, 11)
-    plan = 0x09
+    plan = 0x99                                                   # layers 1 and 4: proj / fc1 / fc2 AND the QKV on one plane
     taps = [t for t in _oracle_taps(monkeypatch, p, x_cal) if t[0] in (1, 4)]
     ref = O.forward(p, x)
     errs = {}
@@ -110,7 +112,7 @@ def test_compensated_rounding_beats_nearest_rounding(monkeypatch):
             plain[k] = p[k]                                        # nearest rounding with the ORIGINAL biases
     for tag, q in (("nearest", plain), ("nearest + fold", nearest), ("compensated + fold", calibrated_params(p, plan, taps))):
         for k, v in q.items():
-            if k.endswith("weight") and k.startswith(("layer1", "layer4")) and any(s in k for s in SHORT):
+            if k.endswith("weight") and k.startswith(("layer1", "layer4")) and any(s in k for s in SHORT + ("attn.qkv",)):
                 assert torch.equal(v, _fp16(v)) and not torch.equal(v, p[k])          # on the fp16 grid, and it is a different matrix
         errs[tag] = O.per_channel_rel_err(O.forward(q, x), ref).max().item()
     print(errs)
