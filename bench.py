@@ -70,7 +70,7 @@ def cpu_baseline(params, geom, x):
             "s_per_step": dt}
 
 
-def toy_parity(precision):
+def toy_parity(precision, rounding="default"):
     """Engine vs oracle on the 13x49x192 toy grid (seconds)."""
     from oracle import pangu_oracle as O
     from skyrim_amd.pangu.engine import PanguEngine
@@ -79,9 +79,9 @@ def toy_parity(precision):
     p = init_synthetic(g, 0)
     x = synthetic_state(g, 0)
     eng = PanguEngine(g, precision)
-    eng.load_params(p)
+    eng.load_params(p, rounding=rounding)
     y = eng.step(x.to(eng.device)).cpu()
-    return {"grid": "49x192", "max_rel_err": O.per_channel_rel_err(y, O.forward(p, x)).max().item(), "bar": 1e-3}
+    return {"grid": "49x192", "max_rel_err": O.per_channel_rel_err(y, O.forward(p, x)).max().item(), "bar": 1e-3, "rounding": eng.rounding}
 
 
 PROFILE_ROUND = "r03"
@@ -126,11 +126,11 @@ PANGU_STAGE_KERNEL = {"mlp_r0": ("fused_mlp_kernel", "MlpShape<192"), "mlp_r1": 
                       "proj_r0": ("gemm_dma_kernel", "256x192", "EpLayerNorm", "RowMapIndexed"), "proj_r1": ("gemm_dma_kernel", "128x384", "EpLayerNorm")}
 
 
-def quick_mode(precision, geom, params, x_host, dev, steps=3, mlp="fused"):
+def quick_mode(precision, geom, params, x_host, dev, steps=3, mlp="fused", rounding="default"):
     """Short run of another precision mode (same workload) for the 'modes' table."""
     from skyrim_amd.pangu.engine import PanguEngine
     eng = PanguEngine(geom, precision, dev, mlp=mlp)
-    eng.load_params(params)
+    eng.load_params(params, rounding=rounding)
     x = x_host.to(dev)
     eng.step(x, x)
     torch.cuda.synchronize()
@@ -678,6 +678,17 @@ def main():
             torch.cuda.empty_cache()
             out["modes"] = {m: dict(quick_mode(m, geom, params, x_host, dev), note=MODE_NOTES[m][1])
                             for m in ("f16x2q", "f16x2c", "f16x3q", "bf16x3", "f16") if m != args.precision}
+            if not args.no_parity:
+                # the opt-in load-time rounding of the one-plane weights (pangu/calibration.py): the same kernels at the same speed, the error
+                # of the three-term modes; full size, one step, against the oracle: f16x2m 1.2e-4, f16x2q 1.4e-4 (nearest: 4.2e-4 / 5.2e-4)
+                for m in ("f16x2m", "f16x2q"):
+                    try:
+                        out["modes"][m + "/compensated"] = dict(quick_mode(m, geom, params, x_host, dev, rounding="compensated"), parity=toy_parity(m, "compensated"),
+                                                                note="weights of the one-plane Linears rounded with error feedback against the operand "
+                                                                     "statistics of the calibration state (load time only); SKYRIM_PANGU_ROUNDING=compensated")
+                    except Exception as exc:                # an optional table entry must not take the headline down with it
+                        out["modes"][m + "/compensated"] = {"error": f"{type(exc).__name__}: {exc}"}
+                    torch.cuda.empty_cache()
             out["modes"][args.precision + "/split-mlp"] = dict(quick_mode(args.precision, geom, params, x_host, dev, mlp="split"),
                                                                note="same arithmetic with the MLP as two tiled GEMMs (hidden through HBM): the round-1 path")
         if world == 1 and not args.no_models:
