@@ -42,6 +42,8 @@ MODE_NOTES = {
                "(A_hi W + A_lo W); QKV 1 term in layers 2 / 3 (12 of 16 blocks), 2 terms (hi/lo weights) in layers 1 / 4; the mean of the dropped "
                "A (W - fp16 W) term over a calibration state folded into the biases at load time" + _ATT,
                "default (term plan 0x6F, calibrated)"),
+    "f16x1m": ("f16x2m with proj / fc1 / fc2 of layers 2 / 3 at ONE term (activation operands as their fp16 hi plane; term plan 0x66F)" + _ATT,
+               "wants rounding=compensated (weights fitted to the rounded operands)"),
     "f16x2c": ("f16x2m with layers 1 / 4 at three terms (hi/lo weights; term plan 0x66, calibrated)" + _ATT, "meets the bar with 3x margin"),
     "f16x2q": ("f16x2m with the one-term QKV in ALL four layers (term plan 0xFF, calibrated)" + _ATT, "inside the bar (7.4e-4 after four full-size steps)"),
     "f16x2": ("f16x2m with the QKV weights as hi/lo planes (2 terms) in all layers (term plan 0x0F, calibrated)" + _ATT, "meets the bar (~5e-4)"),
@@ -681,7 +683,7 @@ def main():
             if not args.no_parity:
                 # the opt-in load-time rounding of the one-plane weights (pangu/calibration.py): the same kernels at the same speed, the error
                 # of the three-term modes; full size, one step, against the oracle: f16x2m 1.2e-4, f16x2q 1.4e-4 (nearest: 4.2e-4 / 5.2e-4)
-                for m in ("f16x2m", "f16x2q"):
+                for m in ("f16x2m", "f16x2q", "f16x1m"):
                     try:
                         out["modes"][m + "/compensated"] = dict(quick_mode(m, geom, params, x_host, dev, rounding="compensated"), parity=toy_parity(m, "compensated"),
                                                                 note="weights of the one-plane Linears rounded with error feedback against the operand "

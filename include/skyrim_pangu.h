@@ -64,8 +64,13 @@ typedef struct skpangu_config {
                       layer l + 1 run proj / fc1 / fc2 with TWO terms, A_hi W_hi + A_lo W_hi -- the weights as ONE fp16 plane, the
                       activations still hi/lo pairs (a third fewer MFMAs, half the LDS and LDS-DMA bytes; 2^-12 relative weight rounding:
                       ~5e-4 per-channel error per step with all four bits set against ~1e-4 with none).  Bit 4 + l (F16X3_Q only): the
-                      layer's QKV linear runs with ONE term, stream hi plane x weight hi plane.  0: three terms everywhere (QKV two).
-                      Host modes: "f16x2m" (default) = F16X3_Q with term_plan 0x66, "f16x2" = 0x0F, "f16x2q" = 0xFF. */
+                      layer's QKV linear runs with ONE term, stream hi plane x weight hi plane.  Bit 8 + l (needs bit l): proj / fc1 / fc2 of
+                      the layer with ONE term -- the activation operands (attention output, mid-block stream, hidden activation) too enter
+                      the GEMMs as their fp16 hi plane; the residual path keeps hi/lo pairs.  Half the MFMAs of the two-term form; meant
+                      for weights rounded with error feedback against those operands (host: pangu/calibration.py), which is what pays for
+                      the activation rounding.  0: three terms everywhere (QKV two).
+                      Host modes: "f16x2m" (default) = F16X3_Q with term_plan 0x6F, "f16x2c" = 0x66, "f16x2" = 0x0F, "f16x2q" = 0xFF,
+                      "f16x1m" = 0x66F (layers 2 / 3 one-term). */
     /* three more conventions the pseudocode leaves open; each is applied once, in skpangu_prepare (no kernel depends on them) */
     int surface_last;    /* 0 (default): the surface slab is token level 0 (PatchRecovery reads it at index 0); 1: it is the LAST level
                             (PatchEmbedding's concatenate((input, input_surface)) as written).  The stream keeps its storage order; the window

@@ -28,7 +28,8 @@ bool make_geom(const skpangu_config& c, Geom& g) {
     if (c.roll_sign < -1 || c.roll_sign > 1 || (c.pad_mode != SKPANGU_PAD_CENTRE && c.pad_mode != SKPANGU_PAD_BACK)) return false;
     if (c.mask_value > 0.f || c.mask_value < -60000.f) return false;      // the mask lives in the fp16 bias tiles
     if (c.mlp_mode != 0 && c.mlp_mode != 1) return false;
-    if (c.term_plan < 0 || c.term_plan > 0xFF) return false;
+    if (c.term_plan < 0 || c.term_plan > 0xFFF) return false;
+    if (((c.term_plan >> 8) & 0xF) & ~(c.term_plan & 0xF)) return false;      // a one-term layer is a two-term layer that also drops the activations' lo planes
     if ((c.surface_last | c.qkv_order | c.bias_transposed) & ~1) return false;
     g.surface_last = c.surface_last; g.qkv_order = c.qkv_order; g.bias_transposed = c.bias_transposed;
     g.roll_sign = c.roll_sign > 0 ? 1 : -1;
@@ -135,6 +136,7 @@ struct Engine : IEngine {
     int plan2 = 0;                          // bit l: layer l + 1 runs proj / fc1 / fc2 with TWO terms (weights as one fp16 plane, fused_block2.hip)
     bool two_term(int layer) const { return (plan2 >> layer) & 1; }
     bool qkv_one(int layer) const { return rt_qkv && ((plan2 >> (4 + layer)) & 1); }   // QKV with ONE term (stream hi plane x weight hi plane)
+    bool block_one(int layer) const { return (plan2 >> (8 + layer)) & 1; }             // proj / fc1 / fc2 with ONE term (activation hi plane x weight hi plane)
     T* zrow = nullptr;
     float *qkv_w_tmp = nullptr, *qkv_b_tmp = nullptr;
     float* cal_sum = nullptr;               // column sums of one GEMM operand (calibrate)
@@ -421,7 +423,7 @@ struct Engine : IEngine {
         if constexpr (std::is_same<P, PrecF16x3>::value) {
             if (two_term(layer0)) {               // ... with two MFMA terms and the halves of the workgroup half a chunk apart
                 mark(C_FC1_0 + o, s);
-                CK(op_proj_mlp_skew(g, bw, w.winv[res][i & 1], res, xs, wk, s));
+                CK(op_proj_mlp_skew(g, bw, w.winv[res][i & 1], res, xs, wk, s, block_one(layer0)));
                 mark(-1, s);
                 return hipSuccess;
             }
@@ -506,6 +508,7 @@ struct Engine : IEngine {
         if (colsum_scratch_floats(ntok, 4 * C) * sizeof(float) > 3 * q_elems * sizeof(f16)) return hipErrorInvalidValue;
         const std::string p = "layer" + std::to_string(layer0 + 1) + ".block" + std::to_string(i) + ".";
         const bool t2 = two_term(layer0), q1 = qkv_one(layer0);
+        const int npl = block_one(layer0) ? 1 : 2;                    // planes of the activation operands the layer's block GEMMs read
         const float *qkv_w = P_(m, p + "attn.qkv.weight"), *qkv_bias = P_(m, p + "attn.qkv.bias");
         if (g.qkv_order) { CK(prep_qkv_rows(qkv_w, qkv_bias, qkv_w_tmp, qkv_b_tmp, C, heads, s)); qkv_w = qkv_w_tmp; qkv_bias = qkv_b_tmp; }
         CK(copyf(bw.qkv_b, qkv_bias, 3 * C, s));
@@ -517,16 +520,16 @@ struct Engine : IEngine {
         if (q1) CK(bias_fold(qkv_w, cal_sum, inv, const_cast<float*>(bw.qkv_b), 3 * C, C, s));
         AttnArgs<P> a{wk.q, wk.k, wk.vt, wk.qkv_plane, bw.bias_exp, bw.bias_cmp, wk.ao, wk.ao_plane, C, g.nwin[res], g.nW[res], heads};
         CK(launch_attention<P>(a, s));
-        if (t2) CK(colsum_planes<T>(wk.ao, wk.ao_plane, 2, w.winv[res][i & 1], ntok, C, scratch, cal_sum, s));   // window rows of the real tokens
+        if (t2) CK(colsum_planes<T>(wk.ao, wk.ao_plane, npl, w.winv[res][i & 1], ntok, C, scratch, cal_sum, s));   // window rows of the real tokens
         CK((op_proj<P>(g, bw, widx, res, xs, wk, s)));
         if (t2) {
             CK(bias_fold(P_(m, p + "attn.proj.weight"), cal_sum, inv, const_cast<float*>(bw.proj_b), C, C, s));
-            CK(colsum_planes<T>(xs, wk.xs_plane[res], 2, nullptr, ntok, C, scratch, cal_sum, s));             // the mid-block stream
+            CK(colsum_planes<T>(xs, wk.xs_plane[res], npl, nullptr, ntok, C, scratch, cal_sum, s));             // the mid-block stream
         }
         CK((op_fc1<P>(g, bw, res, xs, wk, s)));
         if (t2) {
             CK(bias_fold(P_(m, p + "mlp.fc1.weight"), cal_sum, inv, const_cast<float*>(bw.fc1_b), 4 * C, C, s));
-            CK(colsum_planes<T>(wk.hid, wk.hid_plane, 2, nullptr, ntok, 4 * C, scratch, cal_sum, s));
+            CK(colsum_planes<T>(wk.hid, wk.hid_plane, npl, nullptr, ntok, 4 * C, scratch, cal_sum, s));
         }
         CK((op_fc2<P>(g, bw, res, xs, wk, s)));
         if (t2) CK(bias_fold(P_(m, p + "mlp.fc2.weight"), cal_sum, inv, const_cast<float*>(bw.fc2_b), C, 4 * C, s));

@@ -24,8 +24,12 @@
 
 namespace skp {
 
-template <int C_, int FM_, int RD_, bool SKEW_, bool DUO_, int PROBE_ = 0>
+template <int C_, int FM_, int RD_, bool SKEW_, bool DUO_, int PROBE_ = 0, bool ONE_ = false>
 struct Blk2Shape {
+    // ONE: the ACTIVATION operands too as one fp16 plane -- A_hi W only: attention output, mid-block stream and hidden activation are rounded
+    // to fp16 where they enter a GEMM (the residual path keeps the hi/lo pair).  Half of the two-term form's MFMAs; meant for weights rounded
+    // with error feedback against these very operands (pangu/calibration.py), which is what pays for the activation rounding
+    static constexpr bool ONE = ONE_;
     // timing probes (measurement only; results are wrong): 1 no GELU polynomial, 2 one fragment pair read per phase, 4 no weight DMA
     // in the MLP loop, 8 no barrier in the MLP loop, 16 no row gathers / stores
     static constexpr int PROBE = PROBE_;
@@ -137,7 +141,8 @@ proj_mlp2_kernel(const Block2Args<T> a) {
         for (int ks = 0; ks < KS; ++ks) {
             if constexpr (P_IO) { xh[t][ks] = v8{}; xl[t][ks] = v8{}; xh[t][ks][0] = (T)(float)lane; continue; }
             xh[t][ks] = *reinterpret_cast<const v8*>(p + (ks << 9));
-            xl[t][ks] = *reinterpret_cast<const v8*>(p + (ks << 9) + a.ao_plane);
+            if constexpr (S::ONE) xl[t][ks] = v8{};              // the lo plane of the attention output is not read at all
+            else xl[t][ks] = *reinterpret_cast<const v8*>(p + (ks << 9) + a.ao_plane);
         }
     }
 #pragma unroll
@@ -160,10 +165,12 @@ proj_mlp2_kernel(const Block2Args<T> a) {
         if (j + 1 < NPB) dma1(a.projh + ((long long)(j + 1) * S::SLOT_KIB << 9), lds_base + (unsigned)((S::PSLOT0 + ((j + 1) & 1)) * S::SLOT));
         else if constexpr (S::DUO) dma1(a.w1h, lds_base);      // NPB is even: the last block sits in slot 1, slot 0 is free for fc1's chunk 0
         sk_stream<KS, RD>(lrd + (S::PSLOT0 + (j & 1)) * S::SLOT, [&](int ks, const uint4& w0, const uint4& w1) {
+            if constexpr (!S::ONE) {
 #pragma unroll
-            for (int t = 0; t < FM; ++t) yacc[t][2 * j] = OpT<T>::mfma(as_v8<T>(w0), xl[t][ks], yacc[t][2 * j]);
+                for (int t = 0; t < FM; ++t) yacc[t][2 * j] = OpT<T>::mfma(as_v8<T>(w0), xl[t][ks], yacc[t][2 * j]);
 #pragma unroll
-            for (int t = 0; t < FM; ++t) yacc[t][2 * j + 1] = OpT<T>::mfma(as_v8<T>(w1), xl[t][ks], yacc[t][2 * j + 1]);
+                for (int t = 0; t < FM; ++t) yacc[t][2 * j + 1] = OpT<T>::mfma(as_v8<T>(w1), xl[t][ks], yacc[t][2 * j + 1]);
+            }
 #pragma unroll
             for (int t = 0; t < FM; ++t) yacc[t][2 * j] = OpT<T>::mfma(as_v8<T>(w0), xh[t][ks], yacc[t][2 * j]);
 #pragma unroll
@@ -229,10 +236,12 @@ proj_mlp2_kernel(const Block2Args<T> a) {
 #pragma unroll
         for (int t = 0; t < FM; ++t) { hacc[t][0] = f32x4{0.f, 0.f, 0.f, 0.f}; hacc[t][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
         sk_stream<KS, RD, P_LDS>(lrd + slot * S::SLOT, [&](int ks, const uint4& w0, const uint4& w1) {
+            if constexpr (!S::ONE) {
 #pragma unroll
-            for (int t = 0; t < FM; ++t) hacc[t][0] = OpT<T>::mfma(as_v8<T>(w0), xl[t][ks], hacc[t][0]);
+                for (int t = 0; t < FM; ++t) hacc[t][0] = OpT<T>::mfma(as_v8<T>(w0), xl[t][ks], hacc[t][0]);
 #pragma unroll
-            for (int t = 0; t < FM; ++t) hacc[t][1] = OpT<T>::mfma(as_v8<T>(w1), xl[t][ks], hacc[t][1]);
+                for (int t = 0; t < FM; ++t) hacc[t][1] = OpT<T>::mfma(as_v8<T>(w1), xl[t][ks], hacc[t][1]);
+            }
 #pragma unroll
             for (int t = 0; t < FM; ++t) hacc[t][0] = OpT<T>::mfma(as_v8<T>(w0), xh[t][ks], hacc[t][0]);
 #pragma unroll
@@ -255,10 +264,12 @@ proj_mlp2_kernel(const Block2Args<T> a) {
     };
     auto fc2 = [&](int slot) {                          // W2 chunk in `slot`, operand hh / hl -> yacc
         sk_stream<CF / 2, RD, P_LDS>(lrd + slot * S::SLOT, [&](int p, const uint4& w0, const uint4& w1) {
+            if constexpr (!S::ONE) {
 #pragma unroll
-            for (int t = 0; t < FM; ++t) yacc[t][2 * p] = OpT<T>::mfma(as_v8<T>(w0), as_v8<T>(hl[t]), yacc[t][2 * p]);
+                for (int t = 0; t < FM; ++t) yacc[t][2 * p] = OpT<T>::mfma(as_v8<T>(w0), as_v8<T>(hl[t]), yacc[t][2 * p]);
 #pragma unroll
-            for (int t = 0; t < FM; ++t) yacc[t][2 * p + 1] = OpT<T>::mfma(as_v8<T>(w1), as_v8<T>(hl[t]), yacc[t][2 * p + 1]);
+                for (int t = 0; t < FM; ++t) yacc[t][2 * p + 1] = OpT<T>::mfma(as_v8<T>(w1), as_v8<T>(hl[t]), yacc[t][2 * p + 1]);
+            }
 #pragma unroll
             for (int t = 0; t < FM; ++t) yacc[t][2 * p] = OpT<T>::mfma(as_v8<T>(w0), as_v8<T>(hh[t]), yacc[t][2 * p]);
 #pragma unroll
@@ -373,12 +384,13 @@ static hipError_t launch_blk2(const Block2Args<T>& a, hipStream_t s) {
 
 // SKP_BLK2_VARIANT (measurement only): 0 default (two 4-wave workgroups per CU) | 1 one 8-wave workgroup, one barrier per chunk | 2 ... with the
 // halves of the workgroup half a chunk apart | 10.. timing probes of variant 1 (C = 384)
-hipError_t op_proj_mlp_skew(const Geom& g, const BlockW<f16>& b, const int* winv, int res, f16* Xs, const Work<PrecF16x3>& wk, hipStream_t s) {
+hipError_t op_proj_mlp_skew(const Geom& g, const BlockW<f16>& b, const int* winv, int res, f16* Xs, const Work<PrecF16x3>& wk, hipStream_t s, int one) {
     typedef f16 T;
     Block2Args<T> a{wk.ao, wk.ao_plane, g.ntok[res], Xs, wk.xs_plane[res], winv, b.projh, b.w1h, b.w2h,
                     b.proj_b, b.n1_g, b.n1_b, b.fc1_b, b.fc2_b, b.n2_g, b.n2_b, 1e-5f};
     if (a.M % 16 != 0) return hipErrorInvalidValue;
     static const int variant = [] { const char* v = getenv("SKP_BLK2_VARIANT"); return v ? atoi(v) : 0; }();
+    if (one) return res == 0 ? launch_blk2<T, Blk2Shape<192, 2, 2, false, true, 0, true>>(a, s) : launch_blk2<T, Blk2Shape<384, 1, 2, false, true, 0, true>>(a, s);
     if (res == 0) {
         switch (variant) {
             case 1: return launch_blk2<T, Blk2Shape<192, 2, 2, false, false>>(a, s);

@@ -94,6 +94,8 @@ def calibrated_params(params: dict, term_plan: int, taps: Iterable, rounding: st
         for kind in short_kinds(term_plan, layer):
             pre = f"layer{layer}.block{i}.{kind}."
             x = operands[kind]
+            if kind != "attn.qkv" and (term_plan >> (7 + layer)) & 1:
+                x = x.to(torch.float16).float()                   # a one-term layer: this GEMM reads the operand's fp16 hi plane
             w = params[pre + "weight"].to(x.device, torch.float32)
             b = params[pre + "bias"].to(x.device, torch.float32)
             mu, cov = operand_statistics(x)

@@ -24,7 +24,7 @@ PREC_F16X3_Q = 4
 PREC_F16X3_QH = 5
 # per-layer MFMA term plan (skpangu_config.term_plan): bit l = layer l + 1 runs proj / fc1 / fc2 with two terms (weights as ONE fp16 plane);
 # bits 4-7: the layer's QKV with ONE term (stream hi plane x weight hi plane)
-TERM_PLANS = {"f16x2m": 0x6F, "f16x2c": 0x66, "f16x2": 0x0F, "f16x2q": 0xFF}
+TERM_PLANS = {"f16x2m": 0x6F, "f16x2c": 0x66, "f16x2": 0x0F, "f16x2q": 0xFF, "f16x1m": 0x66F}
 PRECISIONS = {"bf16x3": PREC_BF16X3, "f16": PREC_F16, "bf16x3h": PREC_BF16X3_H16,
               "f16x3": PREC_F16X3, "f16x3q": PREC_F16X3_Q, "f16x3qh": PREC_F16X3_QH, **{m: PREC_F16X3_Q for m in TERM_PLANS}}
 # default "f16x2m" (plan 0x6F): fp16 hi/lo ACTIVATION planes everywhere; proj / fc1 / fc2 of EVERY block with their weights as ONE fp16 plane
@@ -33,7 +33,9 @@ PRECISIONS = {"bf16x3": PREC_BF16X3, "f16": PREC_F16, "bf16x3h": PREC_BF16X3_H16
 # A x (W - fp16(W)), has its mean over a calibration state folded into the bias at load time (``PanguEngine.calibrate``): measured at
 # 721x1440 over four steps, plan 0xFF 8.4e-4 -> 7.4e-4, 0x66 5.0e-4 -> 2.9e-4, 0x0F 5.0e-4 (calibrated).  "f16x2c" keeps layers 1 / 4 at three
 # terms (0x66, round 3's first default), "f16x2q" / "f16x2" are the all-layers plans 0xFF / 0x0F, "f16x3q" is three terms everywhere
-# (~1e-4), "bf16x3" the wide-range alternative (activations beyond fp16's 65504).
+# (~1e-4), "bf16x3" the wide-range alternative (activations beyond fp16's 65504).  "f16x1m" (0x66F; bits 8-11: the layer's proj / fc1 / fc2 with
+# ONE term, the activation operands as their fp16 hi plane) is f16x2m with the coarse layers 2 / 3 at half the MFMAs again; it wants
+# rounding="compensated" (pangu/calibration.py fits the weights to the rounded operands): oracle emulation 1.3e-4 against 6.5e-5.
 DEFAULT_PRECISION = "f16x2m"
 DEFAULT_ROUNDING = "nearest"       # of the one-plane weights (PanguEngine.load_params); "compensated": pangu/calibration.py
 

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     assert lib.skpangu_abi_version() == 4
 
 
-@pytest.mark.parametrize("prec", ["bf16x3", "f16", "f16x3q", "f16x3qh", "f16x2", "f16x2q", "f16x2m", "f16x2c"])
+@pytest.mark.parametrize("prec", ["bf16x3", "f16", "f16x3q", "f16x3qh", "f16x2", "f16x2q", "f16x2m", "f16x2c", "f16x1m"])
 @pytest.mark.parametrize("grid", [(49, 192), (721, 1440)])
 def test_param_table_matches_host_spec(grid, prec):
     g = PanguGeometry(*grid)
@@ -64,8 +64,11 @@ def test_term_plan_sizes_and_validation():
         E.make_config(g, "f16x2", mlp="split")
     out = E.SkSizes()
     bad = E.make_config(g, "f16x2")
-    bad.term_plan = 0x100
-    assert lib.skpangu_query_sizes(ctypes.byref(bad), ctypes.byref(out)) == -1
+    for plan, ok in ((0x100, False), (0x1000, False), (0x210, False), (0x101, True), (0x66F, True), (0xFFF, True)):
+        bad.term_plan = plan                  # bits 8-11 (one-term block GEMMs) need the layer's two-term bit; nothing beyond 12 bits
+        assert (lib.skpangu_query_sizes(ctypes.byref(bad), ctypes.byref(out)) == 0) == ok, hex(plan)
+    assert E.make_config(g, "f16x1m").term_plan == 0x66F
+    assert E.query_sizes(g, "f16x1m").prepared_bytes == E.query_sizes(g, "f16x2m").prepared_bytes      # same weights, fewer MFMAs
 
 
 def test_bad_arguments_are_errors_not_crashes():

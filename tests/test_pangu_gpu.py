@@ -285,7 +285,7 @@ def test_pangu_model_rollout_through_reference_api(toy, tmp_path):
                                                      "pangu__file__20240514_00:00__20240514_06:00.nc"]
     ic = torch.from_numpy(m.data_source[t0])
     want = O.rollout(params, ic, 2)
-    assert O.per_channel_rel_err(torch.from_numpy(pred.values[0]), want[0]).max().item() < 1e-3
+    assert O.per_channel_rel_err(torch.from_numpy(pred.values[0].copy()), want[0]).max().item() < 1e-3
     assert O.per_channel_rel_err(torch.from_numpy(pred.values[1]), want[1]).max().item() < 1e-3
     back = open_dataarray(paths[0])
     assert O.per_channel_rel_err(torch.from_numpy(back.values[1].copy()), want[0]).max().item() < 1e-3
@@ -590,6 +590,36 @@ def test_compensated_rounding_of_the_one_plane_weights(toy, ref):
     out = mid + torch.nn.functional.layer_norm(torch.nn.functional.linear(hid, bp["mlp.fc2.weight"], bp["mlp.fc2.bias"]), (192,), bp["norm2.weight"], bp["norm2.bias"], 1e-5)
     assert rel(out, want_mid_to_out) < 1e-3                          # mid-block stream and hidden are the block's own
     assert ops["attn.proj"].shape == x1.shape and torch.isfinite(ops["attn.proj"]).all()
+
+
+def test_one_term_block_gemms_in_the_coarse_layers(toy, ref):
+    """Term-plan bits 8-11 (include/skyrim_pangu.h): proj / fc1 / fc2 of a layer with ONE MFMA term -- the activation operands too as their
+    fp16 hi plane (csrc/fused_block2.hip, ONE).  "f16x1m" = f16x2m with layers 2 / 3 (12 of 16 blocks) in that form.  With the weights
+    fitted to the rounded operands (rounding="compensated") the step stays near the three-term error; the oracle emulation of exactly
+    this plan: 1.3e-4 against 6.5e-5."""
+    from skyrim_amd.pangu.engine import PanguEngine, TERM_PLANS
+    g, params, x = toy
+    taps, y_ref = ref
+    assert TERM_PLANS["f16x1m"] == 0x66F
+    errs, outs = {}, {}
+    for rounding in ("nearest", "compensated"):
+        eng = PanguEngine(g, "f16x1m", "cuda:0")
+        eng.load_params(params, rounding=rounding)
+        assert eng.term_plan == 0x66F
+        outs[rounding] = eng.step(x.cuda()).cpu()
+        errs[rounding] = O.per_channel_rel_err(outs[rounding], y_ref).max().item()
+    two = PanguEngine(g, "f16x2m", "cuda:0")
+    two.load_params(params, rounding="compensated")
+    y2 = two.step(x.cuda()).cpu()
+    errs["two-term, compensated"] = O.per_channel_rel_err(y2, y_ref).max().item()
+    print("f16x1m one step: " + ", ".join(f"{k} {v:.2e}" for k, v in errs.items()))
+    assert errs["nearest"] < 1e-3 and errs["compensated"] < 5e-4, errs
+    assert not torch.equal(outs["compensated"], y2)
+    # a one-term layer's block differs from the two-term engine's, an untouched layer's does not
+    x2, x1 = taps["down"].float().cuda().contiguous(), taps["embed"].float().cuda().contiguous()
+    assert not torch.equal(eng.block(2, 0, x2), two.block(2, 0, x2))
+    with pytest.raises(RuntimeError):
+        PanguEngine(g, "f16x3q", "cuda:0", term_plan=0x100)          # one-term without two-term: rejected by skpangu_create
 
 
 def test_time_loop_calibrates_on_the_first_initial_condition(toy, ref):
