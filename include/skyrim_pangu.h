@@ -108,6 +108,10 @@ void skpangu_destroy(skpangu_ctx* ctx);
  * earth-specific bias expanded per window type with the shifted-window mask folded in, window
  * gather tables).  Replaces the ONNX-session construction of earth2mip.networks.pangu.load. */
 int skpangu_prepare(skpangu_ctx* ctx, const float* master_dev, void* stream);
+/* The one-plane weights of a term plan are rounded to nearest here; master weights that already sit on the fp16 grid pass through
+ * unchanged, so a host may hand in weights it rounded itself -- skyrim_amd/pangu/calibration.py does (error feedback against the operand
+ * statistics of a calibration state, with the biases folded), and reads those operands through the stage-level entry points and
+ * skpangu_debug_buffer below. */
 
 /* Calibration of a term plan (config.term_plan != 0; a no-op otherwise), after skpangu_prepare and with the same master blob.
  * A Linear run with its weights as ONE fp16 plane drops A x (W - fp16(W)); over the tokens of a state that term has a mean, which is a
