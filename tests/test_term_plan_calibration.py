@@ -123,3 +123,21 @@ def test_compensated_rounding_beats_nearest_rounding(monkeypatch):
     assert torch.equal(compensated_round(w, torch.eye(64, dtype=torch.float64)), _fp16(w))
     with pytest.raises(RuntimeError):
         calibrated_params(p, 0x0F, taps)                              # the plan names layers the taps did not cover
+
+
+def test_plane_readback_helpers_invert_the_blocked_layout():
+    """calibration._planes / _unblock against csrc/common.h's blk_off: element (row, col) of a [rows][K] operand sits at
+    ((row >> 4) * (K >> 5) + (col >> 5)) * 512 + (row & 15) * 32 + (col & 31) of its plane; hi at the start of the buffer, lo one
+    plane (half the buffer) further."""
+    from skyrim_amd.pangu.calibration import _planes, _unblock
+    rows, k, plane = 48, 96, 48 * 96 + 512            # the plane is larger than the operand (sized for the other resolution)
+    x = torch.randn(rows, k) * 3.0
+    hi = x.to(torch.float16)
+    lo = (x - hi.float()).to(torch.float16)
+    r, c = torch.meshgrid(torch.arange(rows), torch.arange(k), indexing="ij")
+    off = ((r >> 4) * (k >> 5) + (c >> 5)) * 512 + (r & 15) * 32 + (c & 31)
+    buf = torch.zeros(2 * plane, dtype=torch.float16)
+    buf[off.reshape(-1)] = hi.reshape(-1)
+    buf[plane + off.reshape(-1)] = lo.reshape(-1)
+    got = _unblock(_planes(buf.view(torch.uint8), rows * k), rows, k)
+    assert torch.equal(got, hi.float() + lo.float()) and (got - x).abs().max() < 1e-5
