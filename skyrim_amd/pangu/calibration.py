@@ -14,6 +14,11 @@ Measured on the CPU restatement (tests/test_term_plan_calibration.py; statistics
 of one 6-h step with proj / fc1 / fc2 of all 16 blocks on one plane -- nearest 4.2e-4, nearest + mean fold 2.0e-4, compensated + mean fold
 7.5e-5 (three terms everywhere: 6.6e-5).
 
+The statistics are pooled over the calibration state AND its own 6-h forecast (``PanguEngine.calibrate``): fitted to the first alone, the
+error of a rollout climbs back towards nearest rounding from its second step on -- the second step's input is a model output, a
+different distribution -- (oracle emulation, plan 0xFF, four steps: 6.3e-5 / 2.6e-4 / 2.4e-4 / 2.5e-4); fitted to both it stays where it
+started (6.6e-5 / 5.5e-5 / 6.8e-5 / 7.1e-5).
+
 ``engine_taps`` collects the operands on the GPU: one step of the THREE-term engine in its tiled form (mlp="split": the attention output
 and the hidden activation reach HBM there), stage by stage through the C ABI's stage-level entry points, reading the engine's own buffers
 back.  Nothing here runs per step, and nothing here is an alternative compute path: the forecasts run on the HIP kernels only.
@@ -129,33 +134,39 @@ def _unblock(flat: torch.Tensor, rows: int, cols: int) -> torch.Tensor:
     return flat[:rows * cols].reshape(rows // 16, cols // 32, 16, 32).permute(0, 2, 1, 3).reshape(rows, cols)
 
 
-def engine_taps(eng, params: dict, state: torch.Tensor) -> Iterator:
-    """One step of a three-term, tiled-form engine (``PanguEngine(geom, "f16x3q", mlp="split")`` with ``params`` loaded) on ``state``,
-    stage by stage; yields ``(layer, block, operands)`` where ``operands[kind]`` is the fp32 [tokens, K] operand of that Linear:
-    the stream rounded to fp16 for the QKV (what a one-term QKV reads), the attention output in token order, the mid-block stream
+def engine_taps(eng, params: dict, states) -> Iterator:
+    """One step of a three-term, tiled-form engine (``PanguEngine(geom, "f16x3q", mlp="split")`` with ``params`` loaded) on every state
+    of ``states`` (a (69, n_lat, n_lon) tensor or a list of them), stage by stage and in lock-step; yields ``(layer, block, operands)``
+    where ``operands[kind]`` holds the fp32 [tokens, K] operand rows of that Linear for all states, one after the other: the stream
+    rounded to fp16 for the QKV (what a one-term QKV reads), the attention output in token order, the mid-block stream
     ``x + LayerNorm(proj(attention))``, the hidden activation."""
     if eng.mlp != "split" or eng.term_plan:
         raise ValueError("engine_taps needs the tiled three-term engine (mlp='split', no term plan)")
+    if isinstance(states, torch.Tensor):
+        states = [states]
     dev = eng.device
-    x = eng.patch_embed(state.to(dev, torch.float32).contiguous())
+    xs = [eng.patch_embed(s.to(dev, torch.float32).contiguous()) for s in states]
     for layer in range(1, 5):
         if layer == 2:
-            x = eng.downsample(x)
+            xs = [eng.downsample(x) for x in xs]
         elif layer == 4:
-            x = eng.upsample(x)
+            xs = [eng.upsample(x) for x in xs]
         ntok, c = eng.tokens(layer)
         res = 0 if layer in (1, 4) else 1
         for i in range(DEPTHS[layer - 1]):
-            y = eng.block(layer, i, x)
-            widx = eng.debug_buffer(f"widx{res}{i & 1}", torch.int32).long()     # window row -> stream token, -1 on padding rows
-            mwin = widx.numel()
-            ao_win = _unblock(_planes(eng.debug_buffer("ao", torch.uint8), mwin * c), mwin, c)
-            valid = widx >= 0
-            ao = torch.empty(ntok, c, dtype=torch.float32, device=dev)
-            ao[widx[valid]] = ao_win[valid]
             pre = f"layer{layer}.block{i}."
             p = {k: params[pre + k].to(dev, torch.float32) for k in ("attn.proj.weight", "attn.proj.bias", "norm1.weight", "norm1.bias")}
-            mid = x + F.layer_norm(F.linear(ao, p["attn.proj.weight"], p["attn.proj.bias"]), (c,), p["norm1.weight"], p["norm1.bias"], 1e-5)
-            hid = _unblock(_planes(eng.debug_buffer("hid", torch.uint8), ntok * 4 * c), ntok, 4 * c)
-            yield layer, i, {"attn.qkv": x.to(torch.float16).float(), "attn.proj": ao, "mlp.fc1": mid, "mlp.fc2": hid}
-            x = y
+            widx = eng.debug_buffer(f"widx{res}{i & 1}", torch.int32).long()     # window row -> stream token, -1 on padding rows
+            mwin = widx.numel()
+            valid = widx >= 0
+            per_state = []
+            for k, x in enumerate(xs):
+                y = eng.block(layer, i, x)
+                ao_win = _unblock(_planes(eng.debug_buffer("ao", torch.uint8), mwin * c), mwin, c)
+                ao = torch.empty(ntok, c, dtype=torch.float32, device=dev)
+                ao[widx[valid]] = ao_win[valid]
+                mid = x + F.layer_norm(F.linear(ao, p["attn.proj.weight"], p["attn.proj.bias"]), (c,), p["norm1.weight"], p["norm1.bias"], 1e-5)
+                hid = _unblock(_planes(eng.debug_buffer("hid", torch.uint8), ntok * 4 * c), ntok, 4 * c)
+                per_state.append({"attn.qkv": x.to(torch.float16).float(), "attn.proj": ao, "mlp.fc1": mid, "mlp.fc2": hid})
+                xs[k] = y
+            yield layer, i, {kind: torch.cat([o[kind] for o in per_state]) for kind in KINDS}

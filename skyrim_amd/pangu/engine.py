@@ -265,9 +265,9 @@ class PanguEngine:
         engines without a plan.  Calling again starts over from the parameters handed to ``load_params``.
         rounding "nearest": fold the mean of the dropped term, A x (W - fp16(W)), into each bias -- one step on ``state`` through the
         three-term kernels, column means of every short Linear's operand (include/skyrim_pangu.h: skpangu_calibrate).
-        rounding "compensated": the operands of one three-term step on ``state`` (a second, tiled-form engine that lives for the
-        duration of this call), their covariances, error-compensated fp16 weights + folded biases (pangu/calibration.py), prepared
-        again."""
+        rounding "compensated": the operands of one three-term step on ``state`` and of one on its forecast (a second, tiled-form
+        engine that lives for the duration of this call), their pooled second moments, error-compensated fp16 weights + folded biases
+        (pangu/calibration.py), prepared again."""
         if not self.term_plan:
             return
         if getattr(self, "_params", None) is None:
@@ -278,8 +278,10 @@ class PanguEngine:
                 from .calibration import calibrated_params, engine_taps
                 tap = PanguEngine(self.geom, "f16x3q", self.device, mlp="split", **self._conventions)
                 tap.load_params(self._params, calibration="off")
-                with torch.no_grad():
-                    params = calibrated_params(self._params, self.term_plan, engine_taps(tap, self._params, state))
+                with torch.no_grad(), torch.cuda.device(self.device):
+                    first = state.to(self.device, torch.float32).contiguous()
+                    states = [first, tap.step(first)]           # the state and its own 6-h forecast: a rollout's later inputs are model outputs
+                    params = calibrated_params(self._params, self.term_plan, engine_taps(tap, self._params, states))
                 del tap
             self._prepare(params)                               # fp16-grid weights: the library's own rounding leaves them as they are
             torch.cuda.empty_cache()

@@ -141,3 +141,106 @@ def test_plane_readback_helpers_invert_the_blocked_layout():
     buf[plane + off.reshape(-1)] = lo.reshape(-1)
     got = _unblock(_planes(buf.view(torch.uint8), rows * k), rows, k)
     assert torch.equal(got, hi.float() + lo.float()) and (got - x).abs().max() < 1e-5
+
+
+class _OracleTapEngine:
+    """Stands in for the tiled three-term GPU engine in ``calibration.engine_taps``: the same stage-level calls and debug buffers
+    (window tables, attention output and hidden activation as hi/lo fp16 planes in the blocked layout), filled from the oracle."""
+    mlp, term_plan = "split", 0
+
+    def __init__(self, g, params):
+        import importlib.util
+        from pathlib import Path
+        spec = importlib.util.spec_from_file_location("gpu_diag", Path(__file__).resolve().parent.parent / "tools" / "gpu_diag.py")
+        self.diag = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(self.diag)                         # block_reference: an oracle block with its intermediates
+        self.geom, self.p, self.device = g, params, torch.device("cpu")
+        self.og = O.Geometry(g.n_lat, g.n_lon)
+        self.bufs = {}
+        self.plane = {"ao": max(self._mwin(1) * 192, self._mwin(2) * 384), "hid": max(g.tokens(1) * 768, g.tokens(2) * 1536)}
+
+    def _mwin(self, layer):
+        z, h, w = self.geom.res(layer)
+        return z * self.geom.padded_lat(layer) * w
+
+    def tokens(self, layer):
+        return self.geom.tokens(layer), self.geom.dim(layer)
+
+    def patch_embed(self, state):
+        xn = (state - self.p["norm.mean"][:, None, None]) / self.p["norm.std"][:, None, None]
+        return O.patch_embed(self.p, self.og, *O.split_state(xn))
+
+    def downsample(self, x):
+        return O.downsample(self.p, self.og, x)
+
+    def upsample(self, x):
+        return O.upsample(self.p, self.og, x)
+
+    def step(self, x):
+        return O.forward(self.p, x)
+
+    def _store(self, name, rows):
+        hi = rows.to(torch.float16)
+        lo = (rows - hi.float()).to(torch.float16)
+        r, k = rows.shape
+        buf = torch.zeros(2 * self.plane[name], dtype=torch.float16)
+        for j, t in enumerate((hi, lo)):
+            buf[j * self.plane[name]: j * self.plane[name] + r * k] = t.reshape(r // 16, 16, k // 32, 32).permute(0, 2, 1, 3).reshape(-1)
+        self.bufs[name] = buf
+
+    def block(self, layer, i, x):
+        ref = self.diag.block_reference(O._block_params(self.p, layer, i), x, self.og.res(layer), O.HEADS[layer - 1], i % 2 == 1)
+        self._store("ao", ref["ao"])
+        self._store("hid", ref["hid"])
+        return ref["y"]
+
+    def debug_buffer(self, name, dtype):
+        if name.startswith("widx"):
+            layer, roll = (1, 2)[int(name[4])], int(name[5])
+            z, h, w = self.geom.res(layer)
+            hp, top = self.geom.padded_lat(layer), self.geom.pad_top(layer)
+            t = F.pad(torch.arange(z * h * w).reshape(z, h, w) + 1, (0, 0, top, hp - h - top)) - 1
+            if roll:
+                t = torch.roll(t, shifts=(-1, -3, -6), dims=(0, 1, 2))
+            return t.reshape(z // 2, 2, hp // 6, 6, w // 12, 12).permute(0, 2, 4, 1, 3, 5).reshape(-1).to(dtype)
+        return self.bufs[name].view(dtype)
+
+
+def test_engine_taps_reads_back_the_operands_of_every_block(monkeypatch):
+    """calibration.engine_taps end to end on the CPU, the GPU engine replaced by an oracle-backed stand-in with the same buffers: the
+    rows it delivers for the calibration state and its forecast ARE the operands of the oracle's Linears (pooled: second half = the
+    forecast's), and the parameters fitted to them hold their error over a rollout where a single-state fit does not."""
+    from skyrim_amd.pangu.calibration import calibrated_params, engine_taps
+    g = PanguGeometry(49, 192)
+    p = init_synthetic(g, 3)
+    x, x_cal = synthetic_state(g, 3), synthetic_state(g, 11)
+    eng = _OracleTapEngine(g, p)
+    states = [x_cal, eng.step(x_cal)]
+    taps = list(engine_taps(eng, p, states))
+    assert [(layer, i) for layer, i, _ in taps] == [(layer, i) for layer in (1, 2, 3, 4) for i in range((2, 6, 6, 2)[layer - 1])]
+    want = {(layer, i): ops for layer, i, ops in _oracle_taps(monkeypatch, p, states[1])}      # the oracle's own operands on the forecast
+    for layer, i, ops in taps:
+        n = g.tokens(layer)
+        for kind in ("mlp.fc1", "mlp.fc2"):
+            assert ops[kind].shape[0] == 2 * n
+            ref = want[(layer, i)][kind]
+            assert ((ops[kind][n:] - ref).abs().max() / ref.abs().max()).item() < 1e-5, (layer, i, kind)
+        q_in = want[(layer, i)]["attn.qkv"]                           # window order without the padding rows: compare as multisets of rows
+        assert ops["attn.qkv"][n:].shape == q_in.shape and torch.allclose(ops["attn.qkv"][n:].sum(0), q_in.sum(0), rtol=1e-3, atol=1e-2)
+    plan = 0x99
+    sub = [t for t in taps if t[0] in (1, 4)]
+    single = [(layer, i, {k: v[: g.tokens(layer)] for k, v in ops.items()}) for layer, i, ops in sub]
+    refs, s = [], x
+    for _ in range(3):
+        s = O.forward(p, s)
+        refs.append(s)
+    errs = {}
+    for tag, t in (("single", single), ("pooled", sub)):
+        q = calibrated_params(p, plan, t)
+        s, e = x, []
+        for k in range(3):
+            s = O.forward(q, s)
+            e.append(O.per_channel_rel_err(s, refs[k]).max().item())
+        errs[tag] = e
+    print(errs)
+    assert max(errs["pooled"]) < 1e-4 and errs["pooled"][2] < 0.7 * errs["single"][2]
