@@ -18,7 +18,7 @@
 extern "C" {
 #endif
 
-#define SKGC_ABI_VERSION 3
+#define SKGC_ABI_VERSION 4
 #define SKGC_E_ARG (-1)
 #define SKGC_E_HIP (-2)
 
@@ -90,6 +90,61 @@ typedef struct skgc_sum_desc {
     int group;
 } skgc_sum_desc;
 int skgc_sum_linear_layer_norm(const skgc_sum_desc* desc, void* stream);
+
+/* ---- ABI v4: an interaction-network update as ONE kernel (csrc/graphcast_fused.hip; layouts: skyrim_amd/graphcast/fused.py) ----------
+ *
+ * Edge update + receiver sum, latent 512, on PACKED rows (multiples of 128; a receiver's run of rows never crosses a 128-row tile unless
+ * it is longer than a tile; padding rows have recv < 0 and idx < 0):
+ *     pre  = (has_fc1 ? e_in W_e^T : e_in) + sum_s term[s][ idx[s][row] ]            first Linear by distributivity (b1 folded into a term)
+ *     y    = LayerNorm( swish(pre) W2^T + b2 ) * gamma + beta
+ *     e_out[row] = e_in[row] + y   (has_fc1 only, nullable)          agg[ recv[row] ] = sum of y over the receiver's run of rows
+ * e_in / e_out: ONE fp16 plane in the blocked layout [rows/16][16][16][32] (may alias); with has_fc1 == 0, e_in is the prepared
+ * first-Linear term in "pos" column order.  term[s]: fp32 rows, leading dimension ld[s], "pos" column order.  w1f / w2f: fp16 hi/lo
+ * planes in MFMA fragment order (fused.py: prep_w1_fragments / prep_w2_fragments).  Two MFMA terms (W_hi x + W_lo x): activations are
+ * rounded to fp16, weights are not.  A tile whose first run continues the previous tile's last run writes that run's sum to
+ * heads[tile] instead of agg; skgc_segment_fixup adds those pieces (agg[nodes[i]] += heads[tiles[k]], first[i] <= k < first[i + 1],
+ * in that order).  Every receiver with at least one row is written exactly once per call; deterministic (no atomics). */
+typedef struct skgc_edge_desc {
+    const void* e_in;
+    void* e_out;
+    const float* term[2];
+    const int* idx[2];
+    long long ld[2];
+    int n_term;              /* 0..2 */
+    const int* recv;
+    const void* w1f;
+    const void* w2f;
+    const float* b2;
+    const float* gamma;
+    const float* beta;
+    float* agg;
+    float* heads;            /* [rows / 128][512]; may be NULL when no tile continues its predecessor */
+    long long rows;
+    int has_fc1;
+} skgc_edge_desc;
+int skgc_edge_update(const skgc_edge_desc* desc, void* stream);
+int skgc_segment_fixup(float* agg, const float* heads, const int* nodes, const int* first, const int* tiles, int n_nodes, void* stream);
+
+/* Node update on fp32 rows, latent 512, three MFMA terms (fp32 operands split into fp16 hi/lo on the fly):
+ *     out[r] = (res ? res[r] : 0) + LayerNorm( swish( concat_s src[s][r] W1^T + b1 ) W2^T + b2 ) * gamma + beta,   r < rows
+ * src[s]: fp32 rows of 512 columns (n_src = 1 or 2: W1 is [512][512 n_src]); out may alias res or a source. */
+typedef struct skgc_node_desc {
+    const float* src[2];
+    long long ld[2];
+    int n_src;
+    const void* w1f;
+    const void* w2f;
+    const float* b1;
+    const float* b2;
+    const float* gamma;
+    const float* beta;
+    const float* res;
+    long long ld_res;
+    float* out;
+    long long ld_out;
+    long long rows;
+} skgc_node_desc;
+int skgc_node_mlp(const skgc_node_desc* desc, void* stream);
 
 #ifdef __cplusplus
 }

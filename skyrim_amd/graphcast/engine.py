@@ -22,12 +22,13 @@ import torch
 
 from .. import ops
 from ..sfno import engine as _sf
+from . import fused as _fz
 from .mesh import GraphStructure, build_graph, grouped_rows_by3, latitude_band, shard_graph
 from .spec import N_FORCING, N_STATIC, GraphcastConfig, mlp_names, param_spec
 
 _LIB_PATH = Path(__file__).resolve().parent.parent / "lib" / "libskyrim_graphcast.so"
 EXPORTS = ["skgc_abi_version", "skgc_gather_gemm", "skgc_layer_norm", "skgc_segment_sum", "skgc_prepare_weight_perm8",
-           "skgc_linear_layer_norm", "skgc_sum_linear_layer_norm"]
+           "skgc_linear_layer_norm", "skgc_sum_linear_layer_norm", "skgc_edge_update", "skgc_segment_fixup", "skgc_node_mlp"]
 
 
 class GatherDesc(ctypes.Structure):
@@ -42,6 +43,19 @@ class SumDesc(ctypes.Structure):
                 ("act", ctypes.c_int), ("w", ctypes.c_void_p), ("w_plane", ctypes.c_longlong), ("ldw", ctypes.c_int), ("bias", ctypes.c_void_p),
                 ("gamma", ctypes.c_void_p), ("beta", ctypes.c_void_p), ("res", ctypes.c_void_p), ("out", ctypes.c_void_p), ("rows", ctypes.c_longlong),
                 ("group", ctypes.c_int)]
+
+
+class EdgeDesc(ctypes.Structure):
+    _fields_ = [("e_in", ctypes.c_void_p), ("e_out", ctypes.c_void_p), ("term", ctypes.c_void_p * 2), ("idx", ctypes.c_void_p * 2), ("ld", ctypes.c_longlong * 2),
+                ("n_term", ctypes.c_int), ("recv", ctypes.c_void_p), ("w1f", ctypes.c_void_p), ("w2f", ctypes.c_void_p), ("b2", ctypes.c_void_p),
+                ("gamma", ctypes.c_void_p), ("beta", ctypes.c_void_p), ("agg", ctypes.c_void_p), ("heads", ctypes.c_void_p), ("rows", ctypes.c_longlong),
+                ("has_fc1", ctypes.c_int)]
+
+
+class NodeDesc(ctypes.Structure):
+    _fields_ = [("src", ctypes.c_void_p * 2), ("ld", ctypes.c_longlong * 2), ("n_src", ctypes.c_int), ("w1f", ctypes.c_void_p), ("w2f", ctypes.c_void_p),
+                ("b1", ctypes.c_void_p), ("b2", ctypes.c_void_p), ("gamma", ctypes.c_void_p), ("beta", ctypes.c_void_p), ("res", ctypes.c_void_p),
+                ("ld_res", ctypes.c_longlong), ("out", ctypes.c_void_p), ("ld_out", ctypes.c_longlong), ("rows", ctypes.c_longlong)]
 
 
 _lib = None
@@ -62,6 +76,9 @@ def load_library():
     lib.skgc_linear_layer_norm.argtypes = [ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int] + \
         [ctypes.c_void_p] * 5 + [ctypes.c_longlong, ctypes.c_void_p]
     lib.skgc_sum_linear_layer_norm.argtypes = [ctypes.POINTER(SumDesc), ctypes.c_void_p]
+    lib.skgc_edge_update.argtypes = [ctypes.POINTER(EdgeDesc), ctypes.c_void_p]
+    lib.skgc_segment_fixup.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_int, ctypes.c_void_p]
+    lib.skgc_node_mlp.argtypes = [ctypes.POINTER(NodeDesc), ctypes.c_void_p]
     for name in EXPORTS:
         getattr(lib, name).restype = ctypes.c_int
     _lib = lib
@@ -113,6 +130,9 @@ class GraphcastEngine:
         # terms once per node, the edge term once per layer (once per model for the encoder / decoder, whose edge latents are
         # input-independent); needs the fused Linear + LayerNorm kernel (latent 512)
         self.split_edges = self.fused_ln and not os.environ.get("SKGC_CONCAT_EDGES")
+        # round 4: every interaction-network update as ONE kernel (csrc/graphcast_fused.hip): edge update + receiver sum on packed rows with
+        # one-plane fp16 edge operands, node updates on fp32 rows with three MFMA terms.  SKGC_UNFUSED=1 keeps the round-3 kernel sequence.
+        self.fused = self.split_edges and not os.environ.get("SKGC_UNFUSED")
         self.state_shape = (self.cfg.n_vars, self.lat1 - self.lat0, self.cfg.n_lon)
 
     def _stream(self):
@@ -206,6 +226,158 @@ class GraphcastEngine:
                 srcs.append((self.b_pr, 0, L, idx_r))
         self._sum_ln(name, srcs, rows, out, res=res, label=lab)
 
+    # ---- fused updates (round 4) ------------------------------------------------------------------------- #
+    def _edge_update(self, f, e_in, e_out, terms, agg, label):
+        """f: a prepared edge set (``_prepare_fused``); terms: [(tensor, element offset, ld, index tensor)]."""
+        L = self.cfg.latent
+        self._mark(label, 2.0 * f["n_edges"] * L * L * (2 if f.get("w1f") is not None else 1))
+        ops.hip.gc_edge_update(e_in, e_out, [t for t, _, _, _ in terms], [o for _, o, _, _ in terms], [d for _, _, d, _ in terms], [i for _, _, _, i in terms],
+                               f["recv"], f.get("w1f"), f["w2f"], f["b2"], f["g"], f["b"], agg, f.get("heads"), f["rows"])
+        if f.get("fix") is not None:
+            self._mark(label)
+            ops.hip.gc_segment_fixup(agg, f["heads"], *f["fix"])
+
+    def _node_mlp(self, name, srcs, rows, res, out, label):
+        """srcs / res / out: (tensor, element offset, ld).  out = res + LayerNorm(fc2(swish(fc1(concat(srcs)))))."""
+        m, L = self.m[name], self.cfg.latent
+        self._mark(label, 2.0 * rows * L * L * (len(srcs) + 1))
+        ops.hip.gc_node_mlp([t for t, _, _ in srcs], [o for _, o, _ in srcs], [d for _, _, d in srcs], m["w1f"], m["w2f"], m["b1"], m["b2"], m["g"], m["b"],
+                            res[0] if res is not None else None, res[1] if res is not None else 0, res[2] if res is not None else L, out[0], out[1], out[2], rows)
+
+    def _prepare_fused(self, p):
+        """Packed row orders, blocked fp16 edge operands, fragment-order weights and "pos"-ordered node-term weights (fused.py)."""
+        c, g, dev, L = self.cfg, self.graph, self.device, self.cfg.latent
+        f32 = lambda t: t.float().contiguous().to(dev)  # noqa: E731
+        i32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(dev)  # noqa: E731
+        weng = type("W", (), {"device": dev, "lib": self.sf, "_stream": self._stream})()
+        upos = torch.from_numpy(_fz.unit_at_pos(L))
+
+        def pack(edges):
+            row_edge = _fz.pack_segments(edges[:, 1])
+            ok = row_edge >= 0
+            re = np.where(ok, row_edge, 0)
+            recv = np.where(ok, edges[re, 1], -1)
+            send = np.where(ok, edges[re, 0], -1)
+            d = dict(rows=len(row_edge), n_edges=len(edges), row_edge=row_edge, recv=i32(recv), send=i32(send))
+            nodes, first, tiles = _fz.continuation_list(recv)
+            if len(nodes):
+                d["heads"] = torch.zeros(len(row_edge) // _fz.TILE, L, dtype=torch.float32, device=dev)
+                d["fix"] = (i32(nodes), i32(first), i32(tiles))
+            return d
+
+        def blocked(x, row_edge, cols=None):
+            """x [E][L] fp32 on the device -> the packed rows as one blocked fp16 plane (padding rows zero, columns optionally permuted)."""
+            out = torch.empty(len(row_edge) * L, dtype=torch.float16, device=dev)
+            re = torch.from_numpy(row_edge.astype(np.int64)).to(dev)
+            for r0 in range(0, len(row_edge), 1 << 19):
+                ix = re[r0:r0 + (1 << 19)]
+                v = x[ix.clamp_min(0)]
+                v[ix < 0] = 0.0
+                if cols is not None:
+                    v = v[:, cols]
+                out[r0 * L:(r0 + len(ix)) * L] = _fz.to_blocked_f16(v)
+            return out
+
+        def mlp_frags(name, k0=None, k1=None):
+            w1 = p[name + ".fc1.weight"]
+            w2 = p[name + ".fc2.weight"]
+            d = dict(w2f=_fz.prep_w2_fragments(f32(w2)), b2=self.m[name]["b2"], g=self.m[name]["g"], b=self.m[name]["b"])
+            if k0 is not None:
+                d["w1f"] = _fz.prep_w1_fragments(f32(w1[:, k0:k1]))
+            return d
+
+        cols = upos.to(dev)
+        F = {}
+        # grid -> mesh: the prepared term (e1_0 already holds e W_e^T + b1 + (vm0 W_r^T)[recv]) in "pos" columns; sender term per grid node
+        F["g2m"] = pack(g.g2m_edges)
+        F["g2m"].update(mlp_frags("g2m.edge"))
+        F["g2m"]["static"] = blocked(self.e1_0, F["g2m"]["row_edge"], cols)
+        w1 = p["g2m.edge.fc1.weight"]
+        F["g2m"]["w_s"] = _sf._Weight(weng, w1[:, L:2 * L][upos])
+        # multi-mesh: edge latents live in the packed order as one fp16 plane; [W_s; W_r] in "pos" rows with b1 folded into the sender term
+        me = g.mesh_edges[self.me0:self.me1]
+        F["mesh"] = pack(me)
+        F["mesh"]["em0"] = blocked(self.em_0, F["mesh"]["row_edge"])
+        F["mesh"]["em"] = torch.zeros_like(F["mesh"]["em0"])
+        deg = np.bincount(me[:, 1] - self.mn0, minlength=self.mn1 - self.mn0) if len(me) else np.zeros(self.mn1 - self.mn0, dtype=np.int64)
+        F["mesh"]["zero_agg"] = bool((deg == 0).any())
+        for i in range(c.steps):
+            name = f"proc.{i}.edge"
+            w1, b1 = p[name + ".fc1.weight"], p[name + ".fc1.bias"]
+            d = mlp_frags(name, 0, L)
+            d["w_sr"] = _sf._Weight(weng, torch.cat([w1[:, L:2 * L][upos], w1[:, 2 * L:][upos]], dim=0))
+            d["b_sr"] = f32(torch.cat([b1[upos], torch.zeros(L, dtype=b1.dtype)]))
+            F[name] = d
+        # mesh -> grid
+        F["m2g"] = pack(g.m2g_edges)
+        F["m2g"].update(mlp_frags("m2g.edge"))
+        F["m2g"]["static"] = blocked(self.e2_0, F["m2g"]["row_edge"], cols)
+        w1 = p["m2g.edge.fc1.weight"]
+        F["m2g"]["w_s"], F["m2g"]["w_r"] = _sf._Weight(weng, w1[:, L:2 * L][upos]), _sf._Weight(weng, w1[:, 2 * L:][upos])
+        F["m2g"]["zero_agg"] = bool((np.bincount(g.m2g_edges[:, 1], minlength=g.n_grid) == 0).any())
+        # node updates: fragment-order weights, three-term kernel
+        for name in ["g2m.mesh_node", "g2m.grid_node", "m2g.grid_node"] + [f"proc.{i}.node" for i in range(c.steps)]:
+            self.m[name]["w1f"] = _fz.prep_w1_fragments(f32(p[name + ".fc1.weight"]))
+            self.m[name]["w2f"] = _fz.prep_w2_fragments(f32(p[name + ".fc2.weight"]))
+        self.F = F
+        del self.e1_0, self.e2_0
+        torch.cuda.current_stream(dev).synchronize()
+
+    def _step_fused(self, y):
+        """The graph network of one step on the fused kernels: 3 launches per processor layer (node terms, edge update + receiver sum,
+        node update)."""
+        c, L, g, F = self.cfg, self.cfg.latent, self.graph, self.F
+        P, V = self.P, c.n_vars
+        # encoder: grid -> mesh
+        f = F["g2m"]
+        self._gemm(self.vg, f["w_s"], self.b_ps, P, a_sm=L, a_sk=1, o_sm=L, o_sn=1, label="encoder")
+        self.agg_m.zero_()                                   # receivers without an edge on this rank (grid-sharded runs) must read zero
+        self._edge_update(f, f["static"], None, [(self.b_ps, 0, L, f["send"])], self.agg_m, "encoder")
+        if self.world > 1 or self.exercise:
+            self._mark("exchange")
+            if self.reduce_fn is not None:
+                self.reduce_fn(self.agg_m)
+            else:
+                import torch.distributed as dist
+                dist.all_reduce(self.agg_m, op=dist.ReduceOp.SUM)
+        self._node_mlp("g2m.mesh_node", [(self.vm0, 0, L), (self.agg_m, 0, L)], g.n_mesh, (self.vm0, 0, L), (self.vm, 0, L), "encoder")
+        self._node_mlp("g2m.grid_node", [(self.vg, 0, L)], P, (self.vg, 0, L), (self.vg, 0, L), "encoder")
+        # processor
+        nl, o0 = self.mn1 - self.mn0, self.mn0 * L
+        f = F["mesh"]
+        for i in range(c.steps):
+            d = F[f"proc.{i}.edge"]
+            self._gemm(self.vm, d["w_sr"], self.b_ps, g.n_mesh, a_sm=L, a_sk=1, o_sm=2 * L, o_sn=1, bias=d["b_sr"], label="processor")
+            if f["zero_agg"]:
+                self.agg_m[self.mn0:self.mn1].zero_()
+            self._edge_update({**f, **d}, f["em0"] if i == 0 else f["em"], f["em"], [(self.b_ps, 0, 2 * L, f["send"]), (self.b_ps, L, 2 * L, f["recv"])], self.agg_m, "processor")
+            self._node_mlp(f"proc.{i}.node", [(self.vm, o0, L), (self.agg_m, o0, L)], nl, (self.vm, o0, L), (self.vm, o0, L), "processor")
+            if self.shard_mesh:
+                self._exchange_nodes(nl)
+        # decoder: mesh -> grid
+        f = F["m2g"]
+        self._gemm(self.vm, f["w_s"], self.b_ps, g.n_mesh, a_sm=L, a_sk=1, o_sm=L, o_sn=1, label="decoder")
+        self._gemm(self.vg, f["w_r"], self.b_pr, P, a_sm=L, a_sk=1, o_sm=L, o_sn=1, label="decoder")
+        if f["zero_agg"]:
+            self.agg_g.zero_()
+        self._edge_update(f, f["static"], None, [(self.b_ps, 0, L, f["send"]), (self.b_pr, 0, L, f["recv"])], self.agg_g, "decoder")
+        self._node_mlp("m2g.grid_node", [(self.vg, 0, L), (self.agg_g, 0, L)], P, (self.vg, 0, L), (self.vg, 0, L), "decoder")
+
+    def _exchange_nodes(self, nl):
+        """all-gather of the updated node latents of a mesh-sharded step (84 MB at full size)."""
+        L = self.cfg.latent
+        self._mark("exchange")
+        self.xmine[:nl].copy_(self.vm[self.mn0:self.mn1])
+        if self.gather_fn is not None:
+            self.gather_fn(self.xbuf, self.xmine)
+        else:
+            import torch.distributed as dist
+            dist.all_gather_into_tensor(self.xbuf.view(self.world * self.mn_per, L), self.xmine)
+        for r in range(self.world):
+            n0, n1 = min(r * self.mn_per, self.graph.n_mesh), min((r + 1) * self.mn_per, self.graph.n_mesh)
+            if r != self.rank and n1 > n0:
+                self.vm[n0:n1].copy_(self.xbuf[r, :n1 - n0])
+
     # ---- prepare ------------------------------------------------------------------------------------- #
     def load_params(self, params: dict):
         c, g, dev = self.cfg, self.graph, self.device
@@ -285,7 +457,10 @@ class GraphcastEngine:
             self.feat[n_state + N_FORCING + N_STATIC:] = torch.from_numpy(g.grid_node_feat.T.copy()).to(dev)
             self.vg, self.vm = buf(P, L), buf(g.n_mesh, L)
             self.agg_m, self.agg_g = buf(g.n_mesh, L), buf(P, L)
-            self.e1, self.em, self.e2, self.de = buf(E1, L), buf(EM, L), buf(E2, L), buf(EM, L)
+            if self.fused:                                       # the fused path keeps no fp32 edge latents at all
+                self.e1 = self.em = self.e2 = self.de = None
+            else:
+                self.e1, self.em, self.e2, self.de = buf(E1, L), buf(EM, L), buf(E2, L), buf(EM, L)
             # input-independent embeddings of the structural features
             self.vm0, self.e1_0, self.em_0, self.e2_0 = buf(g.n_mesh, L), buf(E1, L), buf(EM, L), buf(E2, L)
             for name, feat, out in (("embed.mesh", g.mesh_node_feat, self.vm0), ("embed.g2m_edge", g.g2m_edge_feat, self.e1_0),
@@ -310,6 +485,8 @@ class GraphcastEngine:
                 torch.cuda.current_stream(dev).synchronize()
                 self.e2_0.copy_(self.b_h[:E2])
                 m1["static_edge"] = m2["static_edge"] = True
+            if self.fused:
+                self._prepare_fused(p)
             torch.cuda.current_stream(dev).synchronize()
         self.prepared = True
 
@@ -342,60 +519,63 @@ class GraphcastEngine:
             else:
                 self._gemm(self.b_h, m["fc2"], self.b_t, P, a_sm=L, a_sk=1, o_sm=L, o_sn=1, bias=m["b2"], label="embed")
                 self._ln(self.b_t, m["g"], m["b"], None, self.vg, P)
-            # encoder: grid -> mesh
-            if self.split_edges:
-                self._edge_mlp("g2m.edge", self.e1_0, self.vg, self.g2m_s, None, None, self.E1, self.e1, label="encoder")
+            if self.fused:
+                self._step_fused(y)
             else:
-                self._mlp("g2m.edge", [(self.e1_0, None, L), (self.vg, self.g2m_s, L), (self.vm0, self.g2m_r, L)], self.E1, self.e1, label="encoder")
-            self._segsum(self.e1, self.g2m_off, self.agg_m, self.graph.n_mesh)
-            if self.world > 1 or self.exercise:      # the one exchange of a grid-sharded step: sum the partial aggregates over ranks
-                self._mark("exchange")
-                if self.reduce_fn is not None:
-                    self.reduce_fn(self.agg_m)
-                else:
-                    import torch.distributed as dist
-                    dist.all_reduce(self.agg_m, op=dist.ReduceOp.SUM)
-            self._mlp("g2m.mesh_node", [(self.vm0, None, L), (self.agg_m, None, L)], self.graph.n_mesh, self.vm, res=self.vm0, label="encoder")
-            self._mlp("g2m.grid_node", [(self.vg, None, L)], P, self.vg, res=self.vg, label="encoder")
-            # processor on the multi-mesh: this rank's node range and the edges it receives (everything, on one GPU)
-            nl = self.mn1 - self.mn0
-            vm_own, agg_own = self.vm[self.mn0:self.mn1], self.agg_m[self.mn0:self.mn1]
-            self.em.copy_(self.em_0)
-            for i in range(c.steps):
-                de = self.de
+                # encoder: grid -> mesh
                 if self.split_edges:
-                    self._edge_mlp(f"proc.{i}.edge", self.em, self.vm, self.me_s, self.vm, self.me_r, self.EM, de, label="processor")
+                    self._edge_mlp("g2m.edge", self.e1_0, self.vg, self.g2m_s, None, None, self.E1, self.e1, label="encoder")
                 else:
-                    self._mlp(f"proc.{i}.edge", [(self.em, None, L), (self.vm, self.me_s, L), (self.vm, self.me_r, L)], self.EM, de, label="processor")
-                self._segsum(de, self.me_off, agg_own, nl, acc=self.em)                      # receiver sum; em += de rides along
-                self._mlp(f"proc.{i}.node", [(vm_own, None, L), (agg_own, None, L)], nl, vm_own, res=vm_own, label="processor")
-                if self.shard_mesh:                  # all-gather of the updated node latents (84 MB at full size)
+                    self._mlp("g2m.edge", [(self.e1_0, None, L), (self.vg, self.g2m_s, L), (self.vm0, self.g2m_r, L)], self.E1, self.e1, label="encoder")
+                self._segsum(self.e1, self.g2m_off, self.agg_m, self.graph.n_mesh)
+                if self.world > 1 or self.exercise:      # the one exchange of a grid-sharded step: sum the partial aggregates over ranks
                     self._mark("exchange")
-                    self.xmine[:nl].copy_(vm_own)
-                    if self.gather_fn is not None:
-                        self.gather_fn(self.xbuf, self.xmine)
+                    if self.reduce_fn is not None:
+                        self.reduce_fn(self.agg_m)
                     else:
                         import torch.distributed as dist
-                        dist.all_gather_into_tensor(self.xbuf.view(self.world * self.mn_per, L), self.xmine)
-                    for r in range(self.world):
-                        n0, n1 = min(r * self.mn_per, self.graph.n_mesh), min((r + 1) * self.mn_per, self.graph.n_mesh)
-                        if r != self.rank and n1 > n0:
-                            self.vm[n0:n1].copy_(self.xbuf[r, :n1 - n0])
-            # decoder: mesh -> grid
-            if self.m2g_group is not None:
-                # edge update + receiver sum in one kernel: node terms once per node, then sum over a node's three edges of
-                # LayerNorm(fc2(swish(e W_e + b + (v_m W_s)[sender] + (v_g W_r)[node])))
-                me, ie = self.m["m2g.edge"], self.m2g_group
-                self._gemm(self.vm, me["w_s"], self.b_ps, self.graph.n_mesh, a_sm=L, a_sk=1, o_sm=L, o_sn=1, label="decoder")
-                self._gemm(self.vg, me["w_r"], self.b_pr, P, a_sm=L, a_sk=1, o_sm=L, o_sn=1, label="decoder")
-                self._sum_ln("m2g.edge", [(self.e2_0, 0, L, ie[0]), (self.b_ps, 0, L, ie[1]), (self.b_pr, 0, L, ie[2])], P, self.agg_g, label="decoder", group=3)
-            else:
-                if self.split_edges:
-                    self._edge_mlp("m2g.edge", self.e2_0, self.vm, self.m2g_s, self.vg, self.m2g_r, self.E2, self.e2, label="decoder")
+                        dist.all_reduce(self.agg_m, op=dist.ReduceOp.SUM)
+                self._mlp("g2m.mesh_node", [(self.vm0, None, L), (self.agg_m, None, L)], self.graph.n_mesh, self.vm, res=self.vm0, label="encoder")
+                self._mlp("g2m.grid_node", [(self.vg, None, L)], P, self.vg, res=self.vg, label="encoder")
+                # processor on the multi-mesh: this rank's node range and the edges it receives (everything, on one GPU)
+                nl = self.mn1 - self.mn0
+                vm_own, agg_own = self.vm[self.mn0:self.mn1], self.agg_m[self.mn0:self.mn1]
+                self.em.copy_(self.em_0)
+                for i in range(c.steps):
+                    de = self.de
+                    if self.split_edges:
+                        self._edge_mlp(f"proc.{i}.edge", self.em, self.vm, self.me_s, self.vm, self.me_r, self.EM, de, label="processor")
+                    else:
+                        self._mlp(f"proc.{i}.edge", [(self.em, None, L), (self.vm, self.me_s, L), (self.vm, self.me_r, L)], self.EM, de, label="processor")
+                    self._segsum(de, self.me_off, agg_own, nl, acc=self.em)                      # receiver sum; em += de rides along
+                    self._mlp(f"proc.{i}.node", [(vm_own, None, L), (agg_own, None, L)], nl, vm_own, res=vm_own, label="processor")
+                    if self.shard_mesh:                  # all-gather of the updated node latents (84 MB at full size)
+                        self._mark("exchange")
+                        self.xmine[:nl].copy_(vm_own)
+                        if self.gather_fn is not None:
+                            self.gather_fn(self.xbuf, self.xmine)
+                        else:
+                            import torch.distributed as dist
+                            dist.all_gather_into_tensor(self.xbuf.view(self.world * self.mn_per, L), self.xmine)
+                        for r in range(self.world):
+                            n0, n1 = min(r * self.mn_per, self.graph.n_mesh), min((r + 1) * self.mn_per, self.graph.n_mesh)
+                            if r != self.rank and n1 > n0:
+                                self.vm[n0:n1].copy_(self.xbuf[r, :n1 - n0])
+                # decoder: mesh -> grid
+                if self.m2g_group is not None:
+                    # edge update + receiver sum in one kernel: node terms once per node, then sum over a node's three edges of
+                    # LayerNorm(fc2(swish(e W_e + b + (v_m W_s)[sender] + (v_g W_r)[node])))
+                    me, ie = self.m["m2g.edge"], self.m2g_group
+                    self._gemm(self.vm, me["w_s"], self.b_ps, self.graph.n_mesh, a_sm=L, a_sk=1, o_sm=L, o_sn=1, label="decoder")
+                    self._gemm(self.vg, me["w_r"], self.b_pr, P, a_sm=L, a_sk=1, o_sm=L, o_sn=1, label="decoder")
+                    self._sum_ln("m2g.edge", [(self.e2_0, 0, L, ie[0]), (self.b_ps, 0, L, ie[1]), (self.b_pr, 0, L, ie[2])], P, self.agg_g, label="decoder", group=3)
                 else:
-                    self._mlp("m2g.edge", [(self.e2_0, None, L), (self.vm, self.m2g_s, L), (self.vg, self.m2g_r, L)], self.E2, self.e2, label="decoder")
-                self._segsum(self.e2, self.m2g_off, self.agg_g, P)
-            self._mlp("m2g.grid_node", [(self.vg, None, L), (self.agg_g, None, L)], P, self.vg, res=self.vg, label="decoder")
+                    if self.split_edges:
+                        self._edge_mlp("m2g.edge", self.e2_0, self.vm, self.m2g_s, self.vg, self.m2g_r, self.E2, self.e2, label="decoder")
+                    else:
+                        self._mlp("m2g.edge", [(self.e2_0, None, L), (self.vm, self.m2g_s, L), (self.vg, self.m2g_r, L)], self.E2, self.e2, label="decoder")
+                    self._segsum(self.e2, self.m2g_off, self.agg_g, P)
+                self._mlp("m2g.grid_node", [(self.vg, None, L), (self.agg_g, None, L)], P, self.vg, res=self.vg, label="decoder")
             # output layer: x(t+6h) = x(t) + diff_std * MLP(vg), written channel-major
             mo = self.m["out"]
             self._fc1(mo["fc1"], mo["b1"], [(self.vg, None, L)], P, self.b_h, label="output")

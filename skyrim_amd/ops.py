@@ -9,6 +9,7 @@ are stream-ordered, allocation-free and capturable in a HIP graph.
     pangu_step / pangu_patch_embed / pangu_block / pangu_downsample / pangu_upsample / pangu_patch_recover     (ctx = skpangu_ctx*)
     sfno_gemm / sfno_instance_norm / sfno_chain / sfno_instance_stats
     gc_gather_gemm / gc_linear_layer_norm / gc_sum_linear_layer_norm / gc_layer_norm / gc_segment_sum
+    gc_edge_update / gc_segment_fixup / gc_node_mlp      (the fused interaction-network updates, csrc/graphcast_fused.hip)
 """
 from __future__ import annotations
 
@@ -221,6 +222,82 @@ def _gc_segment_sum(e, offsets, out, acc, n_nodes: int, N: int) -> None:
         _ok(lib.skgc_segment_sum(_f32(e, "e", dev), ctypes.c_void_p(offsets.data_ptr()), _f32(out, "out"), _opt(acc), n_nodes, N, _stream(out)), "skgc_segment_sum")
 
 
+def _i32(t, what: str, dev):
+    if t.dtype != torch.int32 or t.device != dev or not t.is_contiguous():
+        raise ValueError(f"{what}: expected a contiguous int32 tensor on {dev}")
+    return t.data_ptr()
+
+
+def _f16(t, what: str, dev):
+    if t.dtype != torch.float16 or t.device != dev or not t.is_contiguous():
+        raise ValueError(f"{what}: expected a contiguous float16 tensor on {dev}")
+    return t.data_ptr()
+
+
+def _gc_edge_update(e_in, e_out, term, term_off, ld, idx, recv, w1f, w2f, b2, gamma, beta, agg, heads, rows: int) -> None:
+    from .graphcast import engine
+    lib = engine.load_library()
+    dev = agg.device
+    if len(term) > 2 or not (len(term) == len(term_off) == len(ld) == len(idx)):
+        raise ValueError("gc_edge_update: at most two gathered terms, each with an element offset, a leading dimension and an index tensor")
+    d = engine.EdgeDesc()
+    d.e_in = _f16(e_in, "e_in", dev)
+    d.e_out = _f16(e_out, "e_out", dev) if e_out is not None else None
+    for s, (t, off, l, ix) in enumerate(zip(term, term_off, ld, idx)):
+        _f32(t, f"term[{s}]", dev)
+        d.term[s], d.idx[s], d.ld[s] = t.data_ptr() + 4 * off, _i32(ix, f"idx[{s}]", dev), l
+        if ix.numel() < rows:
+            raise ValueError("gc_edge_update: index tensors hold one entry per packed row")
+    d.n_term = len(term)
+    if recv.numel() < rows or e_in.numel() < rows * 512 or (e_out is not None and e_out.numel() < rows * 512):
+        raise ValueError("gc_edge_update: recv / e_in / e_out are smaller than `rows` packed rows")
+    d.recv = _i32(recv, "recv", dev)
+    d.w1f = _f16(w1f, "w1f", dev) if w1f is not None else None
+    d.w2f = _f16(w2f, "w2f", dev)
+    d.b2, d.gamma, d.beta = _f32(b2, "b2", dev).value, _f32(gamma, "gamma", dev).value, _f32(beta, "beta", dev).value
+    d.agg = _f32(agg, "agg").value
+    d.heads = _f32(heads, "heads", dev).value if heads is not None else None
+    d.rows, d.has_fc1 = rows, int(w1f is not None)
+    with torch.cuda.device(dev):
+        _ok(lib.skgc_edge_update(ctypes.byref(d), _stream(agg)), "skgc_edge_update")
+
+
+def _gc_segment_fixup(agg, heads, nodes, first, tiles) -> None:
+    from .graphcast import engine
+    lib = engine.load_library()
+    dev = agg.device
+    with torch.cuda.device(dev):
+        _ok(lib.skgc_segment_fixup(_f32(agg, "agg"), _f32(heads, "heads", dev), ctypes.c_void_p(_i32(nodes, "nodes", dev)), ctypes.c_void_p(_i32(first, "first", dev)),
+                                   ctypes.c_void_p(_i32(tiles, "tiles", dev)), nodes.numel(), _stream(agg)), "skgc_segment_fixup")
+
+
+def _gc_node_mlp(src, src_off, ld, w1f, w2f, b1, b2, gamma, beta, res, res_off: int, ld_res: int, out, out_off: int, ld_out: int, rows: int) -> None:
+    from .graphcast import engine
+    lib = engine.load_library()
+    dev = out.device
+    if not (1 <= len(src) <= 2) or not (len(src) == len(src_off) == len(ld)):
+        raise ValueError("gc_node_mlp: one or two fp32 sources, each with an element offset and a leading dimension")
+    d = engine.NodeDesc()
+    for s, (t, off, l) in enumerate(zip(src, src_off, ld)):
+        _f32(t, f"src[{s}]", dev)
+        if t.numel() < off + (rows - 1) * l + 512:
+            raise ValueError("gc_node_mlp: source smaller than rows x 512")
+        d.src[s], d.ld[s] = t.data_ptr() + 4 * off, l
+    d.n_src = len(src)
+    d.w1f, d.w2f = _f16(w1f, "w1f", dev), _f16(w2f, "w2f", dev)
+    if w1f.numel() != 2 * 512 * 512 * len(src) or w2f.numel() != 2 * 512 * 512:
+        raise ValueError("gc_node_mlp: weight fragments are [512][512 n_src] and [512][512] with hi/lo planes")
+    d.b1, d.b2 = _f32(b1, "b1", dev).value, _f32(b2, "b2", dev).value
+    d.gamma, d.beta = _f32(gamma, "gamma", dev).value, _f32(beta, "beta", dev).value
+    d.res = (_f32(res, "res", dev).value + 4 * res_off) if res is not None else None
+    d.ld_res = ld_res
+    if out.numel() < out_off + (rows - 1) * ld_out + 512:
+        raise ValueError("gc_node_mlp: out smaller than rows x 512")
+    d.out, d.ld_out, d.rows = _f32(out, "out").value + 4 * out_off, ld_out, rows
+    with torch.cuda.device(dev):
+        _ok(lib.skgc_node_mlp(ctypes.byref(d), _stream(out)), "skgc_node_mlp")
+
+
 _SCHEMAS = [
     ("pangu_step(int ctx, Tensor x, Tensor(a!) out) -> ()", _pangu_step),
     ("pangu_patch_embed(int ctx, Tensor x, Tensor(a!) out) -> ()", _pangu_patch_embed),
@@ -242,6 +319,11 @@ _SCHEMAS = [
      "Tensor beta, Tensor? res, Tensor(a!) out, int rows, int group=0) -> ()", _gc_sum_linear_layer_norm),
     ("gc_layer_norm(Tensor x, Tensor gamma, Tensor beta, Tensor? res, Tensor(a!) out, int rows, int N) -> ()", _gc_layer_norm),
     ("gc_segment_sum(Tensor e, Tensor offsets, Tensor(a!) out, Tensor(b!)? acc, int n_nodes, int N) -> ()", _gc_segment_sum),
+    ("gc_edge_update(Tensor e_in, Tensor(c!)? e_out, Tensor[] term, int[] term_off, int[] ld, Tensor[] idx, Tensor recv, Tensor? w1f, Tensor w2f, Tensor b2, "
+     "Tensor gamma, Tensor beta, Tensor(a!) agg, Tensor(b!)? heads, int rows) -> ()", _gc_edge_update),
+    ("gc_segment_fixup(Tensor(a!) agg, Tensor heads, Tensor nodes, Tensor first, Tensor tiles) -> ()", _gc_segment_fixup),
+    ("gc_node_mlp(Tensor[] src, int[] src_off, int[] ld, Tensor w1f, Tensor w2f, Tensor b1, Tensor b2, Tensor gamma, Tensor beta, Tensor? res, int res_off, "
+     "int ld_res, Tensor(a!) out, int out_off, int ld_out, int rows) -> ()", _gc_node_mlp),
 ]
 OP_NAMES = [s.split("(", 1)[0] for s, _ in _SCHEMAS]
 
