@@ -99,9 +99,9 @@ int skgc_sum_linear_layer_norm(const skgc_sum_desc* desc, void* stream);
  *     y    = LayerNorm( swish(pre) W2^T + b2 ) * gamma + beta
  *     e_out[row] = e_in[row] + y   (has_fc1 only, nullable)          agg[ recv[row] ] = sum of y over the receiver's run of rows
  * e_in / e_out: ONE fp16 plane in the blocked layout [rows/16][16][16][32] (may alias); with has_fc1 == 0, e_in is the prepared
- * first-Linear term in "pos" column order.  term[s]: fp32 rows, leading dimension ld[s], "pos" column order.  w1f / w2f: fp16 hi/lo
- * planes in MFMA fragment order (fused.py: prep_w1_fragments / prep_w2_fragments).  Two MFMA terms (W_hi x + W_lo x): activations are
- * rounded to fp16, weights are not.  A tile whose first run continues the previous tile's last run writes that run's sum to
+ * first-Linear term in "pos" column order.  term[s]: fp32 rows, leading dimension ld[s], "pos" column order.  w1f / w2f: fp16 planes in
+ * MFMA fragment order (fused.py: prep_w1_fragments / prep_w2_fragments); w2f always hi/lo (two MFMA terms W_hi h + W_lo h: activations
+ * are rounded to fp16, the second Linear's weights are not), w1f with w1_planes planes.  A tile whose first run continues the previous tile's last run writes that run's sum to
  * heads[tile] instead of agg; skgc_segment_fixup adds those pieces (agg[nodes[i]] += heads[tiles[k]], first[i] <= k < first[i + 1],
  * in that order).  Every receiver with at least one row is written exactly once per call; deterministic (no atomics). */
 typedef struct skgc_edge_desc {
@@ -121,6 +121,8 @@ typedef struct skgc_edge_desc {
     float* heads;            /* [rows / 128][512]; may be NULL when no tile continues its predecessor */
     long long rows;
     int has_fc1;
+    int w1_planes;           /* has_fc1: planes of w1f -- 2 = fp16 hi/lo (two MFMA terms), 1 = W_e rounded to fp16 (one term) */
+    long long* probe;        /* NULL, or [rows / 128][8]: shader clocks of the tile's first wave at the phase boundaries (measurement only) */
 } skgc_edge_desc;
 int skgc_edge_update(const skgc_edge_desc* desc, void* stream);
 int skgc_segment_fixup(float* agg, const float* heads, const int* nodes, const int* first, const int* tiles, int n_nodes, void* stream);

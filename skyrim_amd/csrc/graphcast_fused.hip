@@ -6,29 +6,31 @@
 // GEMM; here the rest runs for a tile of 128 edge rows without leaving the CU:
 //
 //   * a wavefront owns 2 x 16 rows.  Their 512 input columns sit in REGISTERS as MFMA B-operand fragments (one fp16 plane, 16-byte
-//     loads of the blocked layout: one wave instruction = one contiguous 1 KiB block), the weights stream through LDS in FRAGMENT
-//     order by LDS-DMA (64 KiB stages, two stages, one barrier per stage), as fp16 hi/lo planes: two MFMA terms W_hi x + W_lo x.
-//     Rounding the ACTIVATIONS of the edge MLPs to one fp16 plane costs 1.7e-4 of the predicted increment at production width and
-//     depth (tools/graphcast_numerics.py); rounding their WEIGHTS would cost 4.3e-4, so the weights keep both planes.
+//     loads of the blocked layout: one wave instruction = one contiguous 1 KiB block); the weights stream through LDS in FRAGMENT
+//     order by LDS-DMA (two stages, one barrier per stage).  The second Linear keeps fp16 hi/lo weight planes (two MFMA terms
+//     W_hi h + W_lo h); the edge part of the first Linear takes one or two planes (skgc_edge_desc::w1_planes).  Measured on the oracle at
+//     production width and depth (tools/graphcast_numerics.py, error relative to the predicted increment, bar 1e-3): activations of the
+//     edge MLPs as one fp16 plane 1.7e-4; W_e as one plane +1.4e-4; the second Linear's weights as one plane would cost 4.5e-4.
 //   * phase 1: the first Linear in chunks of 32 hidden units.  The accumulators START from the gathered node terms (stored in "pos"
 //     column order, skyrim_amd/graphcast/fused.py: a lane's 8 values are 32 contiguous bytes; the gathers of chunk j + 1 fly during
 //     chunk j) and END, after swish and the fp16 rounding, as the second Linear's B-operand fragments -- in swapped order
-//     (D^T = W X^T) a lane's accumulators ARE its k-slots of the next GEMM (same trick as fused_mlp.hip).  The swish of chunk j - 1 is
-//     spliced between the MFMAs of chunk j.
+//     (D^T = W X^T) a lane's accumulators ARE its k-slots of the next GEMM (same trick as fused_mlp.hip).  The swish of chunk j - 1,
+//     the gathers of chunk j + 1 and the LDS-DMA requests of the next stage are spliced between the MFMAs of chunk j.
 //   * phase 2: the second Linear, 16 k-steps x 32 output fragments into 2 x 128 accumulator registers; perm8 weight rows make a
 //     fragment pair 8 consecutive output columns.
+//   * MFMA order: a v_mfma_f32_16x16x32_f16 that accumulates into the result of an earlier one issues ~47 clocks after it (measured:
+//     chains at distance 2 run at 23.7 clocks per MFMA, the pipe's 16 need distance >= 3), so every step interleaves FOUR accumulator
+//     chains (2 row groups x 2 fragments) before it returns to the first.
 //   * epilogue: LayerNorm from the accumulators (in-lane sums + two shuffles), the residual update written back in the blocked
-//     layout, and the RECEIVER SUM from the same registers: rows are sorted by receiver, so a segmented scan over the 16 lanes of a
-//     DPP row (4 steps) leaves every run's sum in its last row; runs that cross a wave's 16-row groups are completed through a 16 KiB
-//     LDS exchange in a fixed order (deterministic, no atomics).  The host packs the rows so that a run never crosses a 128-row tile
-//     unless it is longer than a tile; the pieces of such a run go to a side buffer and skgc_segment_fixup adds them in order.
+//     layout, and the RECEIVER SUM: the normalised rows go through LDS (two halves of 256 columns over the weight stages, 260-float
+//     row stride: conflict-free both ways), one thread per column walks the tile's 128 rows in order and writes a run's sum where the
+//     receiver changes -- sequential, deterministic, no atomics, no second kernel.  The host packs the rows so that a run never crosses
+//     a 128-row tile unless it is longer than a tile; the pieces of such a run go to a side buffer and skgc_segment_fixup adds them.
 //
 // The `static` form (grid->mesh, mesh->grid: edge latents that do not depend on the input) has no first Linear at all: its phase 1 is
 // swish(prepared term + gathered node terms).  The node form (skgc_node_mlp) keeps fp32 node latents exact: hi/lo fragments made on
-// the fly from fp32 rows, three MFMA terms, one 16-row group per wave.
+// the fly from fp32 rows, three MFMA terms, one 16-row group per wave, concatenated sources taken one after the other.
 //
-// Per tile of 128 rows: 2 MiB (1 MiB static) of weights through LDS-DMA against 65.5 k (32.8 k) MFMA clocks per SIMD = 32 B/clk/CU
-// (measured ceiling from L2: 43, tools/micro/dma_bw.hip); every weight fragment read from LDS feeds two MFMAs (128 B/clk/CU of 256).
 // gfx950 only.  One workgroup (4 waves, one per SIMD, 512 registers) per CU; grid = tiles.
 #include <cstdlib>
 #include "../../include/skyrim_graphcast.h"
@@ -38,9 +40,28 @@ namespace skp {
 
 __device__ __forceinline__ float swish_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }
 
+// build-time variants for measurements (tools/gc_edge_probe.py, tools/build_gc_variants.sh)
+#ifndef FZ_RD
+#define FZ_RD 2                    // steps of weight fragments in flight per wave (register ring)
+#endif
+// timing probes (results are WRONG): FZ_PROBE & 1 -- no weight DMA after a kernel's first stages; & 2 -- no MFMAs in the chunk loops
+#ifndef FZ_PROBE
+#define FZ_PROBE 0
+#endif
+#ifndef FZ_DBG
+#define FZ_DBG 0                   // & 1: node kernel requests a stage's 16 DMA pieces in one burst at the chunk top; & 4: RD = 1 (no read-ahead)
+#endif
+__device__ __forceinline__ f32x4 fz_mfma(const uint4& a, const OpT<f16>::v8& b, const f32x4& c) {
+    if (FZ_PROBE & 2) return c;
+    return OpT<f16>::mfma(as_v8<f16>(a), b, c);
+}
 constexpr int FZ_L = 512, FZ_KS = 16, FZ_CF = 32, FZ_NCH = 16, FZ_TILE = 128;
 constexpr int FZ_STAGE = 64 * 1024;
-constexpr int FZ_SMEM = 2 * FZ_STAGE + 4 * FZ_L * 4;
+constexpr int FZ_YLD = 260;                                   // row stride (floats) of the epilogue's exchange buffer: 260 mod 32 = 4
+constexpr int FZ_YBUF = FZ_TILE * FZ_YLD * 4;                 // 133 120 bytes: over both weight stages and 5 KiB more
+constexpr int FZ_TAB = 5 * FZ_L;                              // b2 | gamma | beta | b1 (node form) | receivers of the tile (edge form)
+constexpr int FZ_SMEM = FZ_YBUF + FZ_TAB * 4;
+static_assert(FZ_YBUF >= 2 * FZ_STAGE && FZ_SMEM <= 160 * 1024, "LDS");
 
 struct EdgeArgs {
     const f16* e_in;        // FC1: edge latents; static: prepared first-Linear term ("pos" columns).  Blocked fp16 [rows][512]
@@ -49,42 +70,43 @@ struct EdgeArgs {
     const int* idx[2];      // node of every packed row (< 0: padding row)
     long long ld[2];
     const int* recv;        // receiver of every packed row (< 0: padding row); rows sorted by receiver
-    const f16* w1f;         // FC1: first Linear (edge part), fragment order, hi/lo planes
+    const f16* w1f;         // FC1: first Linear (edge part), fragment order, 1 or 2 planes
     const f16* w2f;         // second Linear, fragment order, hi/lo planes
     const float *b2, *gamma, *beta;
     float* agg;             // [nodes][512] receiver sums
     float* heads;           // [tiles][512] continuation pieces (runs longer than a tile)
     float eps;
+    long long* probe;       // nullable: [tiles][8] shader clocks of wave 0 at the phase boundaries (measurement only)
 };
 
-// DEPTH register pairs (hi, lo plane of one fragment) read DEPTH - 1 pairs ahead of their MFMAs; the scheduling barrier pins the reads
-// in program order (fused_mlp.hip: ld_pair)
-__device__ __forceinline__ void fz_ld2(const char* p, uint4 (&w)[2]) {
-    w[0] = *reinterpret_cast<const uint4*>(p);
-    w[1] = *reinterpret_cast<const uint4*>(p + 1024);
+// NB consecutive 1 KiB fragments per step through a ring of RD steps, read RD - 1 steps ahead of their MFMAs; the scheduling barrier pins
+// the reads in program order (fused_mlp.hip: ld_pair)
+template <int NB>
+__device__ __forceinline__ void fz_ld(const char* p, uint4 (&w)[NB]) {
+#pragma unroll
+    for (int i = 0; i < NB; ++i) w[i] = *reinterpret_cast<const uint4*>(p + i * 1024);
     __builtin_amdgcn_sched_barrier(0);
 }
-template <int NP, int RD, class Body>
-__device__ __forceinline__ void fz_stream(const char* st, Body&& body) {
-    uint4 ring[RD][2];
+template <int NSTEP, int NB, int RD, class Body>
+__device__ __forceinline__ void fz_steps(const char* st, Body&& body) {
+    uint4 ring[RD][NB];
 #pragma unroll
-    for (int p = 0; p < RD - 1 && p < NP; ++p) fz_ld2(st + (p << 11), ring[p % RD]);
+    for (int s = 0; s < RD - 1 && s < NSTEP; ++s) fz_ld<NB>(st + s * NB * 1024, ring[s % RD]);
 #pragma unroll
-    for (int p = 0; p < NP; ++p) {
-        if (p + RD - 1 < NP) fz_ld2(st + ((p + RD - 1) << 11), ring[(p + RD - 1) % RD]);
-        body(p, ring[p % RD][0], ring[p % RD][1]);
+    for (int s = 0; s < NSTEP; ++s) {
+        if (s + RD - 1 < NSTEP) fz_ld<NB>(st + (s + RD - 1) * NB * 1024, ring[(s + RD - 1) % RD]);
+        body(s, ring[s % RD]);
         __builtin_amdgcn_sched_barrier(0);
     }
 }
 
-// 64 KiB of fragments -> one LDS stage: block q by wave q % 4
-__device__ __forceinline__ void fz_dma64k(const f16* src, unsigned dst, int wave, int lane) {
-    const f16* s = src + lane * 8;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int q = wave + i * 4;
-        glds16(s + (q << 9), dst + (unsigned)(q << 10));
-    }
+// piece k of a stage's LDS-DMA: 1 KiB block wave + 4 k of `src` -> the same block of the LDS stage at `dst`.  Pieces are requested ONE AT
+// A TIME between MFMAs: issuing one costs the wave ~60-85 clocks (measured: 16 in a burst add 1.4 k clocks per stage to a wave that has
+// the SIMD to itself), which the matrix pipe covers only when it has work queued.
+__device__ __forceinline__ void fz_piece(const f16* src, unsigned dst, int k, int wave, int lane, bool first = false) {
+    if ((FZ_PROBE & 1) && !first) return;
+    const int q = wave + 4 * k;
+    glds16(src + (q << 9) + lane * 8, dst + (unsigned)(q << 10));
 }
 
 __device__ __forceinline__ f16x8 fz_pack8(const f32x4& a, const f32x4& b) {
@@ -94,13 +116,40 @@ __device__ __forceinline__ f16x8 fz_pack8(const f32x4& a, const f32x4& b) {
     return h;
 }
 
-template <int CTRL>
-__device__ __forceinline__ float fz_dpp(float v) {       // row_shr within the 16 lanes of a DPP row; lanes without a source read 0
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+// 8 fp32 -> fp16 hi / lo fragments.  The hi plane is made opaque before the lo plane is derived from it: left alone, hipcc converts twice
+// (v_cvt_pk_f16_f32 for the stored plane, v_cvt_f16_f32 for the one the remainder is taken from) and on gfx950 the two do not always agree,
+// which shows as a full fp16 ulp of error in single elements (measured: 17 of 2 M hidden activations, all within one fp32 ulp of an fp16
+// grid point).
+__device__ __forceinline__ void fz_split8(const float (&v)[8], f16x8& hi, f16x8& lo) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) hi[i] = (f16)v[i];
+    asm volatile("" : "+v"(hi));
+#pragma unroll
+    for (int i = 0; i < 8; ++i) lo[i] = (f16)(v[i] - (float)hi[i]);
 }
-template <int CTRL>
-__device__ __forceinline__ int fz_dpp_i(int v, int old) { // ... lanes without a source keep `old`
-    return __builtin_amdgcn_update_dpp(old, v, CTRL, 0xf, 0xf, false);
+
+// a[j] with a wave-uniform RUNTIME j: a uniform 16-way branch around a register copy, so that the chunk loops stay rolled (fully unrolled
+// they are ~200 KB of code against a 64 KB instruction cache: measured 1.6x slower in the MFMA loops) and the array stays in registers
+#define FZ_CASES(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15)
+template <class V>
+__device__ __forceinline__ V fz_pick(const V (&a)[16], int j) {
+    V r = a[0];
+    switch (j) {
+#define X(i) case i: r = a[i]; break;
+        FZ_CASES(X)
+#undef X
+        default: break;
+    }
+    return r;
+}
+template <class V>
+__device__ __forceinline__ void fz_put(V (&a)[16], int j, const V& v) {
+    switch (j) {
+#define X(i) case i: a[i] = v; break;
+        FZ_CASES(X)
+#undef X
+        default: break;
+    }
 }
 
 // ---- LayerNorm of a 16-row group held as 32 accumulator fragments (perm8: pair bp = columns 32 bp + 8 g + [0..7]) ------------------ //
@@ -139,27 +188,42 @@ __device__ __forceinline__ void fz_layer_norm(f32x4 (&y)[FZ_CF], const float* ta
     }
 }
 
-template <bool FC1, int NT>
+// W1P: planes of the first Linear's weights (FC1 only).  Fragment order of a chunk of 32 hidden units: [ks][n][plane] -- a step = one k-step
+// against both 16-unit halves, i.e. four accumulator chains with the two row groups.
+template <bool FC1, int NT, int W1P>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 edge_update_kernel(const EdgeArgs a) {
-    constexpr int FM = 2, KS = FZ_KS, CF = FZ_CF, NCH = FZ_NCH, RD = 3;
+    constexpr int FM = 2, KS = FZ_KS, CF = FZ_CF, NCH = FZ_NCH, RD = FZ_RD;
+    constexpr int W1_CHUNK = 16 * 2 * W1P * 512;                      // elements of one chunk of the first Linear: 16 k-steps x 2 halves x planes KiB
+    constexpr int W1_PIECES = 16 * 2 * W1P / 4;                       // DMA pieces per wave and chunk (8 or 16)
     typedef typename OpT<f16>::v8 v8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* tab = reinterpret_cast<float*>(smem + 2 * FZ_STAGE);
+    float* tab = reinterpret_cast<float*>(smem + FZ_YBUF);
+    int* rcv_l = reinterpret_cast<int*>(tab + 4 * FZ_L);              // [0] = receiver of the row before the tile, [1 + r] = of row r, [129] = -3
     const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const unsigned lds_base = (unsigned)(size_t)smem;
     const char* lrd = smem + lane * 16;
     const long long tile0 = (long long)blockIdx.x * FZ_TILE;
+    auto stamp = [&](int k) {
+        if (a.probe != nullptr && tid == 0) a.probe[(long long)blockIdx.x * 8 + k] = (long long)__builtin_amdgcn_s_memtime();
+    };
+    stamp(0);
 
     // ---- prologue: first weight stages, tables, rows ------------------------------------------------------------------------------ //
     if constexpr (FC1) {
-        fz_dma64k(a.w1f, lds_base, wave, lane);
+#pragma unroll
+        for (int k = 0; k < W1_PIECES; ++k) fz_piece(a.w1f, lds_base, k, wave, lane, true);
     } else {
-        fz_dma64k(a.w2f, lds_base, wave, lane);
-        fz_dma64k(a.w2f + (FZ_STAGE / 2), lds_base + FZ_STAGE, wave, lane);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) fz_piece(a.w2f, lds_base, k, wave, lane, true);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) fz_piece(a.w2f + (FZ_STAGE / 2), lds_base + FZ_STAGE, k, wave, lane, true);
     }
     for (int i = tid; i < FZ_L; i += 256) { tab[i] = a.b2[i]; tab[FZ_L + i] = a.gamma[i]; tab[2 * FZ_L + i] = a.beta[i]; }
+    if (tid < FZ_TILE) rcv_l[1 + tid] = a.recv[tile0 + tid];
+    if (tid == FZ_TILE) rcv_l[0] = tile0 > 0 ? a.recv[tile0 - 1] : -2;
+    if (tid == FZ_TILE + 1) rcv_l[1 + FZ_TILE] = -3;
 
     long long row[FM];
     int my[FM];
@@ -177,7 +241,14 @@ edge_update_kernel(const EdgeArgs a) {
     const long long rb0 = (tile0 >> 4) + wave * 2;                    // first 16-row block of the wave
 
     f16x8 hh[FM][NCH];                                                // the second Linear's operand: hidden activations, one fp16 plane
+    if constexpr (FC1) {
+#pragma unroll
+        for (int t = 0; t < FM; ++t)
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) hh[t][k] = f16x8{};
+    }
     f32x4 pre[FM][2];                                                 // pre-activations of the chunk whose swish is in flight
+    static_assert(FM == 2 && NCH == 16, "fz_pick / fz_put and the step bodies are written for two groups of 16 chunks");
 
     auto swish4 = [&](f32x4& v) {
 #pragma unroll
@@ -192,138 +263,200 @@ edge_update_kernel(const EdgeArgs a) {
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) xh[t][ks] = *reinterpret_cast<const v8*>(p + (ks << 9));
         }
-        f32x4 gat[FM][NT > 0 ? NT : 1][2];
-        auto gather = [&](int j) {
-#pragma unroll
-            for (int t = 0; t < FM; ++t)
-#pragma unroll
-                for (int s = 0; s < NT; ++s) {
-                    gat[t][s][0] = *reinterpret_cast<const f32x4*>(tp[t][s] + 32 * j);
-                    gat[t][s][1] = *reinterpret_cast<const f32x4*>(tp[t][s] + 32 * j + 4);
-                }
+        constexpr int NG = FM * (NT > 0 ? NT : 1) * 2;                 // gathered 16-byte pieces per lane and chunk
+        f32x4 gat[NG];
+        auto gather1 = [&](int j, int i) {                            // piece i = (t, s, half)
+            if (NT == 0 || i >= FM * NT * 2) return;
+            const int t = i / (NT * 2), s = (i / 2) % (NT > 0 ? NT : 1), h = i & 1;
+            gat[i] = *reinterpret_cast<const f32x4*>(tp[t][s] + 32 * j + 4 * h);
         };
-        gather(0);
+#pragma unroll
+        for (int i = 0; i < NG; ++i) gather1(0, i);
         // consumed once here so that hipcc's vmcnt waits for these loads sit BEFORE the loop (inside it they would also wait for the
         // LDS-DMA in flight, which the compiler's counter bookkeeping does not know about; fused_mlp.hip)
 #pragma unroll
         for (int t = 0; t < FM; ++t)
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(xh[t][ks]));
+        stamp(1);
 
         f32x4 hacc[FM][2];
 #pragma unroll
+        for (int t = 0; t < FM; ++t) { hacc[t][0] = f32x4{0.f, 0.f, 0.f, 0.f}; hacc[t][1] = hacc[t][0]; }
+#pragma unroll 1
         for (int j = 0; j < NCH; ++j) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             // the gathered terms of chunk j have landed with everything else: hand them to the compiler HERE, before the next requests
+            if constexpr (NT > 0) {
 #pragma unroll
-            for (int t = 0; t < FM; ++t)
-#pragma unroll
-                for (int s = 0; s < NT; ++s) { asm volatile("" : "+v"(gat[t][s][0])); asm volatile("" : "+v"(gat[t][s][1])); }
-            __syncthreads();                           // W1(j) landed in stage j & 1; every wave is done with the other stage
-            if (j > 0) {
-#pragma unroll
-                for (int t = 0; t < FM; ++t) { pre[t][0] = hacc[t][0]; pre[t][1] = hacc[t][1]; }
+                for (int i = 0; i < NG; ++i) asm volatile("" : "+v"(gat[i]));
             }
+            __syncthreads();                           // W1(j) landed in stage j & 1; every wave is done with the other stage
+            // the MFMA-only arrays live in the accumulation half of the register file (MFMA reads its operands from there directly):
+            // left alone, hipcc homes part of them in the low half and spills VALU values to scratch around the chunk loop
 #pragma unroll
             for (int t = 0; t < FM; ++t) {
+#pragma unroll
+                for (int k = 0; k < KS; ++k) { asm volatile("" : "+a"(xh[t][k])); asm volatile("" : "+a"(hh[t][k])); }
+            }
+#pragma unroll
+            for (int t = 0; t < FM; ++t) {             // chunk j - 1's pre-activations (j = 0: zeros, result dropped)
+                pre[t][0] = hacc[t][0]; pre[t][1] = hacc[t][1];
                 f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int s = 0; s < NT; ++s) {
-                    lo += gat[t][s][0];
-                    hi += gat[t][s][1];
+                    lo += gat[(t * NT + s) * 2];
+                    hi += gat[(t * NT + s) * 2 + 1];
                 }
                 hacc[t][0] = lo; hacc[t][1] = hi;
             }
             asm volatile("" ::: "memory");
-            if (j + 1 < NCH) fz_dma64k(a.w1f + (long long)(j + 1) * (FZ_STAGE / 2), lds_base + ((j + 1) & 1) * FZ_STAGE, wave, lane);
-            else fz_dma64k(a.w2f, lds_base, wave, lane);                 // chunk 15 reads stage 1: stage 0 is free for W2(0)
-            if (j + 1 < NCH) gather(j + 1);
-            // pair p = (n, ks): W1 rows 32 j + 16 n + [0, 16), k-step ks; the swish of chunk j - 1 rides between the MFMAs
-            fz_stream<2 * KS, RD>(lrd + (j & 1) * FZ_STAGE, [&](int p, const uint4& wh, const uint4& wl) {
-                const int n = p >> 4, ks = p & 15;
-#pragma unroll
-                for (int t = 0; t < FM; ++t) hacc[t][n] = OpT<f16>::mfma(as_v8<f16>(wl), xh[t][ks], hacc[t][n]);
-#pragma unroll
-                for (int t = 0; t < FM; ++t) hacc[t][n] = OpT<f16>::mfma(as_v8<f16>(wh), xh[t][ks], hacc[t][n]);
-                if (j > 0) {
-                    if (p == 4) swish4(pre[0][0]);
-                    if (p == 8) swish4(pre[0][1]);
-                    if (p == 12) swish4(pre[1][0]);
-                    if (p == 16) swish4(pre[1][1]);
-                    if (p == 20) hh[0][j > 0 ? j - 1 : 0] = fz_pack8(pre[0][0], pre[0][1]);
-                    if (p == 24) hh[1][j > 0 ? j - 1 : 0] = fz_pack8(pre[1][0], pre[1][1]);
+            const bool more = j + 1 < NCH;
+            const f16* nsrc = more ? a.w1f + (long long)(j + 1) * W1_CHUNK : a.w2f;      // chunk 15 reads stage 1: stage 0 is free for W2(0)
+            const unsigned ndst = lds_base + (more ? ((j + 1) & 1) * FZ_STAGE : 0);
+            f16x8 done[FM];
+            // step ks: W1 rows 32 j + 16 n + [0, 16) for n = 0, 1 against k-step ks; between the MFMAs: one DMA piece of the next stage, one
+            // gathered piece of chunk j + 1, a quarter of the swish of chunk j - 1
+            fz_steps<KS, 2 * W1P, RD>(lrd + (j & 1) * FZ_STAGE, [&](int ks, const uint4 (&w)[2 * W1P]) {
+                if constexpr (W1P == 2) {
+                    hacc[0][0] = fz_mfma(w[1], xh[0][ks], hacc[0][0]);
+                    hacc[1][0] = fz_mfma(w[1], xh[1][ks], hacc[1][0]);
+                    hacc[0][1] = fz_mfma(w[3], xh[0][ks], hacc[0][1]);
+                    hacc[1][1] = fz_mfma(w[3], xh[1][ks], hacc[1][1]);
                 }
+                hacc[0][0] = fz_mfma(w[0], xh[0][ks], hacc[0][0]);
+                hacc[1][0] = fz_mfma(w[0], xh[1][ks], hacc[1][0]);
+                hacc[0][1] = fz_mfma(w[W1P], xh[0][ks], hacc[0][1]);
+                hacc[1][1] = fz_mfma(w[W1P], xh[1][ks], hacc[1][1]);
+                // requests in the FIRST half of the chunk, so that they have landed when the next chunk's top waits for them
+                if (ks < 8) {
+                    fz_piece(nsrc, ndst, ks, wave, lane);
+                    if (W1P == 2 || !more) fz_piece(nsrc, ndst, 8 + ks, wave, lane);     // 16 pieces: two planes of W1, or W2(0)
+                    if (ks < NG) gather1(more ? j + 1 : j, ks);         // unconditional: a load inside a branch makes hipcc wait vmcnt(0) at the join
+                }
+                if (ks == 8) swish4(pre[0][0]);
+                if (ks == 9) swish4(pre[0][1]);
+                if (ks == 10) swish4(pre[1][0]);
+                if (ks == 11) swish4(pre[1][1]);
+                if (ks == 12) done[0] = fz_pack8(pre[0][0], pre[0][1]);
+                if (ks == 13) done[1] = fz_pack8(pre[1][0], pre[1][1]);
             });
+            fz_put(hh[0], j - 1, done[0]);
+            fz_put(hh[1], j - 1, done[1]);
         }
 #pragma unroll
         for (int t = 0; t < FM; ++t) { pre[t][0] = hacc[t][0]; pre[t][1] = hacc[t][1]; }
-    } else {
-        // static form: pre-activation = prepared term (fp16, "pos" columns: the lane's 16 bytes of block (row block, j)) + gathered node terms
-#pragma unroll
-        for (int j = 0; j < NCH; ++j) {
-#pragma unroll
-            for (int t = 0; t < FM; ++t) {
-                const v8 st = *reinterpret_cast<const v8*>(a.e_in + ((((rb0 + t) * KS) + j) << 9) + l15 * 32 + g * 8);
-                f32x4 lo = {(float)st[0], (float)st[1], (float)st[2], (float)st[3]}, hi = {(float)st[4], (float)st[5], (float)st[6], (float)st[7]};
-#pragma unroll
-                for (int s = 0; s < NT; ++s) {
-                    const float4 u0 = *reinterpret_cast<const float4*>(tp[t][s] + 32 * j), u1 = *reinterpret_cast<const float4*>(tp[t][s] + 32 * j + 4);
-                    lo[0] += u0.x; lo[1] += u0.y; lo[2] += u0.z; lo[3] += u0.w;
-                    hi[0] += u1.x; hi[1] += u1.y; hi[2] += u1.z; hi[3] += u1.w;
-                }
-                swish4(lo); swish4(hi);
-                hh[t][j] = fz_pack8(lo, hi);
-            }
-        }
-#pragma unroll
-        for (int t = 0; t < FM; ++t)
-#pragma unroll
-            for (int j = 0; j < NCH; ++j) asm volatile("" : "+v"(hh[t][j]));
     }
 
     // ---- phase 2: second Linear ----------------------------------------------------------------------------------------------------- //
+    stamp(2);
     f32x4 yacc[FM][CF];
 #pragma unroll
     for (int t = 0; t < FM; ++t)
 #pragma unroll
         for (int c = 0; c < CF; ++c) yacc[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if constexpr (FC1) {                                // the last chunk's swish has nothing left to hide under: do it here
+    // step q of a chunk: output fragments 2 q, 2 q + 1 (hi, lo planes each) -- four accumulator chains
+    auto fc2_step = [&](int q, const uint4 (&w)[4], const f16x8& h0, const f16x8& h1) {
+        yacc[0][2 * q] = fz_mfma(w[1], h0, yacc[0][2 * q]);
+        yacc[1][2 * q] = fz_mfma(w[1], h1, yacc[1][2 * q]);
+        yacc[0][2 * q + 1] = fz_mfma(w[3], h0, yacc[0][2 * q + 1]);
+        yacc[1][2 * q + 1] = fz_mfma(w[3], h1, yacc[1][2 * q + 1]);
+        yacc[0][2 * q] = fz_mfma(w[0], h0, yacc[0][2 * q]);
+        yacc[1][2 * q] = fz_mfma(w[0], h1, yacc[1][2 * q]);
+        yacc[0][2 * q + 1] = fz_mfma(w[2], h0, yacc[0][2 * q + 1]);
+        yacc[1][2 * q + 1] = fz_mfma(w[2], h1, yacc[1][2 * q + 1]);
+    };
+    if constexpr (FC1) {
+        // the last chunk's swish has nothing left to hide under: do it here
 #pragma unroll
         for (int t = 0; t < FM; ++t) { swish4(pre[t][0]); swish4(pre[t][1]); hh[t][NCH - 1] = fz_pack8(pre[t][0], pre[t][1]); }
-    }
 #pragma unroll
-    for (int j = 0; j < NCH; ++j) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                               // W2(j) landed in stage j & 1; every wave is done with the other stage
-        if (j + 1 < NCH && (FC1 || j > 0)) fz_dma64k(a.w2f + (long long)(j + 1) * (FZ_STAGE / 2), lds_base + ((j + 1) & 1) * FZ_STAGE, wave, lane);
-        fz_stream<CF, RD>(lrd + (j & 1) * FZ_STAGE, [&](int c, const uint4& wh, const uint4& wl) {
+        for (int t = 0; t < FM; ++t)
 #pragma unroll
-            for (int t = 0; t < FM; ++t) yacc[t][c] = OpT<f16>::mfma(as_v8<f16>(wl), hh[t][j], yacc[t][c]);
+            for (int k = 0; k < NCH; ++k) asm volatile("" : "+a"(hh[t][k]));
+#pragma unroll 1
+        for (int j = 0; j < NCH; ++j) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                           // W2(j) landed in stage j & 1; every wave is done with the other stage
+            const bool more = j + 1 < NCH;
+            const f16* nsrc = a.w2f + (long long)(j + 1) * (FZ_STAGE / 2);
+            const unsigned ndst = lds_base + ((j + 1) & 1) * FZ_STAGE;
+            const f16x8 h0 = fz_pick(hh[0], j), h1 = fz_pick(hh[1], j);
+            fz_steps<CF / 2, 4, RD>(lrd + (j & 1) * FZ_STAGE, [&](int q, const uint4 (&w)[4]) {
+                fc2_step(q, w, h0, h1);
+                if (more && q < 8) { fz_piece(nsrc, ndst, q, wave, lane); fz_piece(nsrc, ndst, 8 + q, wave, lane); }
+            });
+        }
+    } else {
+        // static form: the pre-activation of chunk j = prepared term (fp16, "pos" columns: the lane's 16 bytes of block (row block, j)) +
+        // gathered node terms.  Its pieces are requested TWO chunks ahead (they fly during chunk j - 2), summed at the top of chunk j - 1
+        // and go through swish between the MFMAs of chunk j - 1: the whole first phase hides under the second Linear.
+        constexpr int NG = FM * (1 + 2 * NT);                           // pieces per lane and chunk: per row group one fp16 piece + 2 per term
+        f32x4 gat[NG];                                                  // (the fp16 piece is a 16-byte load as well)
+        auto piece = [&](int j, int i) {
+            const int t = i / (1 + 2 * NT), k = i % (1 + 2 * NT);
+            if (k == 0) gat[i] = *reinterpret_cast<const f32x4*>(a.e_in + ((((rb0 + t) * KS) + j) << 9) + l15 * 32 + g * 8);
+            else gat[i] = *reinterpret_cast<const f32x4*>(tp[t][(k - 1) >> 1] + 32 * j + 4 * ((k - 1) & 1));
+        };
+        auto sum_pre = [&]() {                                          // gat -> pre (frees gat for the next requests)
 #pragma unroll
-            for (int t = 0; t < FM; ++t) yacc[t][c] = OpT<f16>::mfma(as_v8<f16>(wh), hh[t][j], yacc[t][c]);
-        });
+            for (int t = 0; t < FM; ++t) {
+                const f16x8 st = __builtin_bit_cast(f16x8, gat[t * (1 + 2 * NT)]);
+                f32x4 lo = {(float)st[0], (float)st[1], (float)st[2], (float)st[3]}, hi = {(float)st[4], (float)st[5], (float)st[6], (float)st[7]};
+#pragma unroll
+                for (int s = 0; s < NT; ++s) { lo += gat[t * (1 + 2 * NT) + 1 + 2 * s]; hi += gat[t * (1 + 2 * NT) + 2 + 2 * s]; }
+                pre[t][0] = lo; pre[t][1] = hi;
+            }
+        };
+        f16x8 hc[FM], hn[FM];
+#pragma unroll
+        for (int i = 0; i < NG; ++i) piece(0, i);
+        sum_pre();
+#pragma unroll
+        for (int i = 0; i < NG; ++i) piece(1, i);
+#pragma unroll
+        for (int t = 0; t < FM; ++t) { swish4(pre[t][0]); swish4(pre[t][1]); hc[t] = fz_pack8(pre[t][0], pre[t][1]); hn[t] = hc[t]; }
+#pragma unroll 1
+        for (int j = 0; j < NCH; ++j) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < NG; ++i) asm volatile("" : "+v"(gat[i]));    // chunk j + 1's pieces have landed: to the compiler HERE
+            __syncthreads();                           // W2(j) landed in stage j & 1; every wave is done with the other stage
+            sum_pre();                                 // pre = pre-activation of chunk j + 1 (past the end: chunk 15 again, dropped)
+            asm volatile("" ::: "memory");
+            const bool more = j + 1 < NCH && j > 0;                       // W2(0) and W2(1) were requested up front
+            const f16* nsrc = a.w2f + (long long)(j + 1) * (FZ_STAGE / 2);
+            const unsigned ndst = lds_base + ((j + 1) & 1) * FZ_STAGE;
+            const int jn = j + 2 < NCH ? j + 2 : NCH - 1;
+            fz_steps<CF / 2, 4, RD>(lrd + (j & 1) * FZ_STAGE, [&](int q, const uint4 (&w)[4]) {
+                fc2_step(q, w, hc[0], hc[1]);
+                if (q < 8) {
+                    if (more) { fz_piece(nsrc, ndst, q, wave, lane); fz_piece(nsrc, ndst, 8 + q, wave, lane); }
+                    if (2 * q < NG) piece(jn, 2 * q);
+                    if (2 * q + 1 < NG) piece(jn, 2 * q + 1);
+                }
+                if (q == 8) swish4(pre[0][0]);
+                if (q == 9) swish4(pre[0][1]);
+                if (q == 10) swish4(pre[1][0]);
+                if (q == 11) swish4(pre[1][1]);
+                if (q == 12) hn[0] = fz_pack8(pre[0][0], pre[0][1]);
+                if (q == 13) hn[1] = fz_pack8(pre[1][0], pre[1][1]);
+            });
+            hc[0] = hn[0]; hc[1] = hn[1];
+        }
     }
 
     // ---- epilogue: LayerNorm, residual update, receiver sum ---------------------------------------------------------------------- //
-    const int prv0 = tile0 > 0 ? a.recv[tile0 - 1] : -2;              // wave-uniform: does the tile's first run continue the previous tile's?
-    const int first = a.recv[tile0];
-    const bool tile_cont = first >= 0 && prv0 == first;
-    int nxt[FM];
+    stamp(3);
+    if constexpr (FC1) {
+        if (a.e_out != nullptr) {
 #pragma unroll
-    for (int t = 0; t < FM; ++t) nxt[t] = (wave * 32 + t * 16 + l15 + 1 < FZ_TILE) ? a.recv[row[t] + 1] : -3;
-    // per 16-row group: LayerNorm, residual update, then the segmented inclusive scan over the group's rows -- after it the LAST row of
-    // every run holds the run's sum inside the group
-#pragma unroll
-    for (int t = 0; t < FM; ++t) {
-        bool stored = false;
-        if constexpr (FC1) {
-            if (a.e_out != nullptr) {
+            for (int t = 0; t < FM; ++t) {
                 const long long off = (((rb0 + t) * KS) << 9) + l15 * 32 + g * 8;
                 v8 xr[KS];
 #pragma unroll
                 for (int bp = 0; bp < KS; ++bp) xr[bp] = *reinterpret_cast<const v8*>(a.e_in + off + (bp << 9));
                 fz_layer_norm(yacc[t], tab, g, a.eps);
-                stored = true;
                 if (my[t] >= 0) {
 #pragma unroll
                     for (int bp = 0; bp < KS; ++bp) {
@@ -334,69 +467,61 @@ edge_update_kernel(const EdgeArgs a) {
                     }
                 }
             }
+        } else {
+#pragma unroll
+            for (int t = 0; t < FM; ++t) fz_layer_norm(yacc[t], tab, g, a.eps);
         }
-        if (!stored) fz_layer_norm(yacc[t], tab, g, a.eps);
-        const int m = my[t];
-        const float m1 = (m >= 0 && fz_dpp_i<0x111>(m, -7) == m) ? 1.f : 0.f, m2 = (m >= 0 && fz_dpp_i<0x112>(m, -7) == m) ? 1.f : 0.f;
-        const float m4 = (m >= 0 && fz_dpp_i<0x114>(m, -7) == m) ? 1.f : 0.f, m8 = (m >= 0 && fz_dpp_i<0x118>(m, -7) == m) ? 1.f : 0.f;
+    } else {
 #pragma unroll
-        for (int c = 0; c < CF; ++c)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float v = yacc[t][c][r];
-                v = fmaf(fz_dpp<0x111>(v), m1, v);
-                v = fmaf(fz_dpp<0x112>(v), m2, v);
-                v = fmaf(fz_dpp<0x114>(v), m4, v);
-                v = fmaf(fz_dpp<0x118>(v), m8, v);
-                yacc[t][c][r] = v;
-            }
+        for (int t = 0; t < FM; ++t) fz_layer_norm(yacc[t], tab, g, a.eps);
     }
-    // exchange between the 8 groups of the tile: group u = 2 wave + t publishes the sum of its LAST run (row 15) and that run's receiver
-    __syncthreads();                                   // every wave is done with the weight stages: stage 0 becomes the exchange buffer
-    float* tails = reinterpret_cast<float*>(smem);     // [8 groups][4 g][128]
-    int* tmeta = reinterpret_cast<int*>(smem + 8 * 2048);
+    stamp(4);
+    // receiver sums: the 128 normalised rows through LDS, 256 columns at a time; thread c walks column c down the rows in order
+    float* ybuf = reinterpret_cast<float*>(smem);
+    const int first = rcv_l[1];
+    const bool tile_cont = first >= 0 && rcv_l[0] == first;          // the tile's first run continues the previous tile's last one
+    // bit r of (ends_hi : ends_lo): the run of row r ends there (the next row has another receiver, or the tile ends)
+    const int rv0 = rcv_l[1 + lane], rv1 = rcv_l[65 + lane];         // receivers of rows lane, 64 + lane: read back with v_readlane at a run's end
+    const unsigned long long ends_lo = __ballot(rcv_l[2 + lane] != rv0), ends_hi = __ballot(rcv_l[66 + lane] != rv1);
 #pragma unroll
-    for (int t = 0; t < FM; ++t) {
-        const int u = wave * 2 + t;
-        if (l15 == 15) {
-            float* dst = tails + u * 512 + g * 128;
+    for (int half = 0; half < 2; ++half) {
+        __syncthreads();                               // every wave is done with the weight stages / with the previous half
 #pragma unroll
-            for (int bp = 0; bp < KS; ++bp) {
-                *reinterpret_cast<float4*>(dst + bp * 8) = make_float4(yacc[t][2 * bp][0], yacc[t][2 * bp][1], yacc[t][2 * bp][2], yacc[t][2 * bp][3]);
-                *reinterpret_cast<float4*>(dst + bp * 8 + 4) = make_float4(yacc[t][2 * bp + 1][0], yacc[t][2 * bp + 1][1], yacc[t][2 * bp + 1][2], yacc[t][2 * bp + 1][3]);
+        for (int t = 0; t < FM; ++t) {
+            float* dst = ybuf + (wave * 32 + t * 16 + l15) * FZ_YLD + 8 * g;
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const f32x4 &x = yacc[t][2 * (8 * half + b)], &z = yacc[t][2 * (8 * half + b) + 1];
+                *reinterpret_cast<float4*>(dst + 32 * b) = make_float4(x[0], x[1], x[2], x[3]);
+                *reinterpret_cast<float4*>(dst + 32 * b + 4) = make_float4(z[0], z[1], z[2], z[3]);
             }
-            if (g == 0) tmeta[u] = my[t];
         }
-    }
-    __syncthreads();
+        __syncthreads();
+        const float* col = ybuf + tid;
+        float* const out_c = a.agg + 256 * half + tid;
+        float* const head_c = a.heads + (long long)blockIdx.x * FZ_L + 256 * half + tid;
+        float acc = 0.f;
+#pragma unroll 1
+        for (int r0 = 0; r0 < FZ_TILE; r0 += 16) {
+            float v[16];
 #pragma unroll
-    for (int t = 0; t < FM; ++t) {
-        const int u = wave * 2 + t;
-        const int head = __builtin_amdgcn_readlane(my[t], 0);         // receiver of the group's first row (wave-uniform)
-        const bool in_head = my[t] == head;
-        // the groups before this one whose last run is this group's first run, nearest first (a fixed order: the sum is deterministic)
-        for (int up = u - 1; up >= 0 && head >= 0 && tmeta[up] == head; --up) {
-            const float* src = tails + up * 512 + g * 128;
+            for (int i = 0; i < 16; ++i) v[i] = col[(r0 + i) * FZ_YLD];          // 16 rows in flight; the run logic below is scalar
+            const unsigned ends = (unsigned)((r0 < 64 ? ends_lo : ends_hi) >> (r0 & 63)) & 0xffffu;
 #pragma unroll
-            for (int bp = 0; bp < KS; ++bp) {
-                const float4 c0 = *reinterpret_cast<const float4*>(src + bp * 8), c1 = *reinterpret_cast<const float4*>(src + bp * 8 + 4);
-                if (in_head) {
-                    yacc[t][2 * bp][0] += c0.x; yacc[t][2 * bp][1] += c0.y; yacc[t][2 * bp][2] += c0.z; yacc[t][2 * bp][3] += c0.w;
-                    yacc[t][2 * bp + 1][0] += c1.x; yacc[t][2 * bp + 1][1] += c1.y; yacc[t][2 * bp + 1][2] += c1.z; yacc[t][2 * bp + 1][3] += c1.w;
+            for (int i = 0; i < 16; ++i) {
+                acc += v[i];
+                if (ends & (1u << i)) {                    // the run ends with row r0 + i (uniform branch)
+                    const int cur = __builtin_amdgcn_readlane(r0 < 64 ? rv0 : rv1, (r0 + i) & 63);
+                    if (cur >= 0) {
+                        if (tile_cont && cur == first) *head_c = acc;
+                        else out_c[(long long)cur * FZ_L] = acc;
+                    }
+                    acc = 0.f;
                 }
             }
         }
-        // a run ends where the next row has another receiver (or the tile ends): its last row writes the sum
-        if (my[t] >= 0 && my[t] != nxt[t]) {
-            float* dst = (tile_cont && my[t] == first) ? a.heads + (long long)blockIdx.x * FZ_L : a.agg + (long long)my[t] * FZ_L;
-            dst += 8 * g;
-#pragma unroll
-            for (int bp = 0; bp < KS; ++bp) {
-                *reinterpret_cast<float4*>(dst + 32 * bp) = make_float4(yacc[t][2 * bp][0], yacc[t][2 * bp][1], yacc[t][2 * bp][2], yacc[t][2 * bp][3]);
-                *reinterpret_cast<float4*>(dst + 32 * bp + 4) = make_float4(yacc[t][2 * bp + 1][0], yacc[t][2 * bp + 1][1], yacc[t][2 * bp + 1][2], yacc[t][2 * bp + 1][3]);
-            }
-        }
     }
+    stamp(5);
 }
 
 // agg[node[i]] += heads[tiles[first[i]]] + heads[tiles[first[i] + 1]] + ...   in that order; one workgroup of 128 lanes x float4 per node
@@ -414,11 +539,13 @@ __global__ void __launch_bounds__(128) segment_fixup_kernel(float* __restrict__ 
 // ---- node update:  out = res + LayerNorm(W2 swish(W1 concat(src...) + b1) + b2)  on fp32 rows, three MFMA terms ------------------------ //
 // The node latents are the network's residual streams; rounding them (or the node MLPs' hidden activations) to one fp16 plane costs
 // 4-5e-4 of the predicted increment (tools/graphcast_numerics.py), so this form splits every fp32 operand into fp16 hi/lo fragments on the
-// fly: A W^T ~ A_hi W_lo^T + A_lo W_hi^T + A_hi W_hi^T.  One 16-row group per wave (x: 128 / 256 registers, hidden: 128), 64 rows per tile.
+// fly: A W^T ~ A_hi W_lo^T + A_lo W_hi^T + A_hi W_hi^T.  One 16-row group per wave, 64 rows per tile.  Concatenated sources are taken one
+// after the other (W1 = [W1_0 | W1_1], prepared source by source): after source 0 the 512 partial pre-activations wait in the registers
+// that become the hidden fragments after the last source, so a wave never holds more than one source's 128 operand registers.
 struct NodeArgs {
     const float* src[2];    // fp32 rows, 512 columns each (concatenated along K)
     long long ld[2];
-    const f16 *w1f, *w2f;   // fragment order, hi/lo planes: [512][512 n_src], [512][512]
+    const f16 *w1f, *w2f;   // fragment order, hi/lo planes: n_src x [512][512], [512][512]
     const float *b1, *b2, *gamma, *beta;
     const float* res;       // nullable; out may alias res
     long long ld_res;
@@ -431,83 +558,124 @@ struct NodeArgs {
 template <int NS>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 node_mlp_kernel(const NodeArgs a) {
-    constexpr int KS = FZ_KS * NS, CF = FZ_CF, NCH = FZ_NCH, RD = 3;
-    constexpr int NST = NCH * NS;                                      // phase-1 stages of 64 KiB: a chunk of 32 units (NS = 1) or half a chunk
+    constexpr int KS = FZ_KS, CF = FZ_CF, NCH = FZ_NCH, RD = FZ_RD;
     typedef typename OpT<f16>::v8 v8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* tab = reinterpret_cast<float*>(smem + 2 * FZ_STAGE);        // b2 | gamma | beta | b1
+    float* tab = reinterpret_cast<float*>(smem + FZ_YBUF);            // b2 | gamma | beta | b1
     const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const unsigned lds_base = (unsigned)(size_t)smem;
     const char* lrd = smem + lane * 16;
 
-    fz_dma64k(a.w1f, lds_base, wave, lane);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) fz_piece(a.w1f, lds_base, k, wave, lane, true);
     for (int i = tid; i < FZ_L; i += 256) { tab[i] = a.b2[i]; tab[FZ_L + i] = a.gamma[i]; tab[2 * FZ_L + i] = a.beta[i]; tab[3 * FZ_L + i] = a.b1[i]; }
 
     const long long row = (long long)blockIdx.x * 64 + wave * 16 + l15;
     const bool live = row < a.rows;
     const long long rr = live ? row : a.rows - 1;
-    v8 xh[KS], xl[KS];
+
+    // part[j]: chunk j's 2 x 4 pre-activations after the sources so far; after the last source the same registers hold the hidden
+    // activation's hi / lo fragments (bit patterns: 8 fp32 <-> 2 x 8 fp16)
+    f32x4 part[2][NCH];
+    static_assert(NCH == 16, "fz_pick / fz_put");
+    int stage = 0;                                                    // LDS stage of the chunk being read
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
-        const float* p = a.src[s] + rr * a.ld[s] + 8 * g;
+        v8 xh[KS], xl[KS];
+        {
+            const float* p = a.src[s] + rr * a.ld[s] + 8 * g;
 #pragma unroll
-        for (int ks = 0; ks < FZ_KS; ++ks) {
-            const float4 u0 = *reinterpret_cast<const float4*>(p + 32 * ks), u1 = *reinterpret_cast<const float4*>(p + 32 * ks + 4);
-            const float v[8] = {u0.x, u0.y, u0.z, u0.w, u1.x, u1.y, u1.z, u1.w};
-            uint4 o[2];
-            split8<f16, 2>(v, o);
-            xh[s * FZ_KS + ks] = as_v8<f16>(o[0]);
-            xl[s * FZ_KS + ks] = as_v8<f16>(o[1]);
+            for (int ks = 0; ks < KS; ++ks) {
+                const float4 u0 = *reinterpret_cast<const float4*>(p + 32 * ks), u1 = *reinterpret_cast<const float4*>(p + 32 * ks + 4);
+                const float v[8] = {u0.x, u0.y, u0.z, u0.w, u1.x, u1.y, u1.z, u1.w};
+                fz_split8(v, xh[ks], xl[ks]);
+            }
         }
-    }
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) { asm volatile("" : "+v"(xh[ks])); asm volatile("" : "+v"(xl[ks])); }
-
-    uint4 hh[NCH], hl[NCH];
-    f32x4 hacc[2];
+        for (int ks = 0; ks < KS; ++ks) { asm volatile("" : "+v"(xh[ks])); asm volatile("" : "+v"(xl[ks])); }
+#pragma unroll 1
+        for (int j = 0; j < NCH; ++j) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                           // this chunk's weights landed; every wave is done with the other stage
+            const bool last = s == NS - 1 && j == NCH - 1;
+            const f16* nsrc = last ? a.w2f : a.w1f + (long long)(s * NCH + j + 1) * (FZ_STAGE / 2);
+            const unsigned ndst = lds_base + (stage ^ 1) * FZ_STAGE;
+            // four accumulator chains: 16-unit half n x parity of the k-step; a step = two k-steps = 8 fragments [ks][n][plane]
+            f32x4 acc[2][2];
+            if (s == 0) {
+                const float4 b0 = *reinterpret_cast<const float4*>(tab + 3 * FZ_L + 32 * j + 4 * g), b1 = *reinterpret_cast<const float4*>(tab + 3 * FZ_L + 32 * j + 16 + 4 * g);
+                acc[0][0] = f32x4{b0.x, b0.y, b0.z, b0.w};
+                acc[1][0] = f32x4{b1.x, b1.y, b1.z, b1.w};
+            } else {
+                acc[0][0] = fz_pick(part[0], j);
+                acc[1][0] = fz_pick(part[1], j);
+            }
+            acc[0][1] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[1][1] = acc[0][1];
+            if (FZ_DBG & 1) {
 #pragma unroll
-    for (int sidx = 0; sidx < NST; ++sidx) {
-        const int j = sidx / NS;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                               // stage sidx landed; every wave is done with the other stage
-        if (sidx + 1 < NST) fz_dma64k(a.w1f + (long long)(sidx + 1) * (FZ_STAGE / 2), lds_base + ((sidx + 1) & 1) * FZ_STAGE, wave, lane);
-        else fz_dma64k(a.w2f, lds_base + (NST & 1) * FZ_STAGE, wave, lane);
-        if (NS == 1 || (sidx & 1) == 0) {
-            const float4 b0 = *reinterpret_cast<const float4*>(tab + 3 * FZ_L + 32 * j + 4 * g), b1 = *reinterpret_cast<const float4*>(tab + 3 * FZ_L + 32 * j + 16 + 4 * g);
-            hacc[0] = f32x4{b0.x, b0.y, b0.z, b0.w};
-            hacc[1] = f32x4{b1.x, b1.y, b1.z, b1.w};
-        }
-        fz_stream<32, RD>(lrd + (sidx & 1) * FZ_STAGE, [&](int p, const uint4& wh, const uint4& wl) {
-            const int n = NS == 1 ? (p >> 4) : (sidx & 1), ks = NS == 1 ? (p & 15) : p;
-            hacc[n] = OpT<f16>::mfma(as_v8<f16>(wl), xh[ks], hacc[n]);
-            hacc[n] = OpT<f16>::mfma(as_v8<f16>(wh), xl[ks], hacc[n]);
-            hacc[n] = OpT<f16>::mfma(as_v8<f16>(wh), xh[ks], hacc[n]);
-        });
-        if (NS == 1 || (sidx & 1) == 1) {
-            float v[8];
+                for (int k = 0; k < 16; ++k) fz_piece(nsrc, ndst, k, wave, lane);
+            }
+            fz_steps<KS / 2, 8, (FZ_DBG & 4) ? 1 : RD>(lrd + stage * FZ_STAGE, [&](int q, const uint4 (&w)[8]) {
+                const int k0 = 2 * q, k1 = 2 * q + 1;
+                acc[0][0] = fz_mfma(w[1], xh[k0], acc[0][0]);
+                acc[1][0] = fz_mfma(w[3], xh[k0], acc[1][0]);
+                acc[0][1] = fz_mfma(w[5], xh[k1], acc[0][1]);
+                acc[1][1] = fz_mfma(w[7], xh[k1], acc[1][1]);
+                if (q < 4 && !(FZ_DBG & 1)) { fz_piece(nsrc, ndst, 4 * q, wave, lane); fz_piece(nsrc, ndst, 4 * q + 1, wave, lane); }
+                acc[0][0] = fz_mfma(w[0], xl[k0], acc[0][0]);
+                acc[1][0] = fz_mfma(w[2], xl[k0], acc[1][0]);
+                acc[0][1] = fz_mfma(w[4], xl[k1], acc[0][1]);
+                acc[1][1] = fz_mfma(w[6], xl[k1], acc[1][1]);
+                if (q < 4 && !(FZ_DBG & 1)) { fz_piece(nsrc, ndst, 4 * q + 2, wave, lane); fz_piece(nsrc, ndst, 4 * q + 3, wave, lane); }
+                acc[0][0] = fz_mfma(w[0], xh[k0], acc[0][0]);
+                acc[1][0] = fz_mfma(w[2], xh[k0], acc[1][0]);
+                acc[0][1] = fz_mfma(w[4], xh[k1], acc[0][1]);
+                acc[1][1] = fz_mfma(w[6], xh[k1], acc[1][1]);
+            });
+            f32x4 lo = acc[0][0] + acc[0][1], hi = acc[1][0] + acc[1][1];
+            if (s == NS - 1) {                          // swish, hi / lo split: the hidden fragments of k-step j of the second Linear
+                float v[8];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { v[r] = swish_f(hacc[0][r]); v[4 + r] = swish_f(hacc[1][r]); }
-            uint4 o[2];
-            split8<f16, 2>(v, o);
-            hh[j] = o[0]; hl[j] = o[1];
+                for (int r = 0; r < 4; ++r) { v[r] = swish_f(lo[r]); v[4 + r] = swish_f(hi[r]); }
+                f16x8 o0, o1;
+                fz_split8(v, o0, o1);
+                lo = __builtin_bit_cast(f32x4, o0);
+                hi = __builtin_bit_cast(f32x4, o1);
+            }
+            fz_put(part[0], j, lo);
+            fz_put(part[1], j, hi);
+            stage ^= 1;
         }
     }
 
     f32x4 yacc[CF];
 #pragma unroll
     for (int c = 0; c < CF; ++c) yacc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
+#pragma unroll 1
     for (int j = 0; j < NCH; ++j) {
-        const int stg = (NST + j) & 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (j + 1 < NCH) fz_dma64k(a.w2f + (long long)(j + 1) * (FZ_STAGE / 2), lds_base + (stg ^ 1) * FZ_STAGE, wave, lane);
-        fz_stream<CF, RD>(lrd + stg * FZ_STAGE, [&](int c, const uint4& wh, const uint4& wl) {
-            yacc[c] = OpT<f16>::mfma(as_v8<f16>(wl), as_v8<f16>(hh[j]), yacc[c]);
-            yacc[c] = OpT<f16>::mfma(as_v8<f16>(wh), as_v8<f16>(hl[j]), yacc[c]);
-            yacc[c] = OpT<f16>::mfma(as_v8<f16>(wh), as_v8<f16>(hh[j]), yacc[c]);
+        const bool more = j + 1 < NCH;
+        const f16* nsrc = a.w2f + (long long)(j + 1) * (FZ_STAGE / 2);
+        const unsigned ndst = lds_base + (stage ^ 1) * FZ_STAGE;
+        const v8 h = __builtin_bit_cast(v8, fz_pick(part[0], j)), l = __builtin_bit_cast(v8, fz_pick(part[1], j));
+        if ((FZ_DBG & 1) && more) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) fz_piece(nsrc, ndst, k, wave, lane);
+        }
+        // step q: output fragments 4 q .. 4 q + 3 (hi, lo planes each): four accumulator chains, three terms each
+        fz_steps<CF / 4, 8, (FZ_DBG & 4) ? 1 : RD>(lrd + stage * FZ_STAGE, [&](int q, const uint4 (&w)[8]) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) yacc[4 * q + i] = fz_mfma(w[2 * i + 1], h, yacc[4 * q + i]);
+            if (more && q < 4 && !(FZ_DBG & 1)) { fz_piece(nsrc, ndst, 4 * q, wave, lane); fz_piece(nsrc, ndst, 4 * q + 1, wave, lane); }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) yacc[4 * q + i] = fz_mfma(w[2 * i], l, yacc[4 * q + i]);
+            if (more && q < 4 && !(FZ_DBG & 1)) { fz_piece(nsrc, ndst, 4 * q + 2, wave, lane); fz_piece(nsrc, ndst, 4 * q + 3, wave, lane); }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) yacc[4 * q + i] = fz_mfma(w[2 * i], h, yacc[4 * q + i]);
         });
+        stage ^= 1;
     }
 
     // epilogue: all loads before the first store (epilogues.h: stores share the VMEM counter with loads)
@@ -536,9 +704,9 @@ node_mlp_kernel(const NodeArgs a) {
 
 using namespace skp;
 
-template <bool FC1, int NT>
+template <bool FC1, int NT, int W1P>
 static int launch_edge(const EdgeArgs& a, long long tiles, hipStream_t st) {
-    auto kern = edge_update_kernel<FC1, NT>;
+    auto kern = edge_update_kernel<FC1, NT, W1P>;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, FZ_SMEM) != hipSuccess) return SKGC_E_HIP;
     hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), FZ_SMEM, st, a);
     return hipGetLastError() == hipSuccess ? 0 : SKGC_E_HIP;
@@ -548,7 +716,8 @@ extern "C" {
 
 int skgc_edge_update(const skgc_edge_desc* d, void* stream) {
     if (!d || !d->e_in || !d->recv || !d->w2f || !d->b2 || !d->gamma || !d->beta || !d->agg || d->rows <= 0 || (d->rows % FZ_TILE) || d->n_term < 0 || d->n_term > 2 ||
-        (d->has_fc1 && !d->w1f) || (!d->has_fc1 && d->e_out) || (reinterpret_cast<size_t>(d->e_in) & 15) || (reinterpret_cast<size_t>(d->e_out) & 15))
+        (d->has_fc1 && (!d->w1f || (d->w1_planes != 1 && d->w1_planes != 2))) || (!d->has_fc1 && d->e_out) || (reinterpret_cast<size_t>(d->e_in) & 15) ||
+        (reinterpret_cast<size_t>(d->e_out) & 15))
         return SKGC_E_ARG;
     const long long tiles = d->rows / FZ_TILE;
     if (tiles > 0x7fffffff) return SKGC_E_ARG;
@@ -563,15 +732,21 @@ int skgc_edge_update(const skgc_edge_desc* d, void* stream) {
     }
     a.recv = d->recv; a.w1f = static_cast<const f16*>(d->w1f); a.w2f = static_cast<const f16*>(d->w2f);
     a.b2 = d->b2; a.gamma = d->gamma; a.beta = d->beta; a.agg = d->agg; a.heads = d->heads; a.eps = 1e-5f;
+    a.probe = d->probe;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (d->has_fc1) {
-        if (d->n_term == 2) return launch_edge<true, 2>(a, tiles, st);
-        if (d->n_term == 1) return launch_edge<true, 1>(a, tiles, st);
-        return launch_edge<true, 0>(a, tiles, st);
+        if (d->w1_planes == 2) {
+            if (d->n_term == 2) return launch_edge<true, 2, 2>(a, tiles, st);
+            if (d->n_term == 1) return launch_edge<true, 1, 2>(a, tiles, st);
+            return launch_edge<true, 0, 2>(a, tiles, st);
+        }
+        if (d->n_term == 2) return launch_edge<true, 2, 1>(a, tiles, st);
+        if (d->n_term == 1) return launch_edge<true, 1, 1>(a, tiles, st);
+        return launch_edge<true, 0, 1>(a, tiles, st);
     }
-    if (d->n_term == 2) return launch_edge<false, 2>(a, tiles, st);
-    if (d->n_term == 1) return launch_edge<false, 1>(a, tiles, st);
-    return launch_edge<false, 0>(a, tiles, st);
+    if (d->n_term == 2) return launch_edge<false, 2, 1>(a, tiles, st);
+    if (d->n_term == 1) return launch_edge<false, 1, 1>(a, tiles, st);
+    return launch_edge<false, 0, 1>(a, tiles, st);
 }
 
 int skgc_node_mlp(const skgc_node_desc* d, void* stream) {

@@ -49,7 +49,7 @@ class EdgeDesc(ctypes.Structure):
     _fields_ = [("e_in", ctypes.c_void_p), ("e_out", ctypes.c_void_p), ("term", ctypes.c_void_p * 2), ("idx", ctypes.c_void_p * 2), ("ld", ctypes.c_longlong * 2),
                 ("n_term", ctypes.c_int), ("recv", ctypes.c_void_p), ("w1f", ctypes.c_void_p), ("w2f", ctypes.c_void_p), ("b2", ctypes.c_void_p),
                 ("gamma", ctypes.c_void_p), ("beta", ctypes.c_void_p), ("agg", ctypes.c_void_p), ("heads", ctypes.c_void_p), ("rows", ctypes.c_longlong),
-                ("has_fc1", ctypes.c_int)]
+                ("has_fc1", ctypes.c_int), ("w1_planes", ctypes.c_int), ("probe", ctypes.c_void_p)]
 
 
 class NodeDesc(ctypes.Structure):
@@ -133,6 +133,11 @@ class GraphcastEngine:
         # round 4: every interaction-network update as ONE kernel (csrc/graphcast_fused.hip): edge update + receiver sum on packed rows with
         # one-plane fp16 edge operands, node updates on fp32 rows with three MFMA terms.  SKGC_UNFUSED=1 keeps the round-3 kernel sequence.
         self.fused = self.split_edges and not os.environ.get("SKGC_UNFUSED")
+        # planes of the processor edge MLPs' first Linear (edge part): 1 = W_e as one fp16 plane (one MFMA term: +1.4e-4 of the predicted
+        # increment at production width and depth, tools/graphcast_numerics.py), 2 = hi/lo planes (two terms)
+        self.w1_planes = int(os.environ.get("SKGC_W1_PLANES", "1"))
+        if self.w1_planes not in (1, 2):
+            raise ValueError("SKGC_W1_PLANES is 1 or 2")
         self.state_shape = (self.cfg.n_vars, self.lat1 - self.lat0, self.cfg.n_lon)
 
     def _stream(self):
@@ -232,7 +237,7 @@ class GraphcastEngine:
         L = self.cfg.latent
         self._mark(label, 2.0 * f["n_edges"] * L * L * (2 if f.get("w1f") is not None else 1))
         ops.hip.gc_edge_update(e_in, e_out, [t for t, _, _, _ in terms], [o for _, o, _, _ in terms], [d for _, _, d, _ in terms], [i for _, _, _, i in terms],
-                               f["recv"], f.get("w1f"), f["w2f"], f["b2"], f["g"], f["b"], agg, f.get("heads"), f["rows"])
+                               f["recv"], f.get("w1f"), f["w2f"], f["b2"], f["g"], f["b"], agg, f.get("heads"), f["rows"], None, self.w1_planes)
         if f.get("fix") is not None:
             self._mark(label)
             ops.hip.gc_segment_fixup(agg, f["heads"], *f["fix"])
@@ -283,7 +288,7 @@ class GraphcastEngine:
             w2 = p[name + ".fc2.weight"]
             d = dict(w2f=_fz.prep_w2_fragments(f32(w2)), b2=self.m[name]["b2"], g=self.m[name]["g"], b=self.m[name]["b"])
             if k0 is not None:
-                d["w1f"] = _fz.prep_w1_fragments(f32(w1[:, k0:k1]))
+                d["w1f"] = _fz.prep_w1_fragments(f32(w1[:, k0:k1]), self.w1_planes)
             return d
 
         cols = upos.to(dev)

@@ -121,20 +121,27 @@ _E = np.arange(8)
 
 
 def prep_w1_fragments(w1: torch.Tensor, planes: int = 2) -> torch.Tensor:
-    """First-Linear weight [H][K] (H % 32 == 0, K % 32 == 0) -> fragment order, flat fp16:
-        block ((2 j + n) KS + ks) planes + p,  [lane][e] = plane_p( w1[32 j + 16 n + (lane & 15)][32 ks + 8 (lane >> 4) + e] )
-    -- one 1 KiB block = the A operand of one v_mfma_f32_16x16x32_f16 (what one ds_read_b128 wave instruction fetches); the blocks of
-    16 hidden units (j, n) are contiguous (K = 512: 32 KiB with both planes, a chunk j of 32 units = 64 KiB = one LDS stage)."""
+    """First-Linear weight [H][K] (H % 32 == 0, K % 512 == 0) -> fragment order, flat fp16.  K is taken in SOURCES of 512 columns (the
+    node kernel walks concatenated sources one after the other); per source
+        block (((j 16 + ks) 2 + n) planes + p),  [lane][e] = plane_p( w1[32 j + 16 n + (lane & 15)][512 s + 32 ks + 8 (lane >> 4) + e] )
+    -- one 1 KiB block = the A operand of one v_mfma_f32_16x16x32_f16 (what one ds_read_b128 wave instruction fetches).  A chunk j of 32
+    hidden units is contiguous (64 KiB with two planes = one LDS stage); inside it the two 16-unit halves n of a k-step are neighbours,
+    so that a step of the kernels' MFMA loops runs four independent accumulator chains."""
     H, K = w1.shape
-    KS = K // 32
-    j, n, ks = np.meshgrid(np.arange(H // 32), np.arange(2), np.arange(KS), indexing="ij")
-    rows = (32 * j + 16 * n)[..., None, None] + _L15[None, None, None, :, None]                # [J][2][KS][64][1]
-    cols = (32 * ks)[..., None, None] + (8 * _G)[None, None, None, :, None] + _E[None, None, None, None, :]
-    rows = np.broadcast_to(rows, cols.shape)
-    idx = torch.from_numpy((rows * K + cols).reshape(-1)).to(w1.device)
-    frag = w1.reshape(-1)[idx].reshape(H // 32, 2, KS, 64, 8)                                  # [J][n][KS][lane][e]
-    pl = _planes(frag, planes)                                                                  # [p][J][n][KS][lane][e]
-    return pl.permute(1, 2, 3, 0, 4, 5).contiguous().reshape(-1)
+    if K % 512 or H % 32:
+        raise ValueError("prep_w1_fragments: [H][512 n_src] with H % 32 == 0")
+    KS = 16
+    out = []
+    for s in range(K // 512):
+        j, ks, n = np.meshgrid(np.arange(H // 32), np.arange(KS), np.arange(2), indexing="ij")
+        rows = (32 * j + 16 * n)[..., None, None] + _L15[None, None, None, :, None]            # [J][KS][2][64][1]
+        cols = (512 * s + 32 * ks)[..., None, None] + (8 * _G)[None, None, None, :, None] + _E[None, None, None, None, :]
+        rows = np.broadcast_to(rows, cols.shape)
+        idx = torch.from_numpy((rows * K + cols).reshape(-1)).to(w1.device)
+        frag = w1.reshape(-1)[idx].reshape(H // 32, KS, 2, 64, 8)                              # [J][KS][n][lane][e]
+        pl = _planes(frag, planes)                                                              # [p][J][KS][n][lane][e]
+        out.append(pl.permute(1, 2, 3, 0, 4, 5).contiguous().reshape(-1))
+    return torch.cat(out)
 
 
 def prep_w2_fragments(w2: torch.Tensor, planes: int = 2) -> torch.Tensor:

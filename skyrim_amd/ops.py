@@ -234,7 +234,7 @@ def _f16(t, what: str, dev):
     return t.data_ptr()
 
 
-def _gc_edge_update(e_in, e_out, term, term_off, ld, idx, recv, w1f, w2f, b2, gamma, beta, agg, heads, rows: int) -> None:
+def _gc_edge_update(e_in, e_out, term, term_off, ld, idx, recv, w1f, w2f, b2, gamma, beta, agg, heads, rows: int, probe=None, w1_planes: int = 2) -> None:
     from .graphcast import engine
     lib = engine.load_library()
     dev = agg.device
@@ -257,7 +257,10 @@ def _gc_edge_update(e_in, e_out, term, term_off, ld, idx, recv, w1f, w2f, b2, ga
     d.b2, d.gamma, d.beta = _f32(b2, "b2", dev).value, _f32(gamma, "gamma", dev).value, _f32(beta, "beta", dev).value
     d.agg = _f32(agg, "agg").value
     d.heads = _f32(heads, "heads", dev).value if heads is not None else None
-    d.rows, d.has_fc1 = rows, int(w1f is not None)
+    d.rows, d.has_fc1, d.w1_planes = rows, int(w1f is not None), w1_planes
+    if w1f is not None and w1f.numel() != w1_planes * 512 * 512:
+        raise ValueError("gc_edge_update: w1f holds w1_planes planes of [512][512] in fragment order")
+    d.probe = probe.data_ptr() if probe is not None else None
     with torch.cuda.device(dev):
         _ok(lib.skgc_edge_update(ctypes.byref(d), _stream(agg)), "skgc_edge_update")
 
@@ -320,7 +323,7 @@ _SCHEMAS = [
     ("gc_layer_norm(Tensor x, Tensor gamma, Tensor beta, Tensor? res, Tensor(a!) out, int rows, int N) -> ()", _gc_layer_norm),
     ("gc_segment_sum(Tensor e, Tensor offsets, Tensor(a!) out, Tensor(b!)? acc, int n_nodes, int N) -> ()", _gc_segment_sum),
     ("gc_edge_update(Tensor e_in, Tensor(c!)? e_out, Tensor[] term, int[] term_off, int[] ld, Tensor[] idx, Tensor recv, Tensor? w1f, Tensor w2f, Tensor b2, "
-     "Tensor gamma, Tensor beta, Tensor(a!) agg, Tensor(b!)? heads, int rows) -> ()", _gc_edge_update),
+     "Tensor gamma, Tensor beta, Tensor(a!) agg, Tensor(b!)? heads, int rows, Tensor(d!)? probe=None, int w1_planes=2) -> ()", _gc_edge_update),
     ("gc_segment_fixup(Tensor(a!) agg, Tensor heads, Tensor nodes, Tensor first, Tensor tiles) -> ()", _gc_segment_fixup),
     ("gc_node_mlp(Tensor[] src, int[] src_off, int[] ld, Tensor w1f, Tensor w2f, Tensor b1, Tensor b2, Tensor gamma, Tensor beta, Tensor? res, int res_off, "
      "int ld_res, Tensor(a!) out, int out_off, int ld_out, int rows) -> ()", _gc_node_mlp),

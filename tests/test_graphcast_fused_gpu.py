@@ -34,8 +34,8 @@ def _edge_case(seed, lens, n_nodes):
     return d
 
 
-@pytest.mark.parametrize("has_fc1", [True, False])
-def test_edge_update_and_receiver_sum_vs_float64(has_fc1):
+@pytest.mark.parametrize("has_fc1,planes", [(True, 2), (True, 1), (False, 2)])
+def test_edge_update_and_receiver_sum_vs_float64(has_fc1, planes):
     from skyrim_amd import ops
     rng = np.random.default_rng(5)
     lens = np.r_[rng.integers(1, 43, size=60), 300, rng.integers(1, 43, size=30), 1, 1, 130]
@@ -55,10 +55,11 @@ def test_edge_update_and_receiver_sum_vs_float64(has_fc1):
     if has_fc1:
         e_b = fz.to_blocked_f16(packed.float().to(dev))
         e_out = e_b.clone()
-        w1f = fz.prep_w1_fragments(c["w1e"].float().to(dev))
-        ops.hip.gc_edge_update(e_b, e_out, [t2, t2], [0, L], [2 * L, 2 * L], [send_d, recv_d], recv_d, w1f, w2f, b2, gamma, beta, agg, heads, R)
+        w1f = fz.prep_w1_fragments(c["w1e"].float().to(dev), planes)
+        ops.hip.gc_edge_update(e_b, e_out, [t2, t2], [0, L], [2 * L, 2 * L], [send_d, recv_d], recv_d, w1f, w2f, b2, gamma, beta, agg, heads, R, None, planes)
         x = f16(c["e"])
-        pre = x @ c["w1e"].float().double().T + c["ts"].float().double()[send_e] + c["tr"].float().double()[recv_e]
+        w1 = c["w1e"].float().double() if planes == 2 else f16(c["w1e"].float())                    # one plane: W_e itself is rounded to fp16
+        pre = x @ w1.T + c["ts"].float().double()[send_e] + c["tr"].float().double()[recv_e]
     else:
         e_b = fz.to_blocked_f16(packed[:, upos].float().to(dev))                                   # the prepared term, "pos" columns
         e_out = None
@@ -88,7 +89,7 @@ def test_edge_update_and_receiver_sum_vs_float64(has_fc1):
     agg2 = torch.full_like(agg, float("nan"))
     heads2 = torch.zeros_like(heads)
     ops.hip.gc_edge_update(e_b, e_out.clone() if has_fc1 else None, [t2, t2], [0, L], [2 * L, 2 * L], [send_d, recv_d], recv_d, w1f if has_fc1 else None, w2f,
-                           b2, gamma, beta, agg2, heads2, R)
+                           b2, gamma, beta, agg2, heads2, R, None, planes)
     ops.hip.gc_segment_fixup(agg2, heads2, i32(nodes), i32(first), i32(tiles))
     assert torch.equal(torch.nan_to_num(agg2), torch.nan_to_num(agg))
 
@@ -115,9 +116,28 @@ def test_node_mlp_vs_float64(n_src, rows):
     assert ((out[:rows].cpu().double() - want).abs().max() / want.abs().max()).item() < 3e-6
     # in place on the residual source, no residual
     ops.hip.gc_node_mlp(sd, [0] * n_src, [L] * n_src, w1f, w2f, *tab, sd[0], 0, L, sd[0], 0, L, rows)
-    plain = torch.empty(rows, L, device=dev)
     torch.cuda.synchronize()
     assert ((sd[0].cpu().double() - want).abs().max() / want.abs().max()).item() < 3e-6
+
+
+def test_hi_lo_split_is_consistent_for_every_element():
+    """Identity weights: the kernel's output is LayerNorm(swish(x)) through the hi/lo planes of x and of the hidden activation.  With a split
+    whose lo plane is not derived from the STORED hi plane (hipcc converts twice, with v_cvt_pk_f16_f32 and v_cvt_f16_f32, and the two disagree
+    for values within an fp32 ulp of an fp16 grid point) single elements come out one fp16 ulp off -- 17 of 2 M here before csrc/common.h:split8
+    made the hi plane opaque."""
+    from skyrim_amd import ops
+    gen = torch.Generator().manual_seed(21)
+    rows, dev = 4096, torch.device("cuda:0")
+    x = (3.0 * torch.randn(rows, L, generator=gen, dtype=torch.float64)).float()
+    eye, zero, one = torch.eye(L), torch.zeros(L), torch.ones(L)
+    w1f, w2f = fz.prep_w1_fragments(eye.to(dev)), fz.prep_w2_fragments(eye.to(dev))
+    out = torch.zeros(rows, L, device=dev)
+    ops.hip.gc_node_mlp([x.to(dev)], [0], [L], w1f, w2f, zero.to(dev), zero.to(dev), one.to(dev), zero.to(dev), None, 0, L, out, 0, L, rows)
+    torch.cuda.synchronize()
+    h = torch.nn.functional.silu(x.double())
+    mean, std = h.mean(1, keepdim=True), (h.var(1, unbiased=False, keepdim=True) + 1e-5).sqrt()
+    d = (out.cpu().double() * std + mean - h).abs()                       # LayerNorm undone with the exact statistics: per-element view
+    assert int((d > 2e-4).sum()) == 0 and d.max().item() < 3e-5
 
 
 def test_fused_engine_matches_the_round3_kernel_sequence(monkeypatch):

@@ -99,11 +99,11 @@ def emulate_edge_tile(tile, e_in_b, recv, idx, terms, w1f, w2f, b2, gamma, beta,
                 piece = tm[base[:, None] + np.arange(8)[None, :]]
                 hacc[0] += piece[:, :4]; hacc[1] += piece[:, 4:]
             if has_fc1:
-                for p in range(2 * KS):
-                    n, ks = p >> 4, p & 15
-                    blk = j * 64 + p * 2                            # chunk j = 64 KiB; pair p = (hi, lo) blocks
-                    w = frag(w1f, blk) + frag(w1f, blk + 1)
-                    hacc[n] = mfma(w, xh[ks], hacc[n])
+                for ks in range(KS):                                # a step = k-step ks against both 16-unit halves n
+                    for n in range(2):
+                        blk = j * 64 + (ks * 2 + n) * 2             # chunk j = 64 KiB of [ks][n][plane] blocks
+                        w = frag(w1f, blk) + frag(w1f, blk + 1)
+                        hacc[n] = mfma(w, xh[ks], hacc[n])
             hh[j][:, :4], hh[j][:, 4:] = swish(hacc[0]), swish(hacc[1])
         yacc = np.zeros((CF, 64, 4))
         for j in range(NCH):
@@ -128,34 +128,26 @@ def emulate_edge_tile(tile, e_in_b, recv, idx, terms, w1f, w2f, b2, gamma, beta,
                 for lane in range(64):
                     if my[lane] >= 0:
                         e_out_b[off[lane]:off[lane] + 8] = e_in_b[off[lane]:off[lane] + 8] + y[lane, bp]
-        # segmented inclusive scan over the 16 lanes of a DPP row
-        for d in (1, 2, 4, 8):
-            src = LANES - d
-            ok = (L15 >= d)
-            prev = np.where(ok, my[np.where(ok, src, 0)], -7)
-            m = ((my >= 0) & (prev == my)).astype(float)
-            shifted = np.where(ok[:, None, None], y[np.where(ok, src, 0)], 0.0)
-            y = y + shifted * m[:, None, None]
         y_groups.append(y); my_groups.append(my)
-    tails = [y_groups[u][15 + 16 * np.arange(4)] for u in range(8)]            # [g][bp][8] of row 15
-    tmeta = [my_groups[u][15] for u in range(8)]
-    prv0 = recv[tile0 - 1] if tile0 > 0 else -2
-    first = recv[tile0]
-    tile_cont = first >= 0 and prv0 == first
+    # receiver sums: the rows through LDS, one thread per column walks the 128 rows in order (two halves of 256 columns)
+    ybuf = np.zeros((128, L))
     for u in range(8):
-        y, my = y_groups[u], my_groups[u]
-        head = my[0]
-        up = u - 1
-        while up >= 0 and head >= 0 and tmeta[up] == head:
-            y = y + np.where((my == head)[:, None, None], tails[up][G], 0.0)
-            up -= 1
-        rows = tile0 + 16 * u + L15
-        nxt = np.where(16 * u + L15 + 1 < 128, recv[np.minimum(rows + 1, len(recv) - 1)], -3)
         for lane in range(64):
-            if my[lane] >= 0 and my[lane] != nxt[lane]:
-                dst = heads[tile] if (tile_cont and my[lane] == first) else agg[my[lane]]
-                for bp in range(16):
-                    dst[32 * bp + 8 * G[lane]:32 * bp + 8 * G[lane] + 8] = y[lane, bp]
+            for bp in range(16):
+                ybuf[16 * u + L15[lane], 32 * bp + 8 * G[lane]:32 * bp + 8 * G[lane] + 8] = y_groups[u][lane, bp]
+    rcv_l = np.r_[recv[tile0 - 1] if tile0 > 0 else -2, recv[tile0:tile0 + 128], -3]
+    first = rcv_l[1]
+    tile_cont = first >= 0 and rcv_l[0] == first
+    acc = np.zeros(L)
+    cur = first
+    for r in range(128):
+        acc = acc + ybuf[r]
+        nx = rcv_l[2 + r]
+        if nx != cur:
+            if cur >= 0:
+                (heads[tile] if (tile_cont and cur == first) else agg[cur])[:] = acc
+            acc = np.zeros(L)
+            cur = nx
 
 
 def _direct(e, recv_e, send_e, terms_nat, w1e, w2, b2, gamma, beta, n_nodes, static=None):
@@ -238,28 +230,38 @@ def _frag64(prep, w):
 
 
 def test_node_kernel_index_algebra():
-    """node_mlp_kernel, K = 1024 (two sources): stage (j, n) = 32 k-steps of 16 hidden units; epilogue rows are fp32 row-major."""
+    """node_mlp_kernel with two sources: source by source against W1 = [W1_0 | W1_1] (a chunk = 64 KiB of [ks][n][plane] blocks, two k-steps
+    per step with split accumulators), partial pre-activations carried between the sources; epilogue rows are fp32 row-major."""
     rng = np.random.default_rng(3)
     x = rng.normal(size=(16, 2 * L)); w1 = rng.normal(size=(L, 2 * L)) / np.sqrt(2 * L); w2 = rng.normal(size=(L, L)) / np.sqrt(L)
     b1, b2, gamma, beta = (rng.normal(size=L) * 0.1 for _ in range(4))
     w1f, w2f = _frag64(fz.prep_w1_fragments, w1), _frag64(fz.prep_w2_fragments, w2)
-    KS = 32
-    xh = np.stack([x[L15][np.arange(64)[:, None], 32 * ks + 8 * G[:, None] + np.arange(8)[None, :]] for ks in range(KS)])
+    part = np.zeros((16, 2, 64, 4))
+    for s in range(2):
+        xh = np.stack([x[L15][np.arange(64)[:, None], 512 * s + 32 * ks + 8 * G[:, None] + np.arange(8)[None, :]] for ks in range(16)])
+        for j in range(16):
+            acc = np.zeros((2, 2, 64, 4))                          # [n][parity of ks]
+            if s == 0:
+                acc[0][0] = b1[32 * j + 4 * G[:, None] + np.arange(4)[None, :]]
+                acc[1][0] = b1[32 * j + 16 + 4 * G[:, None] + np.arange(4)[None, :]]
+            else:
+                acc[0][0], acc[1][0] = part[j][0], part[j][1]
+            for q in range(8):
+                for kk in range(2):
+                    ks = 2 * q + kk
+                    for n in range(2):
+                        blk = (s * 16 + j) * 64 + q * 8 + (kk * 2 + n) * 2
+                        acc[n][kk] = mfma(frag(w1f, blk) + frag(w1f, blk + 1), xh[ks], acc[n][kk])
+            part[j][0], part[j][1] = acc[0][0] + acc[0][1], acc[1][0] + acc[1][1]
     hh = np.zeros((16, 64, 8))
-    for sidx in range(32):
-        j, n = sidx // 2, sidx & 1
-        if n == 0:
-            hacc = np.stack([b1[32 * j + 4 * G[:, None] + np.arange(4)[None, :]], b1[32 * j + 16 + 4 * G[:, None] + np.arange(4)[None, :]]])
-        for p in range(32):
-            blk = sidx * 64 + p * 2
-            hacc[n] = mfma(frag(w1f, blk) + frag(w1f, blk + 1), xh[p], hacc[n])
-        if n == 1:
-            hh[j][:, :4], hh[j][:, 4:] = swish(hacc[0]), swish(hacc[1])
+    for j in range(16):
+        hh[j][:, :4], hh[j][:, 4:] = swish(part[j][0]), swish(part[j][1])
     yacc = np.zeros((32, 64, 4))
     for j in range(16):
-        for c in range(32):
-            blk = j * 64 + c * 2
-            yacc[c] = mfma(frag(w2f, blk) + frag(w2f, blk + 1), hh[j], yacc[c])
+        for q in range(8):
+            for i in range(4):
+                blk = j * 64 + q * 8 + i * 2
+                yacc[4 * q + i] = mfma(frag(w2f, blk) + frag(w2f, blk + 1), hh[j], yacc[4 * q + i])
     z = swish(x @ w1.T + b1) @ w2.T
     got = np.zeros((16, L))
     for bp in range(16):

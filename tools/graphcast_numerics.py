@@ -16,6 +16,7 @@ Switches (comma list in GCNUM_PLAN, default = the shipped plan):
     node_hidden  node MLPs' hidden activation one fp16 plane
     embed_a      grid embedder's input features one fp16 plane (after normalisation)
     out_a        output MLP's operand / hidden one fp16 plane
+    edge_w1_16 / edge_w2_16   only W_e of the processor / only the second Linear of the edge MLPs as one fp16 plane
     edge_w16     weights of the edge MLPs' GEMMs (W_e of the processor, fc2 everywhere) one fp16 plane (ONE MFMA term with edge_store / edge_hidden)
 """
 import os
@@ -57,7 +58,7 @@ def forward(p, graph, x_prev, x_cur, forcing, plan):
         if vr is not None:
             pre = pre + rd("nodeterm16", F.linear(rd("nodeterm_a", vr), w1[:, 2 * L:]))[r_idx]
         h = rd("edge_hidden", F.silu(pre))
-        return ln(name, F.linear(h, rd("edge_w16", p[name + ".fc2.weight"]), p[name + ".fc2.bias"]))
+        return ln(name, F.linear(h, rd("edge_w16", rd("edge_w2_16", p[name + ".fc2.weight"])), p[name + ".fc2.bias"]))
 
     mean, std = p["norm.mean"][:, None, None], p["norm.std"][:, None, None]
     feats = torch.cat([(x_prev - mean) / std, (x_cur - mean) / std, forcing, p["static"]], dim=0).flatten(1).T
@@ -78,7 +79,7 @@ def forward(p, graph, x_prev, x_cur, forcing, plan):
     for i in range(O.processor_steps(p)):
         name = f"proc.{i}.edge"
         w1 = p[name + ".fc1.weight"]
-        de = edge_mlp(name, F.linear(em, rd("edge_w16", w1[:, :L]), p[name + ".fc1.bias"]), vm, me[:, 0], vm, me[:, 1])
+        de = edge_mlp(name, F.linear(em, rd("edge_w16", rd("edge_w1_16", w1[:, :L])), p[name + ".fc1.bias"]), vm, me[:, 0], vm, me[:, 1])
         vm = vm + mlp(f"proc.{i}.node", torch.cat([vm, agg(de, me[:, 1], graph.n_mesh)], dim=1), "node_a", "node_hidden")
         em = rd("edge_store", em + de)
     w1 = p["m2g.edge.fc1.weight"]
@@ -101,8 +102,9 @@ def main():
     chk = O.forward({k: v.float() for k, v in p.items()}, og, x0.float(), x1.float(), fk.float()).double()      # the oracle proper (fp32)
     print(f"grid {n_lat}x{n_lon} M{splits} latent {latent} steps {steps}; emulation with no switch vs oracle: {O.increment_rel_err(ref, chk, x1).max().item():.2e}")
     shipped = os.environ.get("GCNUM_PLAN", "edge_store,edge_hidden,static16")
-    every = ["edge_store", "edge_hidden", "static16", "nodeterm16", "nodeterm_a", "node_a", "node_hidden", "embed_a", "out_a", "edge_w16"]
-    for name, plan in [(k, {k}) for k in every] + [("shipped: " + shipped, set(shipped.split(","))), ("shipped + edge_w16", set(shipped.split(",")) | {"edge_w16"}), ("all", set(every))]:
+    every = [] if os.environ.get("GCNUM_ONLY") else ["edge_store", "edge_hidden", "static16", "nodeterm16", "nodeterm_a", "node_a", "node_hidden", "embed_a", "out_a", "edge_w16", "edge_w1_16", "edge_w2_16"]
+    extra = [(k, {k}) for k in os.environ.get("GCNUM_ONLY", "").split(",") if k]
+    for name, plan in extra + [(k, {k}) for k in every] + [("shipped: " + shipped, set(shipped.split(","))), ("shipped + edge_w16", set(shipped.split(",")) | {"edge_w16"}), ("all", set(every))]:
         y = forward(p, og, x0, x1, fk, plan)
         print(f"  {name:60s} increment {O.increment_rel_err(y, ref, x1).max().item():.2e}   per-channel {O.per_channel_rel_err(y, ref).max().item():.2e}", flush=True)
 
