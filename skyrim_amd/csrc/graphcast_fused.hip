@@ -131,11 +131,13 @@ __device__ __forceinline__ void fz_split8(const float (&v)[8], f16x8& hi, f16x8&
 // a[j] with a wave-uniform RUNTIME j: a uniform 16-way branch around a register copy, so that the chunk loops stay rolled (fully unrolled
 // they are ~200 KB of code against a 64 KB instruction cache: measured 1.6x slower in the MFMA loops) and the array stays in registers
 #define FZ_CASES(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15)
+// (the empty asm in every case keeps the cases apart: without it LLVM folds the switch back into a dynamically indexed array, which lives in
+// scratch memory)
 template <class V>
 __device__ __forceinline__ V fz_pick(const V (&a)[16], int j) {
     V r = a[0];
     switch (j) {
-#define X(i) case i: r = a[i]; break;
+#define X(i) case i: r = a[i]; asm volatile("" : "+v"(r)); break;
         FZ_CASES(X)
 #undef X
         default: break;
@@ -143,9 +145,9 @@ __device__ __forceinline__ V fz_pick(const V (&a)[16], int j) {
     return r;
 }
 template <class V>
-__device__ __forceinline__ void fz_put(V (&a)[16], int j, const V& v) {
+__device__ __forceinline__ void fz_put(V (&a)[16], int j, V v) {
     switch (j) {
-#define X(i) case i: a[i] = v; break;
+#define X(i) case i: asm volatile("" : "+v"(v)); a[i] = v; break;
         FZ_CASES(X)
 #undef X
         default: break;
@@ -264,14 +266,18 @@ edge_update_kernel(const EdgeArgs a) {
             for (int ks = 0; ks < KS; ++ks) xh[t][ks] = *reinterpret_cast<const v8*>(p + (ks << 9));
         }
         constexpr int NG = FM * (NT > 0 ? NT : 1) * 2;                 // gathered 16-byte pieces per lane and chunk
-        f32x4 gat[NG];
-        auto gather1 = [&](int j, int i) {                            // piece i = (t, s, half)
+        // two sets of gathered pieces: the requests of chunk j + 2 fly during chunk j + 1 (a gather out of the 168 MB node-term table takes
+        // ~2 us, longer than a chunk), so the chunk loop is unrolled by two and a chunk's top waits with vmcnt(NG), not vmcnt(0)
+        f32x4 gatA[NG], gatB[NG];
+        auto gather1 = [&](f32x4 (&gat)[NG], int j, int i) {          // piece i = (t, s, half)
             if (NT == 0 || i >= FM * NT * 2) return;
             const int t = i / (NT * 2), s = (i / 2) % (NT > 0 ? NT : 1), h = i & 1;
             gat[i] = *reinterpret_cast<const f32x4*>(tp[t][s] + 32 * j + 4 * h);
         };
 #pragma unroll
-        for (int i = 0; i < NG; ++i) gather1(0, i);
+        for (int i = 0; i < NG; ++i) gather1(gatA, 0, i);
+#pragma unroll
+        for (int i = 0; i < NG; ++i) gather1(gatB, 1, i);
         // consumed once here so that hipcc's vmcnt waits for these loads sit BEFORE the loop (inside it they would also wait for the
         // LDS-DMA in flight, which the compiler's counter bookkeeping does not know about; fused_mlp.hip)
 #pragma unroll
@@ -283,13 +289,17 @@ edge_update_kernel(const EdgeArgs a) {
         f32x4 hacc[FM][2];
 #pragma unroll
         for (int t = 0; t < FM; ++t) { hacc[t][0] = f32x4{0.f, 0.f, 0.f, 0.f}; hacc[t][1] = hacc[t][0]; }
-#pragma unroll 1
-        for (int j = 0; j < NCH; ++j) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            // the gathered terms of chunk j have landed with everything else: hand them to the compiler HERE, before the next requests
+        // one chunk; gat: the set holding chunk j's gathered pieces, refilled with chunk j + 2's
+        auto chunk = [&](int j, f32x4 (&gat)[NG]) {
+            // everything but the newest NG requests (the other set's, issued last in the previous chunk) has landed: W1(j) and this set
             if constexpr (NT > 0) {
+                if (j == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                else if constexpr (NG == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
 #pragma unroll
                 for (int i = 0; i < NG; ++i) asm volatile("" : "+v"(gat[i]));
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
             __syncthreads();                           // W1(j) landed in stage j & 1; every wave is done with the other stage
             // the MFMA-only arrays live in the accumulation half of the register file (MFMA reads its operands from there directly):
@@ -314,9 +324,11 @@ edge_update_kernel(const EdgeArgs a) {
             const bool more = j + 1 < NCH;
             const f16* nsrc = more ? a.w1f + (long long)(j + 1) * W1_CHUNK : a.w2f;      // chunk 15 reads stage 1: stage 0 is free for W2(0)
             const unsigned ndst = lds_base + (more ? ((j + 1) & 1) * FZ_STAGE : 0);
+            const int jg = j + 2 < NCH ? j + 2 : NCH - 1;                                 // past the end: chunk 15 again, dropped
             f16x8 done[FM];
-            // step ks: W1 rows 32 j + 16 n + [0, 16) for n = 0, 1 against k-step ks; between the MFMAs: one DMA piece of the next stage, one
-            // gathered piece of chunk j + 1, a quarter of the swish of chunk j - 1
+            // step ks: W1 rows 32 j + 16 n + [0, 16) for n = 0, 1 against k-step ks.  Between the MFMAs: the next stage's DMA pieces in the
+            // first half of the chunk, THEN chunk j + 2's gathers (so that they are the newest requests at the next top), and the swish of
+            // chunk j - 1
             fz_steps<KS, 2 * W1P, RD>(lrd + (j & 1) * FZ_STAGE, [&](int ks, const uint4 (&w)[2 * W1P]) {
                 if constexpr (W1P == 2) {
                     hacc[0][0] = fz_mfma(w[1], xh[0][ks], hacc[0][0]);
@@ -328,22 +340,30 @@ edge_update_kernel(const EdgeArgs a) {
                 hacc[1][0] = fz_mfma(w[0], xh[1][ks], hacc[1][0]);
                 hacc[0][1] = fz_mfma(w[W1P], xh[0][ks], hacc[0][1]);
                 hacc[1][1] = fz_mfma(w[W1P], xh[1][ks], hacc[1][1]);
-                // requests in the FIRST half of the chunk, so that they have landed when the next chunk's top waits for them
                 if (ks < 8) {
                     fz_piece(nsrc, ndst, ks, wave, lane);
                     if (W1P == 2 || !more) fz_piece(nsrc, ndst, 8 + ks, wave, lane);     // 16 pieces: two planes of W1, or W2(0)
-                    if (ks < NG) gather1(more ? j + 1 : j, ks);         // unconditional: a load inside a branch makes hipcc wait vmcnt(0) at the join
+                } else if (ks - 8 < NG) {
+                    gather1(gat, jg, ks - 8);          // unconditional: a load inside a branch makes hipcc wait vmcnt(0) at the join
                 }
-                if (ks == 8) swish4(pre[0][0]);
-                if (ks == 9) swish4(pre[0][1]);
-                if (ks == 10) swish4(pre[1][0]);
-                if (ks == 11) swish4(pre[1][1]);
-                if (ks == 12) done[0] = fz_pack8(pre[0][0], pre[0][1]);
-                if (ks == 13) done[1] = fz_pack8(pre[1][0], pre[1][1]);
+                if (ks == 2) swish4(pre[0][0]);
+                if (ks == 3) swish4(pre[0][1]);
+                if (ks == 4) swish4(pre[1][0]);
+                if (ks == 5) swish4(pre[1][1]);
+                if (ks == 6) done[0] = fz_pack8(pre[0][0], pre[0][1]);
+                if (ks == 7) done[1] = fz_pack8(pre[1][0], pre[1][1]);
             });
             fz_put(hh[0], j - 1, done[0]);
             fz_put(hh[1], j - 1, done[1]);
+        };
+#pragma unroll 1
+        for (int j = 0; j < NCH; j += 2) {
+            chunk(j, gatA);
+            chunk(j + 1, gatB);
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the last (dropped) gathers
+#pragma unroll
+        for (int i = 0; i < NG; ++i) { asm volatile("" : "+v"(gatA[i])); asm volatile("" : "+v"(gatB[i])); }
 #pragma unroll
         for (int t = 0; t < FM; ++t) { pre[t][0] = hacc[t][0]; pre[t][1] = hacc[t][1]; }
     }
@@ -392,13 +412,15 @@ edge_update_kernel(const EdgeArgs a) {
         // gathered node terms.  Its pieces are requested TWO chunks ahead (they fly during chunk j - 2), summed at the top of chunk j - 1
         // and go through swish between the MFMAs of chunk j - 1: the whole first phase hides under the second Linear.
         constexpr int NG = FM * (1 + 2 * NT);                           // pieces per lane and chunk: per row group one fp16 piece + 2 per term
-        f32x4 gat[NG];                                                  // (the fp16 piece is a 16-byte load as well)
-        auto piece = [&](int j, int i) {
+        // two sets, as in the first form: chunk j + 2's pieces are requested LAST in chunk j (after the DMA pieces), summed at the top of
+        // chunk j + 1 -- which waits with vmcnt(NG): everything but chunk j + 3's requests -- and go through swish during chunk j + 1
+        f32x4 gatA[NG], gatB[NG];                                       // (the fp16 piece is a 16-byte load as well)
+        auto piece = [&](f32x4 (&gat)[NG], int j, int i) {
             const int t = i / (1 + 2 * NT), k = i % (1 + 2 * NT);
             if (k == 0) gat[i] = *reinterpret_cast<const f32x4*>(a.e_in + ((((rb0 + t) * KS) + j) << 9) + l15 * 32 + g * 8);
             else gat[i] = *reinterpret_cast<const f32x4*>(tp[t][(k - 1) >> 1] + 32 * j + 4 * ((k - 1) & 1));
         };
-        auto sum_pre = [&]() {                                          // gat -> pre (frees gat for the next requests)
+        auto sum_pre = [&](const f32x4 (&gat)[NG]) {                    // gat -> pre (frees the set for the next requests)
 #pragma unroll
             for (int t = 0; t < FM; ++t) {
                 const f16x8 st = __builtin_bit_cast(f16x8, gat[t * (1 + 2 * NT)]);
@@ -408,42 +430,56 @@ edge_update_kernel(const EdgeArgs a) {
                 pre[t][0] = lo; pre[t][1] = hi;
             }
         };
+        static_assert(NG == 2 || NG == 6 || NG == 10, "vmcnt immediates below");
         f16x8 hc[FM], hn[FM];
 #pragma unroll
-        for (int i = 0; i < NG; ++i) piece(0, i);
-        sum_pre();
+        for (int i = 0; i < NG; ++i) piece(gatB, 0, i);
+        sum_pre(gatB);
 #pragma unroll
-        for (int i = 0; i < NG; ++i) piece(1, i);
+        for (int i = 0; i < NG; ++i) piece(gatA, 1, i);                 // chunk 1 -> set A, chunk 2 -> set B, ...
+#pragma unroll
+        for (int i = 0; i < NG; ++i) piece(gatB, 2, i);
 #pragma unroll
         for (int t = 0; t < FM; ++t) { swish4(pre[t][0]); swish4(pre[t][1]); hc[t] = fz_pack8(pre[t][0], pre[t][1]); hn[t] = hc[t]; }
-#pragma unroll 1
-        for (int j = 0; j < NCH; ++j) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // chunk j: MFMAs on hc = hidden activation of chunk j; `gat` holds chunk j + 1's pieces and is refilled with chunk j + 3's
+        auto chunk = [&](int j, f32x4 (&gat)[NG]) {
+            if constexpr (NG == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+            else if constexpr (NG == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
 #pragma unroll
             for (int i = 0; i < NG; ++i) asm volatile("" : "+v"(gat[i]));    // chunk j + 1's pieces have landed: to the compiler HERE
             __syncthreads();                           // W2(j) landed in stage j & 1; every wave is done with the other stage
-            sum_pre();                                 // pre = pre-activation of chunk j + 1 (past the end: chunk 15 again, dropped)
+            sum_pre(gat);                              // pre = pre-activation of chunk j + 1 (past the end: chunk 15 again, dropped)
             asm volatile("" ::: "memory");
             const bool more = j + 1 < NCH && j > 0;                       // W2(0) and W2(1) were requested up front
             const f16* nsrc = a.w2f + (long long)(j + 1) * (FZ_STAGE / 2);
             const unsigned ndst = lds_base + ((j + 1) & 1) * FZ_STAGE;
-            const int jn = j + 2 < NCH ? j + 2 : NCH - 1;
+            const int jn = j + 3 < NCH ? j + 3 : NCH - 1;
             fz_steps<CF / 2, 4, RD>(lrd + (j & 1) * FZ_STAGE, [&](int q, const uint4 (&w)[4]) {
                 fc2_step(q, w, hc[0], hc[1]);
                 if (q < 8) {
                     if (more) { fz_piece(nsrc, ndst, q, wave, lane); fz_piece(nsrc, ndst, 8 + q, wave, lane); }
-                    if (2 * q < NG) piece(jn, 2 * q);
-                    if (2 * q + 1 < NG) piece(jn, 2 * q + 1);
+                } else {
+                    if (2 * (q - 8) < NG) piece(gat, jn, 2 * (q - 8));
+                    if (2 * (q - 8) + 1 < NG) piece(gat, jn, 2 * (q - 8) + 1);
                 }
-                if (q == 8) swish4(pre[0][0]);
-                if (q == 9) swish4(pre[0][1]);
-                if (q == 10) swish4(pre[1][0]);
-                if (q == 11) swish4(pre[1][1]);
-                if (q == 12) hn[0] = fz_pack8(pre[0][0], pre[0][1]);
-                if (q == 13) hn[1] = fz_pack8(pre[1][0], pre[1][1]);
+                if (q == 2) swish4(pre[0][0]);
+                if (q == 3) swish4(pre[0][1]);
+                if (q == 4) swish4(pre[1][0]);
+                if (q == 5) swish4(pre[1][1]);
+                if (q == 6) hn[0] = fz_pack8(pre[0][0], pre[0][1]);
+                if (q == 7) hn[1] = fz_pack8(pre[1][0], pre[1][1]);
             });
             hc[0] = hn[0]; hc[1] = hn[1];
+        };
+#pragma unroll 1
+        for (int j = 0; j < NCH; j += 2) {
+            chunk(j, gatA);
+            chunk(j + 1, gatB);
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the last (dropped) requests
+#pragma unroll
+        for (int i = 0; i < NG; ++i) { asm volatile("" : "+v"(gatA[i])); asm volatile("" : "+v"(gatB[i])); }
     }
 
     // ---- epilogue: LayerNorm, residual update, receiver sum ---------------------------------------------------------------------- //
