@@ -86,17 +86,44 @@ def toy_parity(precision, rounding="default"):
     return {"grid": "49x192", "max_rel_err": O.per_channel_rel_err(y, O.forward(p, x)).max().item(), "bar": 1e-3, "rounding": eng.rounding}
 
 
-PROFILE_ROUND = "r03"
+PROFILE_ROUND = "r04"
+
+
+def lib_sha16(model: str) -> str | None:
+    """First 16 hex digits of sha256(skyrim_amd/lib/libskyrim_<model>.so) -- what tools/final_profiles.sh stamps its counter summaries with."""
+    import hashlib
+    f = ROOT / "skyrim_amd" / "lib" / f"libskyrim_{model}.so"
+    try:
+        return hashlib.sha256(f.read_bytes()).hexdigest()[:16]
+    except OSError:
+        return None
 
 
 def pmc_summary(model: str):
-    """profiles/r03_<model>_pmc.json (tools/pmc_collect.sh + tools/pmc_summary.py: rocprofv3 --pmc passes, FETCH_SIZE doubled per
-    MI355X_MICROARCH.md 'HBM'), or None.  A COMMITTED profile, not a measurement of this run."""
+    """profiles/<round>_<model>_pmc.json (tools/pmc_collect.sh + tools/pmc_summary.py: rocprofv3 --pmc passes, FETCH_SIZE doubled per
+    MI355X_MICROARCH.md 'HBM'), or None.  A COMMITTED profile, not a measurement of this run: it is only used when its stamp names the
+    library this process loads -- counters of another binary are dropped (``pmc_stale`` says so), never paired with fresh timings."""
     f = ROOT / "profiles" / f"{PROFILE_ROUND}_{model}_pmc.json"
     try:
-        return json.loads(f.read_text())
+        d = json.loads(f.read_text())
     except Exception:
         return None
+    if not str(d.get("stamp", "")).startswith(lib_sha16(model) or "?"):
+        return None
+    return d
+
+
+def pmc_stale(model: str):
+    """{'stale': True, ...} when a counter summary exists but was taken on another build of the library; None otherwise."""
+    f = ROOT / "profiles" / f"{PROFILE_ROUND}_{model}_pmc.json"
+    try:
+        stamp = str(json.loads(f.read_text()).get("stamp", ""))
+    except Exception:
+        return None
+    have = lib_sha16(model)
+    if have and stamp.startswith(have):
+        return None
+    return {"stale": True, "profiled_at": stamp, "library_sha16": have, "note": "counter summary dropped: it describes another build of the library"}
 
 
 def pmc_kernels(model: str, *needles: str):
@@ -106,7 +133,7 @@ def pmc_kernels(model: str, *needles: str):
     d = pmc_summary(model)
     src = f"profiles/{PROFILE_ROUND}_{model}_pmc.json"
     if not d:
-        return {"note": f"no committed counter summary ({src})"}
+        return pmc_stale(model) or {"note": f"no committed counter summary ({src})"}
     steps = d["total"]["steps"]
     rows = [e for k, e in d["kernels"].items() if all(n in k for n in needles)]
     if not rows:
@@ -401,7 +428,8 @@ def run_graphcast(args, rank, local_rank, world, dist):
     dom = max(stats, key=lambda s: s["total_ms"])
     achieved = dom["flops"] / (dom["total_ms"] * 1e-3)
     gpu_ms = sum(s["total_ms"] for s in stats) / args.steps
-    alg = alg_bytes_per_step(cfg, cfg.n_lat * cfg.n_lon, g.n_mesh, len(g.mesh_edges), len(g.g2m_edges) * (world if sharded else 1), 3 * cfg.n_lat * cfg.n_lon)
+    alg = alg_bytes_per_step(cfg, cfg.n_lat * cfg.n_lon, g.n_mesh, len(g.mesh_edges), len(g.g2m_edges) * (world if sharded else 1), 3 * cfg.n_lat * cfg.n_lon,
+                             edge_bytes=2 if eng.fused else None)
     dom_alg = alg.get(dom["name"], 0.0)
     dom_step_ms = dom["total_ms"] / args.steps
     out = {
@@ -412,28 +440,39 @@ def run_graphcast(args, rank, local_rank, world, dist):
         "config": {"workload": f"GraphCast (M{cfg.splits} multi-mesh: {g.n_mesh} nodes, {len(g.mesh_edges)} edges; {len(g.g2m_edges)} grid->mesh and "
                                f"{len(g.m2g_edges)} mesh->grid edges; latent {cfg.latent}, {cfg.steps} processor layers) 6-h autoregressive rollout, "
                                f"{cfg.n_lat}x{cfg.n_lon}x{cfg.n_vars} state, random-init weights (35.4 M), states resident in HBM, 1 member per GPU",
-                   "precision": "every Linear as a GEMM with fp16 hi/lo operands, 3 MFMA terms, fp32 accumulate; fp32 latents",
+                   "precision": ("node MLPs and node-term GEMMs: fp16 hi/lo operands, 3 MFMA terms, fp32 accumulate, fp32 node latents; edge MLPs: "
+                                 f"edge latents / hidden activations as ONE fp16 plane, second Linear with hi/lo weights (2 terms), W_e with {eng.w1_planes} "
+                                 "plane(s)") if eng.fused else "every Linear as a GEMM with fp16 hi/lo operands, 3 MFMA terms, fp32 accumulate; fp32 latents",
                    "parallelism": (f"one forecast over {world} GPUs: latitude bands of the grid + mesh-node ranges (owner computes); per step one "
                                    f"all-reduce of the ({g.n_mesh} x {cfg.latent}) grid->mesh aggregate and {cfg.steps} all-gathers of the node latents") if sharded else
                                   (f"member-parallel x{world}" if world > 1 else "single GPU"), "finite": finite},
-        # GraphCast at fp32 latents is bandwidth-limited (235 GB measured per step against 15 executed TFLOP): the roofline of the line is the HBM
-        # one, on ALGORITHMIC bytes (spec.alg_bytes_per_step: every tensor of the data flow once in, once out); the MFMA figures stay alongside
-        "roofline": {"bound": "hbm", "kernel": dom["name"] + " (gemm_strided_kernel + sum_linear_ln_kernel + gather_gemm_kernel + linear_ln_kernel)",
-                     "achieved": dom_alg / (dom_step_ms * 1e-3) / 1e9, "peak": PEAK_HBM / 1e9, "unit": "GB/s", "frac": dom_alg / (dom_step_ms * 1e-3) / PEAK_HBM,
-                     "alg_bytes_per_step_of_stage": dom_alg, "stage_ms_per_step": dom_step_ms,
-                     "traffic": pmc_kernels("graphcast", "ln_kernel").get("hbm_bytes_per_step"),
-                     "mfma": {"achieved_tflops": achieved / 1e12, "frac": achieved / PEAK_MFMA_BF16, "note": "executed FLOPs of the dominant stage"},
-                     "counters_linear_layer_norm_kernels": pmc_kernels("graphcast", "ln_kernel"),
-                     "hbm_GB_per_step_all_kernels": ((pmc_summary("graphcast") or {}).get("total") or {}).get("hbm_GB_per_step"),
-                     "avg_launch_ms": dom["total_ms"] / dom["launches"],
-                     "step": {"alg_tflop": f_step / 1e12, "gpu_ms": gpu_ms, "mfma_frac": f_step / (gpu_ms * 1e-3) / PEAK_MFMA_BF16,
-                              "executed_tflop": f_exec / 1e12, "alg_GB": alg["total"] / 1e9, "hbm_frac": alg["total"] / (gpu_ms * 1e-3) / PEAK_HBM,
-                              "alg_GB_per_stage": {k: round(v / 1e9, 2) for k, v in alg.items() if k != "total"},
-                              "note": "alg_tflop: the network as published (every edge MLP on the concatenated 1536-wide row); executed_tflop: the same "
-                                      "result with the first Linear of the edge MLPs taken apart by distributivity (what the kernels run)"},
-                     "stages": {s["name"]: {"ms_per_step": round(s["total_ms"] / args.steps, 3), "launches_per_step": s["launches"] // args.steps,
+        # The roofline of the line is the one the dominant stage sits closer to: HBM on ALGORITHMIC bytes (spec.alg_bytes_per_step: every tensor of
+        # the data flow once in, once out, at the engine's storage types) or the dense fp16 MFMA peak on the MFMA FLOPs the stage executes
+        # (dense FLOPs x terms).  The round-3 kernel sequence was bandwidth-limited (fp32 latents, 235-278 GB measured per step); the fused
+        # kernels keep the edge data on chip and are matrix-pipe / LDS-DMA limited
+        "roofline": dict(
+            ({"bound": "mfma", "achieved": dom["mfma_flops"] / (dom["total_ms"] * 1e-3) / 1e12, "peak": PEAK_MFMA_BF16 / 1e12, "unit": "TFLOP/s",
+              "frac": dom["mfma_flops"] / (dom["total_ms"] * 1e-3) / PEAK_MFMA_BF16}
+             if dom["mfma_flops"] / PEAK_MFMA_BF16 > dom_alg * args.steps / PEAK_HBM else
+             {"bound": "hbm", "achieved": dom_alg / (dom_step_ms * 1e-3) / 1e9, "peak": PEAK_HBM / 1e9, "unit": "GB/s", "frac": dom_alg / (dom_step_ms * 1e-3) / PEAK_HBM}),
+            **{"kernel": dom["name"] + (" (edge_update_kernel + node_mlp_kernel + gemm_strided_kernel_s)" if eng.fused else
+                                         " (gemm_strided_kernel + sum_linear_ln_kernel + gather_gemm_kernel + linear_ln_kernel)"),
+               "hbm": {"achieved_GBps": dom_alg / (dom_step_ms * 1e-3) / 1e9, "frac": dom_alg / (dom_step_ms * 1e-3) / PEAK_HBM},
+               "alg_bytes_per_step_of_stage": dom_alg, "stage_ms_per_step": dom_step_ms,
+               "traffic": pmc_kernels("graphcast", "edge_update_kernel" if eng.fused else "ln_kernel").get("hbm_bytes_per_step"),
+               "mfma": {"achieved_tflops": dom["mfma_flops"] / (dom["total_ms"] * 1e-3) / 1e12, "frac": dom["mfma_flops"] / (dom["total_ms"] * 1e-3) / PEAK_MFMA_BF16,
+                        "dense_tflops": achieved / 1e12, "note": "MFMA FLOPs the dominant stage executes (dense FLOPs x MFMA terms per product)"},
+               "counters_edge_kernels": pmc_kernels("graphcast", "edge_update_kernel" if eng.fused else "ln_kernel"),
+               "hbm_GB_per_step_all_kernels": ((pmc_summary("graphcast") or {}).get("total") or {}).get("hbm_GB_per_step"),
+               "avg_launch_ms": dom["total_ms"] / dom["launches"],
+               "step": {"alg_tflop": f_step / 1e12, "gpu_ms": gpu_ms, "mfma_frac": f_step / (gpu_ms * 1e-3) / PEAK_MFMA_BF16,
+                        "executed_tflop": f_exec / 1e12, "alg_GB": alg["total"] / 1e9, "hbm_frac": alg["total"] / (gpu_ms * 1e-3) / PEAK_HBM,
+                        "alg_GB_per_stage": {k: round(v / 1e9, 2) for k, v in alg.items() if k != "total"},
+                        "note": "alg_tflop: the network as published (every edge MLP on the concatenated 1536-wide row); executed_tflop: the same "
+                                "result with the first Linear of the edge MLPs taken apart by distributivity (what the kernels run)"},
+               "stages": {s["name"]: {"ms_per_step": round(s["total_ms"] / args.steps, 3), "launches_per_step": s["launches"] // args.steps,
                                             "dense_tflops": round(s["flops"] / (s["total_ms"] * 1e-3) / 1e12, 1),
-                                            "alg_GBps": round(alg.get(s["name"], 0.0) / (s["total_ms"] / args.steps * 1e-3) / 1e9, 1)} for s in stats}},
+                                            "alg_GBps": round(alg.get(s["name"], 0.0) / (s["total_ms"] / args.steps * 1e-3) / 1e9, 1)} for s in stats}}),
     }
     if world == 1 and not args.no_cpu_baseline:
         # bounded sample with one piece per cost class, each timed on the host cores and scaled by its own count (not by FLOPs alone:

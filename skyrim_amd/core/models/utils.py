@@ -43,13 +43,15 @@ class ResidentState:
 def run_basic_inference(model, n: int, data_source: Any, time: datetime, x=None):
     """Run a basic inference: returns DataArray(time = n + 1, channel, lat, lon); entry 0 is the state at ``time``."""
     counters = model.__dict__.setdefault("io_counters", {"state_uploads": 0, "resident_hits": 0}) if hasattr(model, "__dict__") else {}
+    resident = getattr(model, "_resident_state", None)
+    if hasattr(model, "__dict__"):
+        model._resident_state = None               # a run that raises must not leave a stale entry armed (it is set again on success)
     if x is None:
         x = get_initial_condition_for_model(model, data_source, time)     # comes with the batch dimension
         counters["state_uploads"] = counters.get("state_uploads", 0) + 1
     else:
         if isinstance(x, (str, os.PathLike)):
             x = open_dataarray(os.fspath(x))
-        resident = getattr(model, "_resident_state", None)
         dev = resident.tensor_for(x, model.n_history_levels) if resident is not None else None
         if dev is not None:
             x = dev                                                        # fed straight back: the states never left HBM
@@ -62,8 +64,17 @@ def run_basic_inference(model, n: int, data_source: Any, time: datetime, x=None)
     # The reference copies every yielded state to the host synchronously (`.cpu().numpy()`, utils.py:36): 286 MB per
     # step through pageable memory, the sync point of its loop.  Here the n + 1 states land in ONE pinned host buffer
     # through a copy stream, so the D2H of step k overlaps the forward of step k + 1; the result is the same array.
-    times, stacked, arrays, side, last = [], None, [], None, []
     loop = model(time, x)
+    try:
+        return _drain(model, loop, n, time)
+    finally:
+        if hasattr(loop, "close"):
+            loop.close()        # lets the TimeLoop flush its deferred checks (FiniteGuard: the last yielded state) -- may raise; also runs
+                                # when the loop body itself raised, so that a generator is never left to the garbage collector
+
+
+def _drain(model, loop, n: int, time):
+    times, stacked, arrays, side, last = [], None, [], None, []
     for k, (time, output, _) in enumerate(loop):
         out = output.squeeze(0) if output.dim() == 4 and output.shape[0] == 1 else output
         if out.is_cuda:
@@ -82,7 +93,7 @@ def run_basic_inference(model, n: int, data_source: Any, time: datetime, x=None)
         if k == n:
             break
     if hasattr(loop, "close"):
-        loop.close()            # lets the TimeLoop flush its deferred checks (FiniteGuard: the last yielded state) -- may raise
+        loop.close()            # flush BEFORE the result is built: a non-finite last state must not be delivered
     if stacked is not None:
         side.synchronize()
         stacked = stacked[:len(times)].numpy()

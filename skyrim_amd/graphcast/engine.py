@@ -144,22 +144,24 @@ class GraphcastEngine:
         return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     # ---- profiling (same contract as SfnoEngine) ---------------------------------------------------- #
-    def _mark(self, label: str, flops: float = 0.0):
+    def _mark(self, label: str, flops: float = 0.0, terms: float = 3.0):
+        """flops: dense FLOPs of the launch that follows; terms: MFMA terms it executes per product (3 = fp16 hi/lo on both operands)."""
         if self.profiling:
             ev = torch.cuda.Event(enable_timing=True)
             ev.record(torch.cuda.current_stream(self.device))
-            self._events.append((label, ev, flops))
+            self._events.append((label, ev, flops, flops * terms))
 
     def profile_read(self) -> list[dict]:
         torch.cuda.synchronize(self.device)
         out: dict[str, dict] = {}
-        for (label, ev, fl), (_, nxt, _) in zip(self._events[:-1], self._events[1:]):
+        for (label, ev, fl, mf), (_, nxt, _, _) in zip(self._events[:-1], self._events[1:]):
             if label == "end":
                 continue
-            d = out.setdefault(label, dict(name=label, launches=0, total_ms=0.0, flops=0.0))
+            d = out.setdefault(label, dict(name=label, launches=0, total_ms=0.0, flops=0.0, mfma_flops=0.0))
             d["launches"] += 1
             d["total_ms"] += ev.elapsed_time(nxt)
             d["flops"] += fl
+            d["mfma_flops"] += mf
         self._events = []
         return list(out.values())
 
@@ -235,7 +237,8 @@ class GraphcastEngine:
     def _edge_update(self, f, e_in, e_out, terms, agg, label):
         """f: a prepared edge set (``_prepare_fused``); terms: [(tensor, element offset, ld, index tensor)]."""
         L = self.cfg.latent
-        self._mark(label, 2.0 * f["n_edges"] * L * L * (2 if f.get("w1f") is not None else 1))
+        fc1 = f.get("w1f") is not None
+        self._mark(label, 2.0 * f["n_edges"] * L * L * (2 if fc1 else 1), (2.0 + self.w1_planes) / 2.0 if fc1 else 2.0)
         ops.hip.gc_edge_update(e_in, e_out, [t for t, _, _, _ in terms], [o for _, o, _, _ in terms], [d for _, _, d, _ in terms], [i for _, _, _, i in terms],
                                f["recv"], f.get("w1f"), f["w2f"], f["b2"], f["g"], f["b"], agg, f.get("heads"), f["rows"], None, self.w1_planes)
         if f.get("fix") is not None:

@@ -131,7 +131,7 @@ def flops_per_step(cfg: GraphcastConfig, n_grid: int, n_mesh: int, e_mesh: int, 
     return f
 
 
-def alg_bytes_per_step(cfg: GraphcastConfig, n_grid: int, n_mesh: int, e_mesh: int, e_g2m: int, e_m2g: int, latent_bytes: int = 4) -> dict:
+def alg_bytes_per_step(cfg: GraphcastConfig, n_grid: int, n_mesh: int, e_mesh: int, e_g2m: int, e_m2g: int, latent_bytes: int = 4, edge_bytes: int | None = None) -> dict:
     """ALGORITHMIC HBM bytes of one step, per stage: every tensor of the network's data flow read once where it is consumed and written
     once where it is produced, at the engine's storage type (fp32 latents: ``latent_bytes`` = 4), with nothing materialised that the
     model does not define -- no concatenated edge rows, no hidden activations, no edge latents of the encoder / decoder beyond their
@@ -139,15 +139,16 @@ def alg_bytes_per_step(cfg: GraphcastConfig, n_grid: int, n_mesh: int, e_mesh: i
     L2-resident and not counted.  This is the floor the measured traffic (rocprofv3 FETCH_SIZE + WRITE_SIZE) is held against."""
     L, V = cfg.latent, cfg.n_vars
     row = L * latent_bytes
+    erow = L * (edge_bytes or latent_bytes)            # the fused engine keeps edge latents / prepared edge terms as ONE fp16 plane (edge_bytes = 2)
     grid, mesh = n_grid * row, n_mesh * row
     st = {
         "embed": n_grid * cfg.grid_in * 4 + grid,                                      # features in, grid latents out
         # grid->mesh: prepared edge terms + sender latents in, mesh aggregate out; mesh-node update (v_m0, agg in, v_m out); grid-node update in place
-        "encoder": e_g2m * row + grid + mesh + 3 * mesh + 2 * grid,
+        "encoder": e_g2m * erow + grid + mesh + 3 * mesh + 2 * grid,
         # per layer: edge latents read + written (residual update), node latents read + written, aggregate out + in
-        "processor": cfg.steps * (2 * e_mesh * row + 4 * mesh),
+        "processor": cfg.steps * (2 * e_mesh * erow + 4 * mesh),
         # mesh->grid: prepared edge terms + mesh and grid latents in, grid aggregate out; grid-node update (v_g, agg in, v_g out)
-        "decoder": e_m2g * row + mesh + grid + grid + 3 * grid,
+        "decoder": e_m2g * erow + mesh + grid + grid + 3 * grid,
         "output": grid + 2 * n_grid * V * 4,                                           # latents in, x(t) in, x(t + 6 h) out
     }
     st["total"] = float(sum(st.values()))

@@ -62,11 +62,44 @@ def _parallel_payload_write(path, offset: int, payload: np.ndarray, threads: int
 def write_dataarray_netcdf3(da, path, fast_threshold: int | None = None):
     """``fast_threshold`` (bytes, default FAST_PAYLOAD_BYTES): float32 payloads at least this large are written by
     ``_parallel_payload_write`` into the hole scipy's writer leaves for them -- header, offsets and coordinate variables are scipy's own, the
-    payload bytes are the same big-endian values: the file is byte-identical to the plain path (tests/test_ncio.py)."""
-    from scipy.io import netcdf_file
+    payload bytes are the same big-endian values: the file is byte-identical to the plain path (tests/test_ncio.py).
+
+    The fast path leans on scipy internals (``_write_var_data``, ``_begin``, ``_pack_begin``, ``_vsize``): it writes to ``<path>.part`` and
+    renames on success; if those internals are gone (AttributeError / a size that does not add up) the partial file is removed and scipy's
+    plain writer takes over; an I/O error (ENOSPC ...) removes the partial file and is raised -- never a valid header over a garbage payload."""
     payload0 = da.values
     thr = FAST_PAYLOAD_BYTES if fast_threshold is None else fast_threshold
     fast = payload0.dtype == np.float32 and payload0.flags.c_contiguous and payload0.nbytes >= thr
+    if fast:
+        import os
+        part = f"{os.fspath(path)}.part"
+        try:
+            _write_netcdf3(da, part, True)
+            os.replace(part, os.fspath(path))
+            return
+        except (AttributeError, _FastPathMismatch):
+            _unlink(part)                                  # scipy changed underneath: the plain writer below
+        except BaseException:
+            _unlink(part)
+            raise
+    _write_netcdf3(da, path, False)
+
+
+class _FastPathMismatch(RuntimeError):
+    pass
+
+
+def _unlink(p):
+    import os
+    try:
+        os.unlink(p)
+    except OSError:
+        pass
+
+
+def _write_netcdf3(da, path, fast: bool):
+    from scipy.io import netcdf_file
+    payload0 = da.values
     pname = da.name or UNNAMED
     hole = {}
 
@@ -114,7 +147,8 @@ def write_dataarray_netcdf3(da, path, fast_threshold: int | None = None):
         if coord_names:
             v.coordinates = coord_names
     if fast:
-        assert hole["vsize"] == payload0.nbytes, (hole, payload0.nbytes)
+        if hole.get("vsize") != payload0.nbytes:
+            raise _FastPathMismatch(f"payload hole {hole} does not match {payload0.nbytes} bytes")
         _parallel_payload_write(path, hole["begin"], payload0)
 
 

@@ -37,7 +37,13 @@ PRECISIONS = {"bf16x3": PREC_BF16X3, "f16": PREC_F16, "bf16x3h": PREC_BF16X3_H16
 # ONE term, the activation operands as their fp16 hi plane) is f16x2m with the coarse layers 2 / 3 at half the MFMAs again; it wants
 # rounding="compensated" (pangu/calibration.py fits the weights to the rounded operands): oracle emulation 1.3e-4 against 6.5e-5.
 DEFAULT_PRECISION = "f16x2m"
-DEFAULT_ROUNDING = "nearest"       # of the one-plane weights (PanguEngine.load_params); "compensated": pangu/calibration.py
+# Rounding of the one-plane weights (PanguEngine.load_params).  "compensated" (pangu/calibration.py: error feedback against the operand
+# statistics of the calibration state and of its own forecast) is the default since round 4: a load-time choice, the kernels and the step time
+# are the same, and at 721x1440 the default plan's error over the 24-h rollout is 1.4 / 1.7 / 1.6 / 1.7e-4 instead of 4.2 / 5.9 / 5.8 / 5.4e-4
+# with "nearest" (three terms everywhere: 1.0 / 1.2 / 1.2 / 1.2e-4) -- the margin the two-term plan gave away.  With 1 % of the weight rows
+# scaled x5 it holds 9e-5 (nearest: 2.8e-4); x30 on every Linear class at once breaks EVERY mode, three-term and bf16x3 included, at ~1e-2
+# (tools/pangu_outlier_scan.py: the attention's one-plane fp16 operands, not the term plan).
+DEFAULT_ROUNDING = "compensated"
 
 _LIB_PATH = Path(__file__).resolve().parent.parent / "lib" / "libskyrim_pangu.so"
 

@@ -49,6 +49,26 @@ def _load_weights(path: str, geom: PanguGeometry) -> dict:
     return torch.load(path, map_location="cpu")
 
 
+def _load_state(path: str, geom: PanguGeometry) -> torch.Tensor:
+    """A (69, n_lat, n_lon) calibration state from a file: torch ``.pt``, numpy ``.npy`` or a netCDF forecast file (its last time level)."""
+    if not os.path.exists(path):
+        raise ValueError(f"calibration = {path!r}: 'synthetic', 'first', 'off' or the path of a state file")
+    if path.endswith(".npy"):
+        import numpy as np
+        t = torch.from_numpy(np.load(path))
+    elif path.endswith(".nc"):
+        from ..labeled import open_dataarray
+        t = torch.from_numpy(open_dataarray(path).values)
+    else:
+        t = torch.load(path, map_location="cpu")
+    t = t.float()
+    while t.dim() > 3:
+        t = t[-1]
+    if tuple(t.shape) != (geom.n_channels, geom.n_lat, geom.n_lon):
+        raise ValueError(f"calibration state {path!r}: expected {(geom.n_channels, geom.n_lat, geom.n_lon)}, got {tuple(t.shape)}")
+    return t.contiguous()
+
+
 class PanguTimeLoop:
     n_history_levels = 1
     time_step = datetime.timedelta(hours=6)
@@ -66,18 +86,19 @@ class PanguTimeLoop:
         # ``conventions``: the points the public pseudocode leaves open and a real pangu_weather_6.onnx settles -- roll_sign, mask_value,
         # surface, qkv_order, bias_index (PanguEngine); padding placement is ``geom.pad``
         # ``calibration``: the state a term plan's biases are calibrated on (PanguEngine.load_params / calibrate): "synthetic" (the
-        # built-in state from the weights' own normalisation constants), "first" (the first initial condition this loop is called
-        # with -- a real analysis when the weights are real), "off", or a (69, n_lat, n_lon) state.  The fitted biases belong to the
-        # activation statistics of the calibration state (a block fed a very different distribution is worse off than uncalibrated,
-        # tests/test_pangu_gpu.py test_earth_specific_block), so the default is "first" for weights loaded from a file and
-        # "synthetic" for seeded random weights, whose forecasts start from synthetic states; SKYRIM_PANGU_CALIBRATION overrides.
+        # built-in state from the weights' own normalisation constants: the DEFAULT, whatever the weights' source -- a set of weights is
+        # always prepared the same way, so the same initial condition gives the same bits in every process), a (69, n_lat, n_lon) state,
+        # a PATH to one (``.pt`` / ``.npy`` tensor or a saved forecast ``.nc``: its last time level -- e.g. a climatological analysis),
+        # "off", or "first" (opt-in: the first initial condition this loop is called with; forecasts then depend on what the process saw
+        # first).  SKYRIM_PANGU_CALIBRATION overrides the default with any of these.
         self.geom = geom or PanguGeometry()
         if calibration is None:
-            from_file = params is None and bool(os.environ.get("SKYRIM_PANGU_WEIGHTS"))
-            calibration = os.environ.get("SKYRIM_PANGU_CALIBRATION", "first" if from_file else "synthetic")
+            calibration = os.environ.get("SKYRIM_PANGU_CALIBRATION", "synthetic")
         self._calibrate_on_first = isinstance(calibration, str) and calibration == "first"
         if self._calibrate_on_first:
             calibration = "off"
+        elif isinstance(calibration, str) and calibration not in ("synthetic", "off"):
+            calibration = _load_state(calibration, self.geom)
         conventions = dict(conventions or {})
         self.engine = PanguEngine(self.geom, precision, device, **conventions)
         if params is None:
@@ -124,7 +145,9 @@ class PanguTimeLoop:
                 time = time + self.time_step
                 guard.push(state, k)
                 yield time, state.unsqueeze(0), restart
-        finally:
+        except GeneratorExit:
             # the consumer stopped (run_basic_inference breaks at k == n and closes the generator): the flag of the LAST yielded
-            # step is still pending -- with n = 1 (predict_one_step / rollout) it is the only one there ever is
+            # step is still pending -- with n = 1 (predict_one_step / rollout) it is the only one there ever is.  Only on a clean
+            # close: when step() itself raised, a device sync here could mask that error.
             guard.check()
+            raise

@@ -4,6 +4,7 @@ import datetime
 import filecmp
 
 import numpy as np
+import pytest
 
 from skyrim_amd import ncio
 from skyrim_amd.labeled import DataArray, open_dataarray
@@ -49,3 +50,31 @@ def test_non_float32_and_small_payloads_take_the_plain_path(tmp_path):
     assert np.array_equal(open_dataarray(str(tmp_path / "f64.nc")).values, da64.values)
     ncio.write_dataarray_netcdf3(da, tmp_path / "small.nc")                      # below FAST_PAYLOAD_BYTES
     assert np.array_equal(open_dataarray(str(tmp_path / "small.nc")).values, da.values)
+
+
+def test_fast_path_failures_never_leave_a_half_written_file(tmp_path, monkeypatch):
+    """The fast payload path writes to <path>.part and renames: if scipy's internals are gone it falls back to the plain writer (same bytes);
+    an I/O error removes the partial file and propagates."""
+    from skyrim_amd import ncio
+    from skyrim_amd.labeled import DataArray
+    vals = np.arange(2 * 3 * 4 * 5, dtype=np.float32).reshape(2, 3, 4, 5)
+    da = DataArray(vals, dims=["time", "channel", "lat", "lon"],
+                   coords=dict(time=np.array(["2024-01-01T00", "2024-01-01T06"], dtype="datetime64[ns]"), channel=["a", "b", "c"],
+                               lat=np.linspace(90, -90, 4), lon=np.arange(5.0)))
+    plain, fast, fallback = tmp_path / "plain.nc", tmp_path / "fast.nc", tmp_path / "fallback.nc"
+    ncio.write_dataarray_netcdf3(da, plain, fast_threshold=1 << 40)
+    ncio.write_dataarray_netcdf3(da, fast, fast_threshold=0)
+    assert plain.read_bytes() == fast.read_bytes() and not (tmp_path / "fast.nc.part").exists()
+
+    def gone(*a, **k):
+        raise AttributeError("scipy changed")
+    monkeypatch.setattr(ncio, "_parallel_payload_write", gone)
+    ncio.write_dataarray_netcdf3(da, fallback, fast_threshold=0)
+    assert fallback.read_bytes() == plain.read_bytes() and not (tmp_path / "fallback.nc.part").exists()
+
+    def full(*a, **k):
+        raise OSError(28, "No space left on device")
+    monkeypatch.setattr(ncio, "_parallel_payload_write", full)
+    with pytest.raises(OSError):
+        ncio.write_dataarray_netcdf3(da, tmp_path / "enospc.nc", fast_threshold=0)
+    assert not (tmp_path / "enospc.nc").exists() and not (tmp_path / "enospc.nc.part").exists()

@@ -24,8 +24,10 @@ from skyrim_amd.pangu.spec import PanguGeometry, init_synthetic, synthetic_state
 pytestmark = pytest.mark.gpu
 
 STAGE_TOL = {"f16x2m": 1.5e-3, "f16x2c": 1.5e-3, "f16x2q": 1.5e-3, "f16x2": 1.5e-3, "bf16x3": 5e-4, "f16x3": 5e-4, "f16x3q": 5e-4, "bf16x3h": 2e-3, "f16x3qh": 2e-3, "f16": 4e-3}
-DEF_TOL = 7e-4       # the default mode's asserted step error (STEP_TOL[DEFAULT_PRECISION]); measured at 721x1440: 4.2e-4 (1 step) .. 5.9e-4 (4 steps)
-STEP_TOL = {"f16x2m": 7e-4, "f16x2c": 7e-4, "f16x2q": 1e-3, "f16x2": 1e-3, "bf16x3": 3e-4, "f16x3": 3e-4, "f16x3q": 3e-4, "bf16x3h": 1e-3, "f16x3qh": 1e-3, "f16": 5e-3}   # 3-term modes: 3x inside the bar
+# the default mode's asserted step error (STEP_TOL[DEFAULT_PRECISION]): the two-term plan with compensated rounding (the default since round 4),
+# measured at 721x1440 at 1.4e-4 (1 step) .. 1.7e-4 (4 steps) -- 3x inside the bar, where nearest rounding (4.2 .. 5.9e-4) needed 7e-4
+DEF_TOL = 3e-4
+STEP_TOL = {"f16x2m": 3e-4, "f16x2c": 3e-4, "f16x2q": 1e-3, "f16x2": 1e-3, "bf16x3": 3e-4, "f16x3": 3e-4, "f16x3q": 3e-4, "bf16x3h": 1e-3, "f16x3qh": 1e-3, "f16": 5e-3}   # 3-term modes: 3x inside the bar
 
 
 def rel(a, b):
@@ -234,11 +236,13 @@ def test_full_size_term_plans_vs_oracle(full, full_ref):
     from skyrim_amd.pangu.engine import PanguEngine
     g, params, x, _ = full
     import os
-    plans = [(0x6F, "synthetic", "nearest"), (0x6F, "off", "nearest"), (0xFF, "synthetic", "nearest"), (0xFF, "off", "nearest"), (0x0F, "synthetic", "nearest"),
-             (0x66, "synthetic", "nearest"), (0x66, "off", "nearest"), (0x00, "off", "nearest")]
-    if os.environ.get("SKYRIM_TEST_ALL_PLANS"):             # the opt-in load-time rounding and the one-term plan (13 s of calibration each)
-        plans += [(0x6F, "synthetic", "compensated"), (0xFF, "synthetic", "compensated"), (0x66F, "synthetic", "compensated"), (0x66F, "synthetic", "nearest")]
-    for plan, cal, rounding in plans:
+    # (plan, calibration, rounding, asserted bound at EVERY step): the default (two-term plan, compensated rounding) 3x inside the bar; the same
+    # plan with nearest rounding (round 3's default) and the one-term coarse layers ("f16x1m", compensated) inside the bar; three terms everywhere
+    plans = [(0x6F, "synthetic", "compensated", 3e-4), (0x6F, "synthetic", "nearest", 1e-3), (0x66F, "synthetic", "compensated", 1e-3), (0x00, "off", "nearest", 3e-4)]
+    if os.environ.get("SKYRIM_TEST_ALL_PLANS"):             # the rest of the table of DESIGN.md 3 (13 s of calibration per compensated plan)
+        plans += [(0x6F, "off", "nearest", 1e-3), (0xFF, "synthetic", "nearest", 1e-3), (0xFF, "off", "nearest", 1e-3), (0x0F, "synthetic", "nearest", 1e-3),
+                  (0x66, "synthetic", "nearest", 1e-3), (0x66, "off", "nearest", 1e-3), (0xFF, "synthetic", "compensated", 1e-3), (0x66F, "synthetic", "nearest", 1e-3)]
+    for plan, cal, rounding, bound in plans:
         e = PanguEngine(g, "f16x3q", "cuda:0", term_plan=plan)
         e.load_params(params, calibration=cal, rounding=rounding)
         state = x.cuda().clone()
@@ -247,7 +251,7 @@ def test_full_size_term_plans_vs_oracle(full, full_ref):
             e.step(state, out=state)
             errs.append(O.per_channel_rel_err(state.cpu(), full_ref[k]).max().item())
         print(f"full-size term plan {plan:#04x} calibration {cal} rounding {rounding}: max per-channel rel err per step " + " ".join(f"{v:.3e}" for v in errs))
-        assert max(errs) < 1e-3, (hex(plan), cal, rounding, errs)
+        assert max(errs) < bound, (hex(plan), cal, rounding, errs)
         del e
         torch.cuda.empty_cache()
 
@@ -628,8 +632,9 @@ def test_one_term_block_gemms_in_the_coarse_layers(toy, ref):
 
 
 def test_time_loop_calibrates_on_the_first_initial_condition(toy, ref):
-    """PanguTimeLoop(calibration="first") -- the default for weights loaded from a file: the biases are fitted on the first state the loop
-    is called with, once; later calls reuse them."""
+    """PanguTimeLoop(calibration="first") -- OPT-IN: the biases are fitted on the first state the loop is called with, once; later calls
+    reuse them.  The default is "synthetic" whatever the weights' source (deterministic: same initial condition, same bits, in every
+    process); a state file can be named instead (``calibration=<path>`` / SKYRIM_PANGU_CALIBRATION)."""
     import datetime
     from skyrim_amd.pangu.timeloop import PanguTimeLoop
     g, params, x = toy
@@ -653,6 +658,94 @@ def test_time_loop_calibrates_on_the_first_initial_condition(toy, ref):
     assert torch.equal(y2, y)
     off = PanguTimeLoop(params, g, calibration="off")
     assert off.engine.calibrated_on is None and PanguTimeLoop(params, g).engine.calibrated_on == "synthetic"
+
+
+def test_calibration_is_deterministic_and_can_name_a_state_file(toy, tmp_path, monkeypatch):
+    """Two fresh loops that saw DIFFERENT first initial conditions give the same bits for the same initial condition (default
+    calibration: the synthetic state); a named state file calibrates on that state, the same in every process."""
+    import datetime
+    from skyrim_amd.pangu.timeloop import PanguTimeLoop
+    g, params, x = toy
+    t0 = datetime.datetime(2024, 1, 1)
+
+    def forecast(loop, state):
+        it = loop(t0, state[None, None].cuda())
+        next(it)
+        _, y, _ = next(it)
+        it.close()
+        return y
+
+    a, b = PanguTimeLoop(params, g), PanguTimeLoop(params, g)
+    forecast(a, synthetic_state(g, 5))                                   # a has seen another state first
+    assert torch.equal(forecast(a, x), forecast(b, x))
+    path = tmp_path / "analysis.pt"
+    torch.save(synthetic_state(g, 7), path)
+    monkeypatch.setenv("SKYRIM_PANGU_CALIBRATION", str(path))
+    c, d = PanguTimeLoop(params, g), PanguTimeLoop(params, g)
+    assert c.engine.calibrated_on == "state"
+    forecast(c, synthetic_state(g, 5))
+    assert torch.equal(forecast(c, x), forecast(d, x))
+    with pytest.raises(ValueError):
+        PanguTimeLoop(params, g, calibration=str(tmp_path / "missing.pt"))
+
+
+def _outlier_params(params, seed=3, frac=0.01, scale=30.0):
+    """Trained-weight-like stress: 1 % of the rows of every Linear weight (2-d parameters but the bias tables) scaled x30 -- heavy-tailed rows the
+    1/sqrt(fan_in) random init never has (their W - fp16(W) residue and their activations are what the one-plane plans lean on)."""
+    gen = torch.Generator().manual_seed(seed)
+    out = {}
+    for k, v in params.items():
+        if v.dim() == 2 and k.endswith(".weight") and "bias_table" not in k and "norm" not in k:
+            v = v.clone()
+            rows = torch.randperm(v.shape[0], generator=gen)[:max(1, int(frac * v.shape[0]))]
+            v[rows] *= scale
+        out[k] = v
+    return out
+
+
+def test_outlier_weights_and_states_stay_inside_the_bar_or_trip_the_guard(toy):
+    """The default mode under outliers.  (1) 1 % of the rows of every Linear weight x5: the default-mode assertion holds (measured 9e-5; nearest
+    rounding 2.8e-4).  (2) the same x30: NO mode survives that on every Linear class at once -- three terms everywhere and bf16x3 sit at ~1e-2
+    like the default, while each class alone stays below 3e-4 (tools/pangu_outlier_scan.py) -- so what is asserted is that the default's term plan
+    is not the weak link: within 2x of the three-term engine on the same tensors.  (3) two channels of the state pushed out by 1e4 sigma: inside
+    the bar, or the forecast is REFUSED -- non-finite output (fp16 planes end at 65504) raises FloatingPointError from the time loop."""
+    import datetime
+    from skyrim_amd.pangu.engine import PanguEngine
+    from skyrim_amd.pangu.timeloop import PanguTimeLoop
+    g, params, x = toy
+
+    def run(p, state, **kw):
+        e = PanguEngine(g, device="cuda:0", **kw)
+        e.load_params(p)
+        return e.step(state.cuda()).cpu()
+
+    mild = _outlier_params(params, scale=5.0)
+    err = O.per_channel_rel_err(run(mild, x), O.forward(mild, x)).max().item()
+    print(f"outlier stress (1 % of the weight rows x5): max per-channel rel err {err:.3e} ({DEFAULT_PRECISION})")
+    assert err < DEF_TOL, err
+    heavy = _outlier_params(params, scale=30.0)
+    ref = O.forward(heavy, x)
+    e_def = O.per_channel_rel_err(run(heavy, x), ref).max().item()
+    e_3t = O.per_channel_rel_err(run(heavy, x, precision="f16x3q", term_plan=0), ref).max().item()
+    print(f"outlier stress (1 % of the weight rows x30): default {e_def:.3e}, three terms everywhere {e_3t:.3e}")
+    assert e_def < 2.0 * e_3t + 1e-3, (e_def, e_3t)
+    mean, std = params["norm.mean"], params["norm.std"]
+    wild = x.clone()
+    for c in (3, 40):
+        wild[c] = mean[c] + 1e4 * (x[c] - mean[c])
+    y = run(mild, wild)
+    if torch.isfinite(y).all():
+        err = O.per_channel_rel_err(y, O.forward(mild, wild)).max().item()
+        print(f"outlier stress (x5 rows + two channels at 1e4 sigma): max per-channel rel err {err:.3e}")
+        assert err < 1e-3, err
+    else:
+        loop = PanguTimeLoop(mild, g)
+        it = loop(datetime.datetime(2024, 1, 1), wild[None, None].cuda())
+        next(it)
+        with pytest.raises(FloatingPointError):
+            next(it)
+            it.close()
+        print("outlier stress (x5 rows + two channels at 1e4 sigma): non-finite state refused by the FiniteGuard")
 
 
 def test_step_as_a_captured_hip_graph(toy):

@@ -6,7 +6,7 @@
 set -u
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
-R=${PROFILE_ROUND:-r03}
+R=${PROFILE_ROUND:-r04}
 O=gpurun_out/final
 mkdir -p $O profiles
 MODELS=${*:-pangu sfno graphcast}
@@ -19,7 +19,7 @@ for m in $MODELS; do
   echo "stats $m rc=$?"
   cp $(ls $O/stats_$m/*/p_kernel_stats.csv $O/stats_$m/p_kernel_stats.csv 2>/dev/null | head -1) $O/${R}_${m}_kernel_stats.csv 2>/dev/null
   bash tools/pmc_collect.sh $m $extra
-  python tools/pmc_summary.py gpurun_out/pmc_$m $O/${R}_${m}_pmc.json --steps 3 --stamp "$stamp" > $O/pmc_$m.log 2>&1 || tail -3 $O/pmc_$m.log
+  python tools/pmc_summary.py gpurun_out/pmc_$m $O/${R}_${m}_pmc.json --steps 3 --bench-json $O/stats_$m.log --stamp "$stamp" > $O/pmc_$m.log 2>&1 || tail -3 $O/pmc_$m.log
   cp $O/${R}_${m}_pmc.json profiles/ 2>/dev/null          # the bench lines below read the counter summaries (roofline.traffic)
   rm -rf gpurun_out/pmc_${m}_*                              # raw counter CSVs: tens of MB, summarised above
 done

@@ -1,6 +1,11 @@
 """Per-kernel summary of the rocprofv3 counter passes written by tools/pmc_collect.sh.
 
-    python tools/pmc_summary.py gpurun_out/pmc_<tag> profiles/r02_<tag>_pmc.json [--steps N]
+    python tools/pmc_summary.py gpurun_out/pmc_<tag> profiles/r04_<tag>_pmc.json [--steps N] [--per-step K | --bench-json FILE] [--stamp S]
+
+--per-step K (or --bench-json: a bench.py output line, K = the sum of its stages' launches_per_step): only the LAST steps x K dispatches of
+every pass are counted, i.e. the bench's own steps.  Without it the one-time kernels of load_params (GraphCast: embedders and prepared edge
+terms over 5 M rows, with the same kernel names as the step's) are summed into the per-step totals -- the reason round 2 and round 3 reported
+235 and 278 GB per step for unchanged step kernels: their load paths differed.
 
 For every kernel (demangled name, template arguments shortened) over all its dispatches: calls, average duration under the
 counters, and per dispatch
@@ -42,7 +47,15 @@ def load(d: Path):
     return list(csv.DictReader(open(f)))
 
 
+def launches_per_step(bench_json: str) -> int:
+    line = [l for l in open(bench_json).read().strip().splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    return sum(int(v["launches_per_step"]) for v in d["roofline"]["stages"].values())
+
+
 def main(prefix, out, *rest):
+    steps = int(rest[rest.index("--steps") + 1]) if "--steps" in rest else 3
+    per_step = int(rest[rest.index("--per-step") + 1]) if "--per-step" in rest else (launches_per_step(rest[rest.index("--bench-json") + 1]) if "--bench-json" in rest else 0)
     per = defaultdict(lambda: defaultdict(float))
     calls = defaultdict(int)
     dur = defaultdict(float)
@@ -51,11 +64,17 @@ def main(prefix, out, *rest):
         rows = load(Path(f"{prefix}_{pas}"))
         seen = set()
         for r in rows:
+            if r["Kernel_Name"] not in cache:
+                cache[r["Kernel_Name"]] = short(r["Kernel_Name"])
+        keep = lambda k: not ("prep_" in k or "at::" in k or "rocclr" in k or "split_planes" in k)          # noqa: E731
+        if per_step:                                     # the bench's own steps: the last steps x K dispatches of the engine's kernels
+            ids = sorted({int(r["Dispatch_Id"]) for r in rows if keep(cache[r["Kernel_Name"]])})
+            first = ids[-steps * per_step] if len(ids) >= steps * per_step else (ids[0] if ids else 0)
+            rows = [r for r in rows if int(r["Dispatch_Id"]) >= first]
+        for r in rows:
             kn = r["Kernel_Name"]
-            if kn not in cache:
-                cache[kn] = short(kn)
             k = cache[kn]
-            if "prep_" in k or "at::" in k or "rocclr" in k or "split_planes" in k:
+            if not keep(k):
                 continue
             per[k][r["Counter_Name"] + "@" + pas] += float(r["Counter_Value"])
             if pas == "sq1" and (kn, r["Dispatch_Id"]) not in seen:
@@ -83,10 +102,10 @@ def main(prefix, out, *rest):
         e["hbm_GBps_under_pmc"] = round(e["hbm_GB"] / (e["avg_us"] * 1e-6), 1) if e["avg_us"] else None
         e["raw_per_dispatch"] = {kk: round(v / n, 1) for kk, v in sorted(c.items())}
         res[k] = e
-    steps = int(rest[rest.index("--steps") + 1]) if "--steps" in rest else 3
     total = {"hbm_GB_per_step": round(sum(e["hbm_GB"] * e["calls"] for e in res.values()) / steps, 2),
              "write_GB_per_step": round(sum(e["write_GB"] * e["calls"] for e in res.values()) / steps, 2),
-             "kernel_ms_per_step_under_pmc": round(sum(e["avg_us"] * e["calls"] for e in res.values()) / steps / 1e3, 2), "steps": steps}
+             "kernel_ms_per_step_under_pmc": round(sum(e["avg_us"] * e["calls"] for e in res.values()) / steps / 1e3, 2), "steps": steps,
+             "launches_per_step": per_step or None, "scope": "the bench's own steps" if per_step else "every dispatch of the process (load-time kernels included)"}
     stamp = rest[rest.index("--stamp") + 1] if "--stamp" in rest else None      # e.g. sha256 of the profiled .so, so that bench.py can say what was profiled
     json.dump({"total": total, "stamp": stamp, "kernels": res}, open(out, "w"), indent=1)
     print(json.dumps(total))
