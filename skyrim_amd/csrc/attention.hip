@@ -178,7 +178,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
 //  are then four consecutive fp16 of one row -- one ds_read_b64, IF the address is 8-byte aligned, which depends on w_q mod 4 only:
 //  the table is stored four times, copy c shifted by c entries, and a lane reads copy (w_q + 1) mod 4 (32 KB of LDS, 81 reads per
 //  window and lane).  Per window a wave now moves 27 KB of Q / K / V and 18 KB of output.
-constexpr int BT_ROW = 28, BT_COPY = 144 * BT_ROW;      // fp16 entries per table row / per shifted copy
+// fp16 entries per table row / per shifted copy.  The 120-entry pad between the copies spreads the four copies (which a 16-query fragment mixes:
+// copy = (w_q + 1) mod 4) over the LDS banks: simulated over every (query fragment, key group) read of the kernel, a ds_read_b64 half-wave
+// costs 1.99 LDS cycles on average (worst 2) instead of 3.13 (worst 4) with the copies back to back -- round 3's counters showed 57 % of the
+// kernel's LDS-active cycles as bank conflicts.
+constexpr int BT_ROW = 28, BT_COPY = 144 * BT_ROW + 120;
 
 template <class TO, int NPL_O>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) earth_attention2_kernel(const f16* __restrict__ q, const f16* __restrict__ k,

@@ -70,6 +70,7 @@ def _load_state(path: str, geom: PanguGeometry) -> torch.Tensor:
 
 
 class PanguTimeLoop:
+    RANGE_LIMIT = 512.0          # sigma: 512 x 2^-22 = 1.2e-4 of an O(1) signal
     n_history_levels = 1
     time_step = datetime.timedelta(hours=6)
     in_channel_names = list(CHANNELS)
@@ -111,6 +112,8 @@ class PanguTimeLoop:
             self.engine24 = PanguEngine(self.geom, precision, device, **conventions)
             self.engine24.load_params(params24, calibration=calibration, rounding=rounding)
         self.grid = Grid(self.geom.lat, self.geom.lon)
+        self._mean = params["norm.mean"].to(self.engine.device, torch.float32).reshape(-1, 1, 1)
+        self._std = params["norm.std"].to(self.engine.device, torch.float32).reshape(-1, 1, 1)
 
     @property
     def device(self):
@@ -125,6 +128,14 @@ class PanguTimeLoop:
         if x.dim() != 5 or x.shape[0] != 1 or x.shape[1] != self.n_history_levels or tuple(x.shape[2:]) != self.engine.state_shape:
             raise ValueError(f"expected x of shape (1, 1, {', '.join(map(str, self.engine.state_shape))}), got {tuple(x.shape)}")
         state = x[0, 0].to(self.device, torch.float32).contiguous()
+        # range check of the initial condition, once per forecast: the engine carries activations as fp16 hi/lo planes -- 22 significant
+        # bits per element -- so a channel that sits N sigma from its mean costs the O(1) signals it is mixed with N x 2^-22 (measured: two
+        # channels at 1e4 sigma -> 2.8e-3 per-channel error, outside the 1e-3 bar, with finite output).  Analyses stay within tens of sigma;
+        # beyond RANGE_LIMIT the forecast is refused rather than delivered degraded.
+        z = ((state - self._mean) / self._std).abs().amax().item()
+        if not (z <= self.RANGE_LIMIT):
+            raise FloatingPointError(f"initial condition reaches {z:.3g} sigma from the channel means (limit {self.RANGE_LIMIT:g}): beyond what the "
+                                     "engine's fp16 hi/lo operand planes resolve inside the 1e-3 bar -- check the units / channel order of the state")
         if self._calibrate_on_first:                       # once per loop object: rollout / forecast calls after it reuse the biases
             self._calibrate_on_first = False
             for e in (self.engine, self.engine24):
