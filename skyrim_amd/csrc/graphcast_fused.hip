@@ -294,8 +294,8 @@ edge_update_kernel(const EdgeArgs a) {
             // everything but the newest NG requests (the other set's, issued last in the previous chunk) has landed: W1(j) and this set
             if constexpr (NT > 0) {
                 if (j == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                else if constexpr (NG == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else __builtin_amdgcn_s_waitcnt(0x0F70 | NG);          // (the builtin: the compiler's own bookkeeping follows it, see the static form)
+                asm volatile("" ::: "memory");
 #pragma unroll
                 for (int i = 0; i < NG; ++i) asm volatile("" : "+v"(gat[i]));
             } else {
@@ -443,9 +443,10 @@ edge_update_kernel(const EdgeArgs a) {
         for (int t = 0; t < FM; ++t) { swish4(pre[t][0]); swish4(pre[t][1]); hc[t] = fz_pack8(pre[t][0], pre[t][1]); hn[t] = hc[t]; }
         // chunk j: MFMAs on hc = hidden activation of chunk j; `gat` holds chunk j + 1's pieces and is refilled with chunk j + 3's
         auto chunk = [&](int j, f32x4 (&gat)[NG]) {
-            if constexpr (NG == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-            else if constexpr (NG == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            // a waitcnt the COMPILER sees (the builtin, not asm): its own bookkeeping then knows this set has landed and adds no vmcnt(0) of its
+            // own at the loop header; the LDS-DMA requests it does not know about are older than the set that stays in flight
+            __builtin_amdgcn_s_waitcnt(0x0F70 | NG);
+            asm volatile("" ::: "memory");
 #pragma unroll
             for (int i = 0; i < NG; ++i) asm volatile("" : "+v"(gat[i]));    // chunk j + 1's pieces have landed: to the compiler HERE
             __syncthreads();                           // W2(j) landed in stage j & 1; every wave is done with the other stage
@@ -472,6 +473,7 @@ edge_update_kernel(const EdgeArgs a) {
             });
             hc[0] = hn[0]; hc[1] = hn[1];
         };
+        __builtin_amdgcn_s_waitcnt(0x0F70 | ((2 * NG) & 15) | (((2 * NG) >> 4) << 14));   // only the two sets are in flight at the loop's entry
 #pragma unroll 1
         for (int j = 0; j < NCH; j += 2) {
             chunk(j, gatA);
