@@ -6,6 +6,7 @@ import pytest
 
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
+sys.path.insert(1, str(ROOT / "tests"))          # tests/_oracle_jobs.py
 
 
 # Tests run on seeded synthetic initial conditions and random-init parameters; both are explicit opt-ins of the product
@@ -16,6 +17,24 @@ os.environ.setdefault("SKYRIM_SYNTHETIC_WEIGHTS", "1")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_collection_finish(session):
+    """The full-size oracle runs the selected GPU tests will ask for start now, in host processes of their own (tests/_oracle_jobs.py)."""
+    ids = [item.nodeid for item in session.items]
+    if not any("_gpu.py::test_full_size" in i for i in ids):
+        return
+    import torch
+    if not torch.cuda.is_available() or os.environ.get("SKYRIM_TEST_ORACLE_JOBS", "1") == "0":
+        return
+    import _oracle_jobs
+    _oracle_jobs.start([k for k, frags in _oracle_jobs.WANTED_BY.items() if any(f in i for f in frags for i in ids)])
+
+
+def pytest_sessionfinish(session, exitstatus):
+    mod = sys.modules.get("_oracle_jobs")
+    if mod is not None:
+        mod.stop()
 
 
 @pytest.fixture(scope="session")

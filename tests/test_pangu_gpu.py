@@ -198,8 +198,8 @@ def full():
 @pytest.fixture(scope="module")
 def full_ref(full):
     """BASELINE configs[1]: the oracle's 24-h rollout (4 steps) at 721x1440 -- ~1 min of host time per step."""
-    g, params, x, e = full
-    return O.rollout(params, x, 4)
+    import _oracle_jobs
+    return _oracle_jobs.fetch("pangu_full_rollout4")["rollout"]      # = O.rollout(params, x, 4), started when collection finished
 
 
 @pytest.mark.timeout(1500)
