@@ -261,6 +261,7 @@ def predict_inclusive(precision, geom, params, dev, n_steps=8):
             torch.cuda.synchronize()
             t = time.perf_counter()
             pred, paths = m.rollout(t0, n_steps=n_steps, save=save, save_config={"output_dir": d}, initial_condition=pred)
+            pred.values                                  # the last prediction's copy to the host is part of the rollout (DataArray.values waits for it)
             dt = (time.perf_counter() - t) / n_steps
             out["save" if save else "no_save"] = {"ms_per_step": 1e3 * dt, "steps_per_s": 1.0 / dt, "files": len(paths),
                                                    "bytes_per_file": os.path.getsize(paths[0]) if paths else 0}
@@ -269,8 +270,9 @@ def predict_inclusive(precision, geom, params, dev, n_steps=8):
     out["io_counters"] = dict(m.model.io_counters)
     out["note"] = (f"GlobalModel.rollout(n_steps={n_steps}, initial_condition=<the previous prediction>) through the reference-shaped API: the state stays in "
                    "HBM (io_counters: one upload, the initial condition of the warm-up); every step's (t, t + 6 h) pair copied to pinned host memory on a "
-                   f"copy stream; save: one netCDF-3 file of 573 MB per step ({'tmpfs' if base else 'tmp dir'}) written by the save thread (parallel big-endian "
-                   "conversion + pwrite) while the next steps run")
+                   "copy stream, the copy of step k running under step k + 1 (the delivered array waits for it when its numbers are read); "
+                   f"save: one netCDF-3 file of 573 MB per step ({'tmpfs' if base else 'tmp dir'}) written by the save thread (workers convert to big-endian "
+                   "straight into a mapping of the file) while the next steps run")
     return out
 
 

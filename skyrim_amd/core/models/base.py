@@ -6,6 +6,7 @@ from __future__ import annotations
 
 import datetime
 import logging
+import os
 import time
 from concurrent.futures import ThreadPoolExecutor
 from pathlib import Path
@@ -19,6 +20,8 @@ from ...labeled import DataArray, open_dataarray
 from .utils import run_basic_inference
 
 logger = logging.getLogger("skyrim_amd")
+
+SAVE_WORKERS = 6          # per-step netCDF files written at once by ``rollout`` (SKYRIM_SAVE_WORKERS; measured in ncio.py / tools/predict_cost.py)
 
 
 def adjust_lead_time(lead_time: int, step_size: int = 6):
@@ -93,18 +96,24 @@ class GlobalModel:
             save_config["forecast_id"] = cfg["forecast_id"]
         pred, pending = initial_condition, []
         source = "file" if initial_condition is not None else self.source_label
-        # Step k's file is written by ONE worker thread while step k + 1 runs (the reference writes 573 MB synchronously between two
-        # steps, base.py:134-143).  One worker keeps the files -- and the zarr appends -- in step order; at most two predictions wait
-        # for the disk, so a slow target throttles the rollout instead of filling host memory.  Same files, same order, same paths.
-        pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="skyrim-save") if save else None
+        # Step k's file is written by a worker thread while the next steps run (the reference writes 573 MB synchronously between two
+        # steps, base.py:134-143).  netCDF targets are one independent file per step, so up to SAVE_WORKERS of them are written at once:
+        # the page cache takes ONE file's bytes at ~6 GB/s however many threads push them (buffered writes serialise on the inode,
+        # tools/predict_cost.py), different files do not share that lock.  zarr appends to one store and keeps a single worker, in step
+        # order.  At most ``workers + 1`` predictions wait for the disk, so a slow target throttles the rollout instead of filling host
+        # memory.  Same files, same paths, returned in step order.
+        workers = 1
+        if save and (cfg.get("file_type") or "netcdf") == "netcdf" and "://" not in str(cfg.get("output_dir", "")):
+            workers = max(1, int(os.environ.get("SKYRIM_SAVE_WORKERS", SAVE_WORKERS)))
+        pool = ThreadPoolExecutor(max_workers=workers, thread_name_prefix="skyrim-save") if save else None
         try:
             for n in range(n_steps):
                 pred = self.predict_one_step(start_time, initial_condition=pred)
                 pred_time = start_time + self.time_step
                 if save:
                     pending.append(pool.submit(save_forecast, pred, self.model_name, start_time, pred_time, source, config=cfg))
-                    if len(pending) > 2:
-                        pending[-3].result()
+                    if len(pending) > workers + 1:
+                        pending[-(workers + 2)].result()
                 start_time, source = pred_time, "file"
                 logger.info(f"Rollout step {n + 1}/{n_steps} completed")
             output_paths = [f.result() for f in pending]         # re-raises a writer's exception here, in step order

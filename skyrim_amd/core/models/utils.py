@@ -34,7 +34,9 @@ class ResidentState:
 
     def tensor_for(self, x, n_hist: int):
         """(1, n_hist, C, lat, lon) device tensor if ``x`` carries the array these states were delivered in, else None."""
-        vals = getattr(x, "values", None)
+        vals = getattr(x, "_values", None)         # (the array object, not its contents: a DataArray's ``values`` would wait for the copy)
+        if vals is None:
+            vals = getattr(x, "values", None)
         if vals is None or vals is not self._host() or vals.flags.writeable or len(self.states) < n_hist:
             return None
         return torch.stack([t[0] if t.dim() == 4 else t for t in self.states[-n_hist:]], dim=0).unsqueeze(0)
@@ -94,15 +96,27 @@ def _drain(model, loop, n: int, time):
             break
     if hasattr(loop, "close"):
         loop.close()            # flush BEFORE the result is built: a non-finite last state must not be delivered
+    ready = None
     if stacked is not None:
-        side.synchronize()
+        # The last state's copy is still in flight on the side stream.  The array is handed over now and the DataArray waits for the
+        # copy's event the first time its numbers are read (labeled.DataArray.values): ``rollout`` feeds the prediction straight back
+        # (ResidentState: no read), so the 286 MB copy of step k runs under step k + 1 instead of between the two; the save thread and
+        # any other reader wait first.  Pageable results (beyond _PINNED_LIMIT) were copied synchronously by torch: nothing to wait for.
+        done = torch.cuda.Event()
+        done.record(side)
+        pinned = stacked.is_pinned()
+        keep = stacked                              # the tensor owns the pinned block: it must outlive the numpy view
         stacked = stacked[:len(times)].numpy()
+        if pinned:
+            ready = lambda ev=done, _keep=keep: ev.synchronize()    # noqa: E731
+        else:
+            done.synchronize()
         if hasattr(model, "__dict__"):
             model._resident_state = ResidentState(stacked, last)
     else:
         stacked = np.stack(arrays)
     coords = dict(time=times, channel=model.out_channel_names, lat=np.asarray(model.grid.lat), lon=np.asarray(model.grid.lon))
-    return DataArray(stacked, dims=["time", "channel", "lat", "lon"], coords=coords)
+    return DataArray(stacked, dims=["time", "channel", "lat", "lon"], coords=coords, ready=ready)
 
 
 def perturb_initial_conditions(initial_conditions: DataArray, channel, lat, lon, value):

@@ -53,7 +53,7 @@ template <class P, class TC>
 constexpr int gemm_smem_bytes() { return (P::NA * TC::BM + P::NW * TC::BN) * TC::BK * 2; }
 
 template <class P, class TC, class AL, class EP, bool SWAP>
-__device__ __forceinline__ void gemm_body(const GemmArgs<P, AL, EP>& g, char* smem) {
+__device__ __forceinline__ void gemm_body(const GemmArgs<P, AL, EP>& g, char* smem, const int tile_x = blockIdx.x, const int tile_y = blockIdx.y) {
     typedef typename P::T T;
     constexpr int NA = P::NA, NW = P::NW;
     constexpr int BM = TC::BM, BN = TC::BN, BK = TC::BK, CPR = TC::CPR, THREADS = TC::THREADS;
@@ -63,7 +63,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs<P, AL, EP>& g, char* sm
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / TC::WN, wn = wave % TC::WN;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int m0 = tile_y * BM, n0 = tile_x * BN;          // (the launch's own block indices unless the caller re-maps them: sfno_ops.hip)
     char* As = smem;
     char* Ws = smem + NA * A_PLANE;
 
@@ -192,9 +192,9 @@ __device__ __forceinline__ void gemm_body(const GemmArgs<P, AL, EP>& g, char* sm
         __syncthreads();
     }
 #ifdef SKP_PROBE_NO_EPILOGUE
-    if (g.M > 0) { if (acc[0][0][0] == 12345.678f) g.ep.template run<TC, SWAP>(acc, m0 + wm * TC::WTM, n0 + wn * TC::WTN, lane, wm, wn, smem + gemm_smem_bytes<P, TC>(), g.M, g.N, (int)blockIdx.x); return; }
+    if (g.M > 0) { if (acc[0][0][0] == 12345.678f) g.ep.template run<TC, SWAP>(acc, m0 + wm * TC::WTM, n0 + wn * TC::WTN, lane, wm, wn, smem + gemm_smem_bytes<P, TC>(), g.M, g.N, tile_x); return; }
 #endif
-    g.ep.template run<TC, SWAP>(acc, m0 + wm * TC::WTM, n0 + wn * TC::WTN, lane, wm, wn, smem + gemm_smem_bytes<P, TC>(), g.M, g.N, (int)blockIdx.x);
+    g.ep.template run<TC, SWAP>(acc, m0 + wm * TC::WTM, n0 + wn * TC::WTN, lane, wm, wn, smem + gemm_smem_bytes<P, TC>(), g.M, g.N, tile_x);
 }
 
 template <class P, class TC, class AL, class EP>

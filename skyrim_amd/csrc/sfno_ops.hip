@@ -43,12 +43,25 @@ __device__ __forceinline__ void gemm_strided_body(GemmArgs<PX, AL, EpStrided>& g
         g.K -= kb;
         g.al.K -= kb;
     }
+    // Which tile this workgroup computes.  Workgroups go to the 8 XCDs round-robin in launch order (x fastest), so with the plain mapping the
+    // column tiles of one row tile -- which all read the same 128 rows of A -- land on 8 different L2s and every XCD streams the whole of A
+    // (GraphCast's node-term GEMM, N = 1024 = 8 column tiles: 1.44 GB fetched per launch for an 84 MB operand).  Re-mapped, the workgroups
+    // of one XCD (same launch index mod 8) walk a contiguous range of tiles, column tile fastest: a row tile's columns run side by side on one
+    // L2.  The map is a bijection for any tile count (the first T mod 8 XCDs take one tile more).
+    int tx = blockIdx.x, ty = blockIdx.y;
+    if (bs.xcd_remap) {
+        const int gx = gridDim.x, T = gx * (int)gridDim.y, l = tx + gx * ty;
+        const int q = T >> 3, r = T & 7, x = l & 7, slot = l >> 3;
+        const int v = x < r ? x * (q + 1) + slot : r * (q + 1) + (x - r) * q + slot;
+        ty = v / gx;
+        tx = v - ty * gx;
+    }
     if (bs.m_cap_step > 0) {
         const int cap = bs.m_cap0 + (int)z * bs.m_cap_step;
         if (cap < g.M) { g.M = cap; g.al.M = cap; }
-        if ((int)blockIdx.y * TC::BM >= g.M) return;
+        if (ty * TC::BM >= g.M) return;
     }
-    gemm_body<PX, TC, AL, EpStrided, SWAP>(g, smem);
+    gemm_body<PX, TC, AL, EpStrided, SWAP>(g, smem, tx, ty);
 }
 
 template <class PX, class AL, bool SWAP>
@@ -131,7 +144,8 @@ int sksfno_gemm_run(const sksfno_gemm* d, void* stream) {
         return SKSFNO_E_ARG;
     const ALStrided al{d->a, d->M, d->K, d->a_m1, d->a_sm, d->a_sm2, d->a_sk, d->a_kscale, d->a_kshift, d->a2, d->a2_sk, d->a2_k_split};
     const EpStrided ep{d->out, d->bias, d->res_pre, d->res_post, d->o_m1, d->act, d->o_sm, d->o_sm2, d->o_sn};
-    const BatchStrides bs{d->a_sb, d->w_sb, d->o_sb, d->k_lo_step, d->m_cap0, d->m_cap_step};
+    static const bool no_remap = getenv("SKSFNO_NO_XCD_REMAP") != nullptr;                                     // A/B switch (tools/r4_remap.sh)
+    const BatchStrides bs{d->a_sb, d->w_sb, d->o_sb, d->k_lo_step, d->m_cap0, d->m_cap_step, no_remap ? 0 : 1};
     // rows contiguous in the output (NCHW activations): un-swapped order gives 4 consecutive rows per lane
     const bool swap = !(d->o_sm == 1 && d->o_sn != 1);
     static const int tile_env = [] { const char* v = getenv("SKSFNO_TILE"); return v ? atoi(v) : 0; }();      // 128 / 256: force one tile

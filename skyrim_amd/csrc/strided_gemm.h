@@ -217,6 +217,6 @@ struct EpStrided {
 #endif
 typedef TileCfg<SKP_STRIDED_TILE> TG;      // wide N: the fp32 A operand is fetched and split once per 256 output columns
 
-struct BatchStrides { long long a, w, o; int k_lo_step, m_cap0, m_cap_step; };
+struct BatchStrides { long long a, w, o; int k_lo_step, m_cap0, m_cap_step, xcd_remap; };
 
 }  // namespace skp

@@ -45,31 +45,48 @@ class Coordinate:
 
 
 class DataArray:
-    def __init__(self, data, dims: Iterable[str], coords: dict[str, Any] | None = None, name: str | None = None):
-        self.values = np.asarray(data)
+    def __init__(self, data, dims: Iterable[str], coords: dict[str, Any] | None = None, name: str | None = None, ready=None):
+        """``ready``: a callable that returns once ``data`` holds its final contents (run_basic_inference hands over a pinned host
+        buffer whose device-to-host copy may still be in flight, with the copy's event wait as ``ready``).  It is called the first
+        time ``values`` is read -- shape, dims and coordinates never wait -- so a prediction fed straight back into the next step
+        (``rollout``) lets its copy overlap that step; whoever reads the numbers (the save thread, the caller) waits first."""
+        self._values = np.asarray(data)
+        self._ready = ready
         self.dims = tuple(dims)
-        if len(self.dims) != self.values.ndim:
-            raise ValueError(f"{len(self.dims)} dims for a {self.values.ndim}-d array")
+        if len(self.dims) != self._values.ndim:
+            raise ValueError(f"{len(self.dims)} dims for a {self._values.ndim}-d array")
         self.name = name
         self._coords: dict[str, np.ndarray] = {}
         for k, v in (coords or {}).items():
             arr = _as_index_array(v) if not np.isscalar(v) else np.array(v)
-            if k in self.dims and arr.shape != (self.values.shape[self.dims.index(k)],):
-                raise ValueError(f"coordinate {k} has length {arr.shape}, dim has {self.values.shape[self.dims.index(k)]}")
+            if k in self.dims and arr.shape != (self._values.shape[self.dims.index(k)],):
+                raise ValueError(f"coordinate {k} has length {arr.shape}, dim has {self._values.shape[self.dims.index(k)]}")
             self._coords[k] = arr
+
+    @property
+    def values(self) -> np.ndarray:
+        ready = self.__dict__.get("_ready")
+        if ready is not None:
+            ready()                                 # (an event wait: harmless if two threads get here together)
+            self._ready = None
+        return self._values
+
+    @values.setter
+    def values(self, v):
+        self._values, self._ready = np.asarray(v), None
 
     # -- basic accessors --------------------------------------------------- #
     @property
     def coords(self) -> dict[str, Coordinate]:
         return {k: Coordinate(k, v) for k, v in self._coords.items()}
     @property
-    def shape(self): return self.values.shape
+    def shape(self): return self._values.shape
     @property
-    def size(self): return self.values.size
+    def size(self): return self._values.size
     @property
-    def dtype(self): return self.values.dtype
+    def dtype(self): return self._values.dtype
     @property
-    def ndim(self): return self.values.ndim
+    def ndim(self): return self._values.ndim
 
     def __getattr__(self, name):
         c = self.__dict__.get("_coords", {})

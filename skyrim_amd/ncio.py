@@ -35,18 +35,52 @@ def _native(a: np.ndarray) -> np.ndarray:
 FAST_PAYLOAD_BYTES = 64 << 20      # payloads of at least this size go through the parallel writer below
 
 
-def _parallel_payload_write(path, offset: int, payload: np.ndarray, threads: int | None = None):
-    """Big-endian float32 bytes of ``payload`` into ``path`` at ``offset``: the array is cut into chunks, every worker converts its chunk
-    (numpy releases the GIL in the cast loop) and writes it with ``os.pwrite`` (released in the system call).  A 573 MB forecast step
-    otherwise spends ~0.5 s in three serial passes (byte swap, ``tobytes``, ``write``) of scipy's writer."""
+def _parallel_payload_write(path, offset: int, payload: np.ndarray, threads: int | None = None, use_mmap: bool | None = None):
+    """Big-endian float32 bytes of ``payload`` into ``path`` at ``offset``: the array is cut into pieces, every worker converts its pieces
+    (numpy releases the GIL in the cast loop) and writes them with ``os.pwrite`` (released in the system call).  A 573 MB forecast step
+    otherwise spends ~0.5 s in three serial passes (byte swap, ``tobytes``, ``write``) of scipy's writer.
+
+    What bounds it (tools/predict_cost.py on the MI355X host, 573 MB into tmpfs): buffered writes to ONE file serialise on its inode, so the
+    page cache takes the bytes at ~6 GB/s whatever the worker count (8 workers 89 ms, 16: 94, 64: 100) -- the conversion only has to keep up,
+    hence few workers (4; SKYRIM_NC_THREADS); ``rollout`` gets its throughput from writing several steps' files at once instead
+    (core/models/base.py SAVE_WORKERS; 8 full-size steps with their files, ms per step: 1 file at a time 151, 3: 76, 4: 61 - 70, 6: 50, 8: 47 - 52).
+    ``use_mmap`` / ``SKYRIM_NC_MMAP=1``: the workers convert straight into a shared mapping of the file (no intermediate buffer, no system
+    call per piece).  Twice as fast on a small host (8 cores: 110 vs 230 ms) but page-fault bound and slower the more threads fault on a
+    large one (256 hardware threads: 8 workers 122 ms, 32: 233, 64: 406), so it is opt-in."""
     import os
     from concurrent.futures import ThreadPoolExecutor
     flat = payload.reshape(-1)
     n = flat.shape[0]
-    threads = threads or max(1, min(32, (os.cpu_count() or 4) // 2))
-    chunk = max(1 << 20, -(-n // (threads * 4)))                     # elements per piece: a few pieces per worker
-    fd = os.open(str(path), os.O_WRONLY)
+    threads = threads or int(os.environ.get("SKYRIM_NC_THREADS", 0)) or max(1, min(4, (os.cpu_count() or 4) // 2))
+    chunk = max(1 << 18, -(-n // (threads * 4)))                     # elements per piece: a few pieces per worker
+    if use_mmap is None:
+        use_mmap = os.environ.get("SKYRIM_NC_MMAP", "0") == "1"
+    fd = os.open(str(path), os.O_RDWR)
     try:
+        view = None
+        if use_mmap and n:
+            import mmap
+            base = offset // mmap.ALLOCATIONGRANULARITY * mmap.ALLOCATIONGRANULARITY
+            try:
+                if os.fstat(fd).st_size < offset + 4 * n:              # the hole is the file's tail: a store past the end would be a SIGBUS
+                    os.ftruncate(fd, offset + 4 * n)
+                view = mmap.mmap(fd, offset - base + 4 * n, offset=base)
+            except (OSError, ValueError):
+                view = None                                            # not mappable (some network / FUSE targets): pwrite below
+        if view is not None:
+            try:
+                dst = np.frombuffer(view, dtype=">f4", count=n, offset=offset - base)
+
+                def put(i0):
+                    dst[i0:i0 + chunk] = flat[i0:i0 + chunk]           # cast + byte swap in one pass, into the mapping
+
+                with ThreadPoolExecutor(max_workers=threads) as pool:
+                    list(pool.map(put, range(0, n, chunk)))
+                del dst
+            finally:
+                view.close()                                           # (a failed store -- SIGBUS on ENOSPC aside -- raises above; close never hides it)
+            return
+
         def put(i0):
             be = flat[i0:i0 + chunk].astype(">f4")
             mv, off = memoryview(be).cast("B"), offset + 4 * i0

@@ -325,6 +325,31 @@ def test_resident_state_is_tied_to_the_delivered_array():
     assert edited.values is not host and edited.values[-1, 1, 2, 3] == 9.0 and host.sum() == 0.0 and rs.tensor_for(edited, 1) is None
 
 
+def test_a_delivered_array_waits_for_its_copy_only_when_its_numbers_are_read():
+    """labeled.DataArray(ready=...): run_basic_inference hands over a pinned buffer whose device-to-host copy may still be in flight; shape,
+    dims, coordinates and the resident-state lookup never wait, the first read of ``values`` (by anyone: a derived array, numpy, a
+    writer) waits exactly once; assigning new values drops the wait."""
+    from skyrim_amd.core.models.utils import ResidentState
+    calls = []
+    host = np.arange(2 * 3 * 4 * 5, dtype=np.float32).reshape(2, 3, 4, 5)
+    mk = lambda: DataArray(host, ["time", "channel", "lat", "lon"], dict(channel=["a", "b", "c"], lat=np.arange(4.0), lon=np.arange(5.0)),  # noqa: E731
+                           ready=lambda: calls.append(1))
+    da = mk()
+    rs = ResidentState(host, [torch.zeros(1, 3, 4, 5)])
+    assert da.shape == (2, 3, 4, 5) and da.ndim == 4 and da.size == 120 and da.dtype == np.float32 and da.channel.tolist() == ["a", "b", "c"]
+    assert "DataArray" in repr(da) and rs.tensor_for(da, 1) is not None and calls == []
+    assert da.values is host and calls == [1] and da.values is host and calls == [1]
+    for read in (lambda d: d.sel(channel="b"), lambda d: np.asarray(d), lambda d: d.isel(time=-1), lambda d: d.copy(), lambda d: d.mean("time"),
+                 lambda d: d.assign_coords(lat=np.arange(4.0) + 1).values):
+        calls.clear()
+        read(mk())
+        assert calls == [1], read
+    calls.clear()
+    d = mk()
+    d.values = host.copy()
+    assert d.values is not host and calls == []
+
+
 def test_predict_one_step_accepts_a_pathlib_path(tmp_path):
     m = BoringGlobalModel(ic_source="synthetic")
     first, paths = m.rollout(T0, n_steps=1, save=True, save_config={"output_dir": str(tmp_path)})

@@ -34,6 +34,14 @@ def test_parallel_writer_is_byte_identical_to_the_plain_path(tmp_path):
     # many small pieces over few workers
     big = _da((2, 9, 181, 360), seed=2)
     ncio.write_dataarray_netcdf3(big, tmp_path / "big_plain.nc", fast_threshold=1 << 60)
+    for mapped in (True, False):                                   # the mapped writer and its pwrite fallback: same bytes
+        orig_w = ncio._parallel_payload_write
+        try:
+            ncio._parallel_payload_write = lambda path, off, payload, m=mapped: orig_w(path, off, payload, threads=2, use_mmap=m)
+            ncio.write_dataarray_netcdf3(big, tmp_path / f"big_{mapped}.nc", fast_threshold=0)
+        finally:
+            ncio._parallel_payload_write = orig_w
+        assert filecmp.cmp(tmp_path / "big_plain.nc", tmp_path / f"big_{mapped}.nc", shallow=False)
     orig = ncio._parallel_payload_write
     try:
         ncio._parallel_payload_write = lambda path, off, payload: orig(path, off, payload, threads=3)

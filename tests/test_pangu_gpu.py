@@ -335,7 +335,11 @@ def test_rollout_keeps_the_state_in_hbm_and_saves_the_same_files(toy, tmp_path):
     edited = perturb_initial_conditions(pred, "t2m", 48.0, 11.5, 250.0)
     assert edited.values.flags.writeable and edited.values[1, 68].min() <= 250.0
     nxt = m.predict_one_step(t, initial_condition=edited)
-    assert m.model.io_counters["state_uploads"] == 2 and np.array_equal(nxt.values[0], edited.values[1])
+    # the delivered array's last copy may still be in flight: shape and coordinates do not wait, the first read of the numbers does
+    assert nxt._ready is not None and nxt.shape == pred.shape and nxt.time.values[0] == np.datetime64(t) and nxt._ready is not None
+    assert m.model.io_counters["state_uploads"] == 2 and np.array_equal(nxt.values[0], edited.values[1]) and nxt._ready is None
+    fed = m.predict_one_step(t + m.time_step, initial_condition=nxt)              # fed back unread or read: the same resident state
+    assert m.model.io_counters["resident_hits"] == 3 and np.array_equal(fed.values[0], nxt.values[1])
 
 
 def test_forecast_interleaves_6h_and_24h_networks(toy):
