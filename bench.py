@@ -58,14 +58,17 @@ MODE_NOTES = {
 }
 
 
-def cpu_baseline(params, geom, x):
-    """CPU restatement (oracle/, kind 'port') timed on this box's host cores: ONE full step of the same workload, no scaling."""
+def cpu_baseline(params, geom, x, keep=None):
+    """CPU restatement (oracle/, kind 'port') timed on this box's host cores: ONE full step of the same workload, no scaling.
+    ``keep`` (a dict): receives the step's output under "y" -- the full-size parity figure of the line is read against it."""
     from oracle import pangu_oracle as O
     cores = torch.get_num_threads()
     t0 = time.time()
     with torch.no_grad():
         y = O.forward(params, x)
     dt = time.time() - t0
+    if keep is not None:
+        keep["y"] = y
     return {"value": 1.0 / dt, "unit": "steps/s", "cores": cores, "kind": "port",
             "sample": f"ONE full {geom.n_lat}x{geom.n_lon} 6-h step of the PyTorch-CPU fp32 restatement (oracle/pangu_oracle.py) in {dt:.1f} s on {cores} "
                       f"threads; no scaling; not the reference's ONNX graph (onnxruntime and the weights are not obtainable here); finite={bool(torch.isfinite(y).all())}",
@@ -526,7 +529,7 @@ def run_graphcast(args, rank, local_rank, world, dist):
                                "s_per_step_est": t_step}
     if world == 1 and not args.no_parity:
         from oracle import graphcast_oracle as O
-        small = GraphcastConfig(n_lat=61, n_lon=120, splits=3, latent=64, steps=4)
+        small = GraphcastConfig(n_lat=61, n_lon=120, splits=3, latent=512, steps=4)      # the production latent: the fused edge / node kernels
         se = GraphcastEngine(small, dev)
         sp = init_synthetic(small, 0)
         se.load_params(sp)
@@ -535,7 +538,7 @@ def run_graphcast(args, rank, local_rank, world, dist):
         y = se.step(s0.to(dev), s1.to(dev), sf.to(dev)).cpu()
         from oracle import graphcast_graph as OG
         ref = O.forward(sp, OG.build(small.n_lat, small.n_lon, small.splits), s0, s1, sf)
-        out["parity"] = {"grid": "61x120, M3 mesh", "max_rel_err": O.per_channel_rel_err(y, ref).max().item(),
+        out["parity"] = {"grid": "61x120, M3 mesh, latent 512, 4 processor layers", "fused_kernels": bool(se.fused), "max_rel_err": O.per_channel_rel_err(y, ref).max().item(),
                          "max_rel_err_of_increment": O.increment_rel_err(y, ref, s1).max().item(), "bar": 1e-3}
     return out
 
@@ -717,10 +720,19 @@ def main():
                            for s in timed},
             },
         }
+        kept = {}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(params, geom, x_host)
+            out["cpu_baseline"] = cpu_baseline(params, geom, x_host, kept)
         if world == 1 and not args.no_parity:
             out["parity"] = toy_parity(args.precision)
+            if "y" in kept and args.members <= 1:
+                # the timed workload itself: this engine's first step from the synthetic state against the oracle step the CPU baseline just ran
+                from oracle import pangu_oracle as O
+                y_gpu = eng.step(x_host.to(dev)).cpu()
+                out["parity"]["full_size"] = {"grid": f"{geom.n_lat}x{geom.n_lon}", "steps": 1, "max_rel_err": O.per_channel_rel_err(y_gpu, kept["y"]).max().item(),
+                                              "note": "per channel, max|y - ref| / max|ref|; the 24-h rollout (4 steps, each asserted) is tests/test_pangu_gpu.py"}
+                del y_gpu
+        kept.clear()
         if world == 1 and not args.no_alt_modes:
             out["pcie_inclusive"] = api_rollout_rate(args.precision, geom, params, x_host, dev)
             eng = None

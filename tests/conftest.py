@@ -19,6 +19,14 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """The full-size oracle comparisons run last: their oracle results come from host processes started when collection finishes
+    (tests/_oracle_jobs.py, four minutes of host time), and every other GPU test runs while those compute."""
+    last = [i for i in items if "_gpu.py::test_full_size" in i.nodeid]
+    if last:
+        items[:] = [i for i in items if "_gpu.py::test_full_size" not in i.nodeid] + last
+
+
 def pytest_collection_finish(session):
     """The full-size oracle runs the selected GPU tests will ask for start now, in host processes of their own (tests/_oracle_jobs.py)."""
     ids = [item.nodeid for item in session.items]
