@@ -68,3 +68,64 @@ def test_default_line_carries_the_other_models_and_the_host_path_figures():
     rows = list(csv.DictReader((PROFILES / "r03_pangu_kernel_stats.csv").open()))
     avg_ms = next(float(x["AverageNs"]) for x in rows if "proj_mlp2_kernel" in x["Name"] and "Li384" in x["Name"]) / 1e6
     assert abs(avg_ms / r["avg_launch_ms"] - 1.0) < 0.06, (avg_ms, r["avg_launch_ms"])
+
+
+# ---- round 4 (profiles/r04_*): the fused GraphCast kernels, the XCD-aware strided GEMM, the host path ------------------------------------- #
+R4_KERNELS = {"pangu": ["proj_mlp2_kernel", "rt_qkv_kernel", "earth_attention2_kernel"], "sfno": ["sfno_chain_kernel", "gemm_strided_kernel"],
+              "graphcast": ["edge_update_kernel<true, 2, 1>", "edge_update_kernel<false, 2, 1>", "node_mlp_kernel<2>", "gemm_strided_kernel_s"]}
+
+
+@pytest.mark.parametrize("model", ["pangu", "sfno", "graphcast"])
+def test_r04_bench_line_and_counter_summary(model):
+    d = json.loads((PROFILES / f"r04_bench_{model}.json").read_text())
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+                "roofline", "cpu_baseline", "parity"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["vs_baseline"] is None and d["data"] == "synthetic" and "721x1440" in d["config"]["workload"]
+    assert abs(d["value"] * d["ms_per_step"] / 1e3 - 1.0) < 1e-6
+    r = d["roofline"]
+    assert r["bound"] == {"pangu": "mfma", "sfno": "hbm", "graphcast": "mfma"}[model]            # GraphCast: the fused kernels sit nearer the MFMA roof
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0 < r["frac"] < 1 and r["traffic"] > 0
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0 and d["parity"]["max_rel_err"] < 3e-4
+    p = json.loads((PROFILES / f"r04_{model}_pmc.json").read_text())
+    assert p["total"]["scope"] == "the bench's own steps" and f"libskyrim_{model}.so" in p["stamp"]
+    names, stats = " ".join(p["kernels"]), (PROFILES / f"r04_{model}_kernel_stats.csv").read_text()
+    for k in R4_KERNELS[model]:
+        assert k in names and k in stats, k
+
+
+def test_r04_graphcast_meets_the_traffic_and_launch_targets_of_the_fused_design():
+    """no segment_sum in the processor path, <= 3 launches per processor layer, counter traffic <= 130 GB per step; the step time
+    target (<= 50 ms) is NOT met and the committed line says what it is."""
+    d = json.loads((PROFILES / "r04_bench_graphcast.json").read_text())
+    p = json.loads((PROFILES / "r04_graphcast_pmc.json").read_text())
+    assert "segment_sum_kernel" not in " ".join(p["kernels"]) and "segment_sum_kernel" not in (PROFILES / "r04_graphcast_kernel_stats.csv").read_text()
+    st = d["roofline"]["stages"]
+    assert st["processor"]["launches_per_step"] == 3 * 16 and p["total"]["launches_per_step"] <= 61
+    assert p["total"]["hbm_GB_per_step"] <= 130.0 and d["roofline"]["hbm_GB_per_step_all_kernels"] == p["total"]["hbm_GB_per_step"]
+    assert 50.0 < d["ms_per_step"] < 60.0                                                # round 3: 80.8 - 81.7
+    assert abs(sum(s["ms_per_step"] for s in st.values()) / d["ms_per_step"] - 1.0) < 0.03
+    par = d["parity"]
+    assert par["fused_kernels"] and "latent 512" in par["grid"] and par["max_rel_err"] < 1e-5 and par["max_rel_err_of_increment"] < 1e-3
+
+
+def test_r04_default_line_full_size_parity_other_models_and_host_path():
+    d = json.loads((PROFILES / "r04_bench_pangu.json").read_text())
+    # the timed workload itself against the oracle step the CPU baseline ran (VERDICT r3 #4: the full-size figure, not the 49 x 192 one)
+    full = d["parity"]["full_size"]
+    assert full["grid"] == "721x1440" and full["max_rel_err"] < 3e-4 and d["config"]["rounding"] == "compensated" and d["config"]["calibration"] == "synthetic"
+    assert d["modes"]["f16x2m/nearest"]["parity"]["max_rel_err"] > d["parity"]["max_rel_err"]      # what compensated rounding buys, toy grid
+    assert set(d["models"]) == {"sfno", "graphcast"}
+    for m in ("sfno", "graphcast"):
+        e, o = d["models"][m], json.loads((PROFILES / f"r04_bench_{m}.json").read_text())
+        assert "error" not in e and e["finite"] and abs(e["ms_per_step"] / o["ms_per_step"] - 1.0) < 0.1 and f"r04_{m}_pmc.json" in e["profile"]
+        assert e["roofline"]["traffic"] > 0                                             # the stamp of the summary named the library that ran
+    pi = d["predict_inclusive"]
+    assert pi["io_counters"]["state_uploads"] == 1 and pi["save"]["files"] == 8
+    assert pi["no_save"]["ms_per_step"] < 23.0 and pi["save"]["ms_per_step"] < 90.0      # round 3: 26.0 / 133 (targets 21.5 / 45: the second is not met)
+    r = d["roofline"]
+    assert r["kernel"] == "proj_mlp_r1" and "libskyrim_pangu.so" in r["counters"]["profiled_at"]
+    import csv
+    rows = list(csv.DictReader((PROFILES / "r04_pangu_kernel_stats.csv").open()))
+    avg_ms = next(float(x["AverageNs"]) for x in rows if "proj_mlp2_kernel" in x["Name"] and "384" in x["Name"]) / 1e6
+    assert abs(avg_ms / r["avg_launch_ms"] - 1.0) < 0.06, (avg_ms, r["avg_launch_ms"])
