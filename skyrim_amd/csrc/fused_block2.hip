@@ -18,11 +18,27 @@
 // Row-tile structure, epilogues and data layouts are fused_block.hip's: a wave owns FM x 16 stream tokens, their attention rows are
 // gathered through the inverse window table as MFMA B-operand fragments, x_mid = x + LayerNorm(proj) becomes the MLP's operand in
 // registers (perm8), the stream is read once and written once.  gfx950 only.
+//
+// SKP_BLK2_CHAINS4 (build-time variant, tools/blk2_chains.sh): a v_mfma_f32_16x16x32_f16 that accumulates into the result of an earlier one
+// issues ~47 clocks after it (measured in graphcast_fused.hip's loops: two alternating accumulator chains run at 23.7 clocks per MFMA, four at
+// the pipe's 16).  With FM = 1 (C = 384: 12 of the 16 blocks) every loop below alternates between exactly TWO accumulators per k-step; the
+// variant gives each loop four chains without more live registers: the lo-plane terms of the projection and of fc1 go to accumulators of their
+// own (added once per block / chunk; they live where the fc2 operand fragments are dead), and fc2 issues the hi-plane terms of column pair
+// p - 1 after the lo-plane terms of pair p (the previous fragment pair stays in registers where fc1's accumulators are dead).
+// MEASURED (round 4, 721x1440, same box, back to back): 19.48 ms per step against 18.56 for the plain order, toy parity 1.23e-4 against 1.19e-4 --
+// 5 % SLOWER.  With two waves per SIMD the partner wave's MFMAs fill the dependent-issue gaps (graphcast_fused.hip runs ONE wave per SIMD, where
+// they are exposed); what the variant adds -- 168 bytes more scratch per lane, the accumulator adds -- is pure cost here.  Not built by default.
 #include <cstdlib>
 #include "gemm_dma.h"
 #include "launchers.h"
 
 namespace skp {
+
+#ifdef SKP_BLK2_CHAINS4
+constexpr bool kBlk2Chains4 = true;
+#else
+constexpr bool kBlk2Chains4 = false;
+#endif
 
 template <int C_, int FM_, int RD_, bool SKEW_, bool DUO_, int PROBE_ = 0, bool ONE_ = false>
 struct Blk2Shape {
@@ -164,6 +180,17 @@ proj_mlp2_kernel(const Block2Args<T> a) {
         __syncthreads();                               // block j landed; every wave is done with block j - 1
         if (j + 1 < NPB) dma1(a.projh + ((long long)(j + 1) * S::SLOT_KIB << 9), lds_base + (unsigned)((S::PSLOT0 + ((j + 1) & 1)) * S::SLOT));
         else if constexpr (S::DUO) dma1(a.w1h, lds_base);      // NPB is even: the last block sits in slot 1, slot 0 is free for fc1's chunk 0
+        if constexpr (kBlk2Chains4 && FM == 1 && !S::ONE) {
+            f32x4 plo[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};          // the lo-plane terms: two chains of their own
+            sk_stream<KS, RD>(lrd + (S::PSLOT0 + (j & 1)) * S::SLOT, [&](int ks, const uint4& w0, const uint4& w1) {
+                plo[0] = OpT<T>::mfma(as_v8<T>(w0), xl[0][ks], plo[0]);
+                plo[1] = OpT<T>::mfma(as_v8<T>(w1), xl[0][ks], plo[1]);
+                yacc[0][2 * j] = OpT<T>::mfma(as_v8<T>(w0), xh[0][ks], yacc[0][2 * j]);
+                yacc[0][2 * j + 1] = OpT<T>::mfma(as_v8<T>(w1), xh[0][ks], yacc[0][2 * j + 1]);
+            });
+            yacc[0][2 * j] += plo[0];
+            yacc[0][2 * j + 1] += plo[1];
+        } else
         sk_stream<KS, RD>(lrd + (S::PSLOT0 + (j & 1)) * S::SLOT, [&](int ks, const uint4& w0, const uint4& w1) {
             if constexpr (!S::ONE) {
 #pragma unroll
@@ -235,6 +262,18 @@ proj_mlp2_kernel(const Block2Args<T> a) {
     auto fc1 = [&](int slot) {                          // W1 chunk in `slot` -> hacc
 #pragma unroll
         for (int t = 0; t < FM; ++t) { hacc[t][0] = f32x4{0.f, 0.f, 0.f, 0.f}; hacc[t][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        if constexpr (kBlk2Chains4 && FM == 1 && !S::ONE) {
+            f32x4 hlo[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+            sk_stream<KS, RD, P_LDS>(lrd + slot * S::SLOT, [&](int ks, const uint4& w0, const uint4& w1) {
+                hlo[0] = OpT<T>::mfma(as_v8<T>(w0), xl[0][ks], hlo[0]);
+                hlo[1] = OpT<T>::mfma(as_v8<T>(w1), xl[0][ks], hlo[1]);
+                hacc[0][0] = OpT<T>::mfma(as_v8<T>(w0), xh[0][ks], hacc[0][0]);
+                hacc[0][1] = OpT<T>::mfma(as_v8<T>(w1), xh[0][ks], hacc[0][1]);
+            });
+            hacc[0][0] += hlo[0];
+            hacc[0][1] += hlo[1];
+            return;
+        }
         sk_stream<KS, RD, P_LDS>(lrd + slot * S::SLOT, [&](int ks, const uint4& w0, const uint4& w1) {
             if constexpr (!S::ONE) {
 #pragma unroll
@@ -263,6 +302,21 @@ proj_mlp2_kernel(const Block2Args<T> a) {
         }
     };
     auto fc2 = [&](int slot) {                          // W2 chunk in `slot`, operand hh / hl -> yacc
+        if constexpr (kBlk2Chains4 && FM == 1 && !S::ONE) {
+            uint4 pw0 = make_uint4(0, 0, 0, 0), pw1 = pw0;          // the fragment pair of step p - 1: its hi-plane terms follow step p's lo-plane terms
+            sk_stream<CF / 2, RD, P_LDS>(lrd + slot * S::SLOT, [&](int p, const uint4& w0, const uint4& w1) {
+                yacc[0][2 * p] = OpT<T>::mfma(as_v8<T>(w0), as_v8<T>(hl[0]), yacc[0][2 * p]);
+                yacc[0][2 * p + 1] = OpT<T>::mfma(as_v8<T>(w1), as_v8<T>(hl[0]), yacc[0][2 * p + 1]);
+                if (p > 0) {
+                    yacc[0][2 * p - 2] = OpT<T>::mfma(as_v8<T>(pw0), as_v8<T>(hh[0]), yacc[0][2 * p - 2]);
+                    yacc[0][2 * p - 1] = OpT<T>::mfma(as_v8<T>(pw1), as_v8<T>(hh[0]), yacc[0][2 * p - 1]);
+                }
+                pw0 = w0; pw1 = w1;
+            });
+            yacc[0][CF - 2] = OpT<T>::mfma(as_v8<T>(pw0), as_v8<T>(hh[0]), yacc[0][CF - 2]);
+            yacc[0][CF - 1] = OpT<T>::mfma(as_v8<T>(pw1), as_v8<T>(hh[0]), yacc[0][CF - 1]);
+            return;
+        }
         sk_stream<CF / 2, RD, P_LDS>(lrd + slot * S::SLOT, [&](int p, const uint4& w0, const uint4& w1) {
             if constexpr (!S::ONE) {
 #pragma unroll
