@@ -18,6 +18,9 @@ Switches (comma list in GCNUM_PLAN, default = the shipped plan):
     out_a        output MLP's operand / hidden one fp16 plane
     edge_w1_16 / edge_w2_16   only W_e of the processor / only the second Linear of the edge MLPs as one fp16 plane
     edge_w16     weights of the edge MLPs' GEMMs (W_e of the processor, fc2 everywhere) one fp16 plane (ONE MFMA term with edge_store / edge_hidden)
+    gridnode_w16 / gridnode_a / gridnode_hidden   the two GRID-node MLPs of the encoder / decoder only (1 M rows each at full size: 12 of the
+                 step's 55 ms): weights as one fp16 plane (two MFMA terms, half the bytes every workgroup streams) / fc1 operand / hidden one plane
+    meshnode_w16 the mesh-node MLPs (encoder + the 16 processor layers): weights as one fp16 plane
 """
 import os
 import sys
@@ -36,7 +39,7 @@ def f16(x):
     return x.to(torch.float16).to(x.dtype)
 
 
-def forward(p, graph, x_prev, x_cur, forcing, plan):
+def forward(p, graph, x_prev, x_cur, forcing, plan, taps=None):
     t = lambda a: torch.from_numpy(a).double()  # noqa: E731
     on = lambda k: k in plan  # noqa: E731
     rd = lambda k, x: f16(x) if on(k) else x  # noqa: E731
@@ -45,9 +48,14 @@ def forward(p, graph, x_prev, x_cur, forcing, plan):
     def ln(name, y):
         return F.layer_norm(y, (y.shape[-1],), p[name + ".ln.weight"], p[name + ".ln.bias"], 1e-5) if name + ".ln.weight" in p else y
 
-    def mlp(name, x, ka=None, kh=None):
-        h = F.silu(F.linear(rd(ka, x) if ka else x, p[name + ".fc1.weight"], p[name + ".fc1.bias"]))
-        return ln(name, F.linear(rd(kh, h) if kh else h, p[name + ".fc2.weight"], p[name + ".fc2.bias"]))
+    def mlp(name, x, ka=None, kh=None, kw=None, ka2=None, kh2=None):
+        w = lambda m: rd(kw, m) if kw else m  # noqa: E731
+        a = rd(ka2, x) if ka2 else x
+        h = F.silu(F.linear(rd(ka, a) if ka else a, w(p[name + ".fc1.weight"]), p[name + ".fc1.bias"]))
+        h = rd(kh2, h) if kh2 else h
+        if taps is not None:
+            taps[name + ".fc1"], taps[name + ".fc2"] = x, h
+        return ln(name, F.linear(rd(kh, h) if kh else h, w(p[name + ".fc2.weight"]), p[name + ".fc2.bias"]))
 
     def edge_mlp(name, e_term, vs, s_idx, vr, r_idx):
         """e_term: the (possibly stored) e W_e^T + b1 (+ folded receiver term); node terms by distributivity."""
@@ -73,19 +81,19 @@ def forward(p, graph, x_prev, x_cur, forcing, plan):
     w1 = p["g2m.edge.fc1.weight"]
     st1 = rd("static16", F.linear(e1, w1[:, :L], p["g2m.edge.fc1.bias"]) + F.linear(vm, w1[:, 2 * L:])[g2m[:, 1]])
     y1 = edge_mlp("g2m.edge", st1, vg, g2m[:, 0], None, None)
-    vm = vm + mlp("g2m.mesh_node", torch.cat([vm, agg(y1, g2m[:, 1], graph.n_mesh)], dim=1), "node_a", "node_hidden")
-    vg = vg + mlp("g2m.grid_node", vg, "node_a", "node_hidden")
+    vm = vm + mlp("g2m.mesh_node", torch.cat([vm, agg(y1, g2m[:, 1], graph.n_mesh)], dim=1), "node_a", "node_hidden", "meshnode_w16")
+    vg = vg + mlp("g2m.grid_node", vg, "node_a", "node_hidden", "gridnode_w16", "gridnode_a", "gridnode_hidden")
     em = rd("edge_store", em)
     for i in range(O.processor_steps(p)):
         name = f"proc.{i}.edge"
         w1 = p[name + ".fc1.weight"]
         de = edge_mlp(name, F.linear(em, rd("edge_w16", rd("edge_w1_16", w1[:, :L])), p[name + ".fc1.bias"]), vm, me[:, 0], vm, me[:, 1])
-        vm = vm + mlp(f"proc.{i}.node", torch.cat([vm, agg(de, me[:, 1], graph.n_mesh)], dim=1), "node_a", "node_hidden")
+        vm = vm + mlp(f"proc.{i}.node", torch.cat([vm, agg(de, me[:, 1], graph.n_mesh)], dim=1), "node_a", "node_hidden", "meshnode_w16")
         em = rd("edge_store", em + de)
     w1 = p["m2g.edge.fc1.weight"]
     st2 = rd("static16", F.linear(e2, w1[:, :L], p["m2g.edge.fc1.bias"]))
     y2 = edge_mlp("m2g.edge", st2, vm, m2g[:, 0], vg, m2g[:, 1])
-    vg = vg + mlp("m2g.grid_node", torch.cat([vg, agg(y2, m2g[:, 1], graph.n_grid)], dim=1), "node_a", "node_hidden")
+    vg = vg + mlp("m2g.grid_node", torch.cat([vg, agg(y2, m2g[:, 1], graph.n_grid)], dim=1), "node_a", "node_hidden", "gridnode_w16", "gridnode_a", "gridnode_hidden")
     out = mlp("out", vg, "out_a", "out_a")
     return x_cur + (out * p["norm.diff_std"][None, :]).T.reshape(x_cur.shape)
 
@@ -101,6 +109,29 @@ def main():
     ref = forward(p, og, x0, x1, fk, set())
     chk = O.forward({k: v.float() for k, v in p.items()}, og, x0.float(), x1.float(), fk.float()).double()      # the oracle proper (fp32)
     print(f"grid {n_lat}x{n_lon} M{splits} latent {latent} steps {steps}; emulation with no switch vs oracle: {O.increment_rel_err(ref, chk, x1).max().item():.2e}")
+    if os.environ.get("GCNUM_COMPENSATED"):
+        # the weights of the named MLPs as ONE fp16 plane, rounded with error feedback against the operand statistics of ANOTHER state pair
+        # (skyrim_amd/pangu/calibration.py: compensated_round + bias fold), nearest rounding beside it
+        from skyrim_amd.pangu.calibration import compensated_round, operand_statistics
+        names = os.environ["GCNUM_COMPENSATED"].split(",")
+        c0, c1 = (x.double() for x in synthetic_states(cfg, 1))
+        taps = {}
+        forward(p, og, c0, c1, forcings(cfg, 2000.0).double(), set(), taps)
+        for rounding in ("nearest", "nearest + bias fold", "compensated"):
+            q = dict(p)
+            for name in names:
+                for fc in ("fc1", "fc2"):
+                    w, b, x = p[f"{name}.{fc}.weight"], p[f"{name}.{fc}.bias"], taps[f"{name}.{fc}"]
+                    mu, cov = operand_statistics(x.float())
+                    wq = compensated_round(w.float(), cov + torch.outer(mu, mu)).double() if rounding == "compensated" else f16(w)
+                    q[f"{name}.{fc}.weight"] = wq
+                    if rounding != "nearest":
+                        q[f"{name}.{fc}.bias"] = b + (w - wq) @ mu
+            for label, plan in (("alone", set()), ("with the shipped plan", {"edge_store", "edge_hidden", "static16", "edge_w1_16"})):
+                y = forward(q, og, x0, x1, fk, plan)
+                print(f"  one-plane weights of {','.join(names)}, {rounding}, {label}: increment {O.increment_rel_err(y, ref, x1).max().item():.2e}   "
+                      f"per-channel {O.per_channel_rel_err(y, ref).max().item():.2e}", flush=True)
+        return
     shipped = os.environ.get("GCNUM_PLAN", "edge_store,edge_hidden,static16")
     every = [] if os.environ.get("GCNUM_ONLY") else ["edge_store", "edge_hidden", "static16", "nodeterm16", "nodeterm_a", "node_a", "node_hidden", "embed_a", "out_a", "edge_w16", "edge_w1_16", "edge_w2_16"]
     extra = [(k, {k}) for k in os.environ.get("GCNUM_ONLY", "").split(",") if k]
