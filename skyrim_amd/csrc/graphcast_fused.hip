@@ -748,6 +748,164 @@ node_mlp_kernel(const NodeArgs a) {
     }
 }
 
+#ifdef SKGC_NODE_V2
+// ---- node update, second form (build-time variant -DSKGC_NODE_V2, tools/node_v2.sh; NOT in the default build) ------------------------------ //
+// The first form holds a 16-row group's whole operand (128 registers of hi / lo fragments) and walks the hidden units chunk by chunk: every
+// 64 KiB stage of W1 feeds 96 MFMAs of ONE row group, and a stage costs ~4.5 k clocks against 1.5 k of matrix pipe (one wave per SIMD: the DMA
+// requests, the LDS read latency and the barrier are all exposed).  Here the first Linear runs K-OUTER on 2 x 16 rows per wave: the 512 hidden
+// pre-activations of both row groups are the accumulators (256 registers), a stage is ONE k-step of all 512 hidden units (fragment order
+// [ks][n = 32 unit groups][plane], fused.py: prep_w1_fragments_kouter) and feeds 192 MFMAs, the operand's 32 columns of the next k-step are loaded
+// and split while the current one computes.  Half the W1 stages per row.  The second Linear keeps the first form's loop, once per row group
+// (its LayerNorm needs a group's 512 outputs in registers, and two groups' outputs do not fit beside the hidden activations).
+template <int NS>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+node_mlp2_kernel(const NodeArgs a) {
+    constexpr int KS = FZ_KS, CF = FZ_CF, NCH = FZ_NCH, RD = FZ_RD, FM = 2;
+    typedef typename OpT<f16>::v8 v8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* tab = reinterpret_cast<float*>(smem + FZ_YBUF);            // b2 | gamma | beta | b1
+    const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned lds_base = (unsigned)(size_t)smem;
+    const char* lrd = smem + lane * 16;
+
+#pragma unroll
+    for (int k = 0; k < 16; ++k) fz_piece(a.w1f, lds_base, k, wave, lane, true);
+    for (int i = tid; i < FZ_L; i += 256) { tab[i] = a.b2[i]; tab[FZ_L + i] = a.gamma[i]; tab[2 * FZ_L + i] = a.beta[i]; tab[3 * FZ_L + i] = a.b1[i]; }
+
+    long long row[FM], rr[FM];
+    bool live[FM];
+#pragma unroll
+    for (int t = 0; t < FM; ++t) {
+        row[t] = (long long)blockIdx.x * FZ_TILE + wave * 32 + t * 16 + l15;
+        live[t] = row[t] < a.rows;
+        rr[t] = live[t] ? row[t] : a.rows - 1;
+    }
+    // hp[t][half][j]: first the accumulators of hidden units 32 j + 16 half + 4 g + r of row group t, then (after swish) the hi (half 0) / lo
+    // (half 1) fragment of k-step j of the second Linear -- the same registers, 8 fp32 <-> 2 x 8 fp16 as in the first form
+    f32x4 hp[FM][2][NCH];
+#pragma unroll
+    for (int t = 0; t < FM; ++t)
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) { hp[t][0][j] = f32x4{0.f, 0.f, 0.f, 0.f}; hp[t][1][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+    // the operand's columns of the first k-step
+    float4 u[FM][2];
+#pragma unroll
+    for (int t = 0; t < FM; ++t) {
+        const float* p = a.src[0] + rr[t] * a.ld[0] + 8 * g;
+        u[t][0] = *reinterpret_cast<const float4*>(p);
+        u[t][1] = *reinterpret_cast<const float4*>(p + 4);
+    }
+    int stage = 0;
+#pragma unroll 1
+    for (int it = 0; it < NS * KS; ++it) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                               // this k-step's weights and operand columns landed; every wave is done with the other stage
+        v8 xh[FM], xl[FM];
+#pragma unroll
+        for (int t = 0; t < FM; ++t) {
+            const float v[8] = {u[t][0].x, u[t][0].y, u[t][0].z, u[t][0].w, u[t][1].x, u[t][1].y, u[t][1].z, u[t][1].w};
+            fz_split8(v, xh[t], xl[t]);
+        }
+        const bool last = it + 1 == NS * KS;
+        {                                              // the next k-step's columns fly under this one's MFMAs (unconditional: a load inside a
+            const int nx = last ? it : it + 1;         //  branch makes hipcc wait vmcnt(0) at the join; the last k-step re-reads its own columns)
+            const int s1 = NS > 1 && nx >= KS ? 1 : 0, k1 = nx - s1 * KS;
+            const float* base = s1 ? a.src[NS - 1] : a.src[0];
+            const long long ld = s1 ? a.ld[NS - 1] : a.ld[0];
+#pragma unroll
+            for (int t = 0; t < FM; ++t) {
+                const float* p = base + rr[t] * ld + 32 * k1 + 8 * g;
+                u[t][0] = *reinterpret_cast<const float4*>(p);
+                u[t][1] = *reinterpret_cast<const float4*>(p + 4);
+            }
+        }
+        const f16* nsrc = last ? a.w2f : a.w1f + (long long)(it + 1) * (FZ_STAGE / 2);
+        const unsigned ndst = lds_base + (stage ^ 1) * FZ_STAGE;
+        // step q: unit groups 2 q, 2 q + 1 (= chunk q, halves 0 / 1), fragments [n][plane]; four accumulator chains x three terms
+        fz_steps<NCH, 4, RD>(lrd + stage * FZ_STAGE, [&](int q, const uint4 (&w)[4]) {
+            hp[0][0][q] = fz_mfma(w[0], xh[0], hp[0][0][q]);
+            hp[1][0][q] = fz_mfma(w[0], xh[1], hp[1][0][q]);
+            hp[0][1][q] = fz_mfma(w[2], xh[0], hp[0][1][q]);
+            hp[1][1][q] = fz_mfma(w[2], xh[1], hp[1][1][q]);
+            if (q < 8) fz_piece(nsrc, ndst, 2 * q, wave, lane);
+            hp[0][0][q] = fz_mfma(w[0], xl[0], hp[0][0][q]);
+            hp[1][0][q] = fz_mfma(w[0], xl[1], hp[1][0][q]);
+            hp[0][1][q] = fz_mfma(w[2], xl[0], hp[0][1][q]);
+            hp[1][1][q] = fz_mfma(w[2], xl[1], hp[1][1][q]);
+            if (q < 8) fz_piece(nsrc, ndst, 2 * q + 1, wave, lane);
+            hp[0][0][q] = fz_mfma(w[1], xh[0], hp[0][0][q]);
+            hp[1][0][q] = fz_mfma(w[1], xh[1], hp[1][0][q]);
+            hp[0][1][q] = fz_mfma(w[3], xh[0], hp[0][1][q]);
+            hp[1][1][q] = fz_mfma(w[3], xh[1], hp[1][1][q]);
+        });
+        stage ^= 1;
+    }
+    // + b1, swish, hi / lo split: the hidden fragments of both row groups (tab was filled before the first barrier)
+#pragma unroll
+    for (int t = 0; t < FM; ++t)
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const float4 b0 = *reinterpret_cast<const float4*>(tab + 3 * FZ_L + 32 * j + 4 * g), b1 = *reinterpret_cast<const float4*>(tab + 3 * FZ_L + 32 * j + 16 + 4 * g);
+            const f32x4 lo = hp[t][0][j], hi = hp[t][1][j];
+            const float v[8] = {swish_f(lo[0] + b0.x), swish_f(lo[1] + b0.y), swish_f(lo[2] + b0.z), swish_f(lo[3] + b0.w),
+                                swish_f(hi[0] + b1.x), swish_f(hi[1] + b1.y), swish_f(hi[2] + b1.z), swish_f(hi[3] + b1.w)};
+            f16x8 o0, o1;
+            fz_split8(v, o0, o1);
+            hp[t][0][j] = __builtin_bit_cast(f32x4, o0);
+            hp[t][1][j] = __builtin_bit_cast(f32x4, o1);
+        }
+
+    // second Linear + LayerNorm + residual, one row group after the other (W2 streams through the stages once per group)
+#pragma unroll
+    for (int t = 0; t < FM; ++t) {
+        f32x4 yacc[CF];
+#pragma unroll
+        for (int c = 0; c < CF; ++c) yacc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+        for (int j = 0; j < NCH; ++j) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            const bool more = !(t == FM - 1 && j == NCH - 1);
+            const f16* nsrc = j + 1 < NCH ? a.w2f + (long long)(j + 1) * (FZ_STAGE / 2) : a.w2f;      // (the next group starts over at chunk 0)
+            const unsigned ndst = lds_base + (stage ^ 1) * FZ_STAGE;
+            const v8 h = __builtin_bit_cast(v8, fz_pick(hp[t][0], j)), l = __builtin_bit_cast(v8, fz_pick(hp[t][1], j));
+            fz_steps<CF / 4, 8, RD>(lrd + stage * FZ_STAGE, [&](int q, const uint4 (&w)[8]) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) yacc[4 * q + i] = fz_mfma(w[2 * i + 1], h, yacc[4 * q + i]);
+                if (more && q < 4) { fz_piece(nsrc, ndst, 4 * q, wave, lane); fz_piece(nsrc, ndst, 4 * q + 1, wave, lane); }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) yacc[4 * q + i] = fz_mfma(w[2 * i], l, yacc[4 * q + i]);
+                if (more && q < 4) { fz_piece(nsrc, ndst, 4 * q + 2, wave, lane); fz_piece(nsrc, ndst, 4 * q + 3, wave, lane); }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) yacc[4 * q + i] = fz_mfma(w[2 * i], h, yacc[4 * q + i]);
+            });
+            stage ^= 1;
+        }
+        float4 r0[FZ_KS], r1[FZ_KS];
+        if (a.res != nullptr) {
+            const float* p = a.res + rr[t] * a.ld_res + 8 * g;
+#pragma unroll
+            for (int bp = 0; bp < FZ_KS; ++bp) { r0[bp] = *reinterpret_cast<const float4*>(p + 32 * bp); r1[bp] = *reinterpret_cast<const float4*>(p + 32 * bp + 4); }
+        } else {
+#pragma unroll
+            for (int bp = 0; bp < FZ_KS; ++bp) { r0[bp] = make_float4(0.f, 0.f, 0.f, 0.f); r1[bp] = r0[bp]; }
+        }
+        fz_layer_norm(yacc, tab, g, a.eps);
+        if (live[t]) {
+            float* dst = a.out + row[t] * a.ld_out + 8 * g;
+#pragma unroll
+            for (int bp = 0; bp < FZ_KS; ++bp) {
+                const f32x4 &x = yacc[2 * bp], &z = yacc[2 * bp + 1];
+                *reinterpret_cast<float4*>(dst + 32 * bp) = make_float4(r0[bp].x + x[0], r0[bp].y + x[1], r0[bp].z + x[2], r0[bp].w + x[3]);
+                *reinterpret_cast<float4*>(dst + 32 * bp + 4) = make_float4(r1[bp].x + z[0], r1[bp].y + z[1], r1[bp].z + z[2], r1[bp].w + z[3]);
+            }
+        }
+    }
+}
+#endif  // SKGC_NODE_V2
+
 }  // namespace skp
 
 using namespace skp;
@@ -814,7 +972,11 @@ int skgc_node_mlp(const skgc_node_desc* d, void* stream) {
     a.w1f = static_cast<const f16*>(d->w1f); a.w2f = static_cast<const f16*>(d->w2f);
     a.b1 = d->b1; a.b2 = d->b2; a.gamma = d->gamma; a.beta = d->beta;
     a.res = d->res; a.ld_res = d->ld_res; a.out = d->out; a.ld_out = d->ld_out; a.rows = d->rows; a.eps = 1e-5f;
+#ifdef SKGC_NODE_V2
+    const long long tiles = (d->rows + FZ_TILE - 1) / FZ_TILE;      // the variant library: K-outer first Linear on 128-row tiles, w1f in prep_w1_fragments_kouter order
+#else
     const long long tiles = (d->rows + 63) / 64;
+#endif
     if (tiles > 0x7fffffff) return SKGC_E_ARG;
     hipStream_t st = static_cast<hipStream_t>(stream);
     auto go = [&](auto kern) {
@@ -822,7 +984,11 @@ int skgc_node_mlp(const skgc_node_desc* d, void* stream) {
         hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), FZ_SMEM, st, a);
         return hipGetLastError() == hipSuccess ? 0 : SKGC_E_HIP;
     };
+#ifdef SKGC_NODE_V2
+    return d->n_src == 2 ? go(node_mlp2_kernel<2>) : go(node_mlp2_kernel<1>);
+#else
     return d->n_src == 2 ? go(node_mlp_kernel<2>) : go(node_mlp_kernel<1>);
+#endif
 }
 
 int skgc_segment_fixup(float* agg, const float* heads, const int* nodes, const int* first, const int* tiles, int n_nodes, void* stream) {

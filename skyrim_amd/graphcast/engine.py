@@ -135,6 +135,9 @@ class GraphcastEngine:
         self.fused = self.split_edges and not os.environ.get("SKGC_UNFUSED")
         # planes of the processor edge MLPs' first Linear (edge part): 1 = W_e as one fp16 plane (one MFMA term: +1.4e-4 of the predicted
         # increment at production width and depth, tools/graphcast_numerics.py), 2 = hi/lo planes (two terms)
+        # SKGC_NODE_V2=1: the node kernels' first Linear in K-outer fragment order -- ONLY together with a library built with -DSKGC_NODE_V2
+        # (SKYRIM_GRAPHCAST_LIB; tools/node_v2.sh): the second form of the node kernel, a measurement variant that is not in the default build
+        self.node_v2 = bool(os.environ.get("SKGC_NODE_V2"))
         self.w1_planes = int(os.environ.get("SKGC_W1_PLANES", "1"))
         if self.w1_planes not in (1, 2):
             raise ValueError("SKGC_W1_PLANES is 1 or 2")
@@ -325,7 +328,7 @@ class GraphcastEngine:
         F["m2g"]["zero_agg"] = bool((np.bincount(g.m2g_edges[:, 1], minlength=g.n_grid) == 0).any())
         # node updates: fragment-order weights, three-term kernel
         for name in ["g2m.mesh_node", "g2m.grid_node", "m2g.grid_node"] + [f"proc.{i}.node" for i in range(c.steps)]:
-            self.m[name]["w1f"] = _fz.prep_w1_fragments(f32(p[name + ".fc1.weight"]))
+            self.m[name]["w1f"] = _fz.prep_w1_node(f32(p[name + ".fc1.weight"]))
             self.m[name]["w2f"] = _fz.prep_w2_fragments(f32(p[name + ".fc2.weight"]))
         self.F = F
         del self.e1_0, self.e2_0

@@ -144,6 +144,29 @@ def prep_w1_fragments(w1: torch.Tensor, planes: int = 2) -> torch.Tensor:
     return torch.cat(out)
 
 
+def prep_w1_fragments_kouter(w1: torch.Tensor, planes: int = 2) -> torch.Tensor:
+    """The same 1 KiB blocks as ``prep_w1_fragments`` in K-OUTER order, for the second form of the node kernel (csrc/graphcast_fused.hip,
+    build-time variant SKGC_NODE_V2): per source, block ((ks 32 + n) planes + p) with n = 2 j + half the 16-unit group -- one LDS stage
+    (64 KiB with two planes, H = 512) = ONE k-step of all hidden units."""
+    H, K = w1.shape
+    if H != 512 or K % 512:
+        raise ValueError("prep_w1_fragments_kouter: [512][512 n_src]")
+    per = (H // 32) * 16 * 2 * planes * 512                        # elements per source
+    flat = prep_w1_fragments(w1, planes)
+    out = []
+    for s in range(K // 512):
+        blk = flat[s * per:(s + 1) * per].reshape(H // 32, 16, 2, planes, 512)     # [j][ks][half][p][lane * 8 + e]
+        out.append(blk.permute(1, 0, 2, 3, 4).contiguous().reshape(-1))           # [ks][j][half][p]
+    return torch.cat(out)
+
+
+def prep_w1_node(w1: torch.Tensor) -> torch.Tensor:
+    """The node kernel's first Linear in the order the loaded library's node kernel reads: the first form's chunk order, or -- SKGC_NODE_V2=1,
+    together with a library built with -DSKGC_NODE_V2 -- the K-outer order of its second form."""
+    import os
+    return prep_w1_fragments_kouter(w1) if os.environ.get("SKGC_NODE_V2") else prep_w1_fragments(w1)
+
+
 def prep_w2_fragments(w2: torch.Tensor, planes: int = 2) -> torch.Tensor:
     """Second-Linear weight [N][H] (N % 32 == 0, H % 32 == 0) -> fragment order, flat fp16:
         block (j CF + c) planes + p,  [lane][e] = plane_p( w2[perm8_col(16 c + (lane & 15))][32 j + 16 (e >> 2) + 4 (lane >> 4) + (e & 3)] )

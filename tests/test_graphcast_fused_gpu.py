@@ -107,7 +107,7 @@ def test_node_mlp_vs_float64(n_src, rows):
     y = _ln(torch.nn.functional.silu(x @ w1.double().T + b1.double()) @ w2.double().T + b2.double(), gamma.double(), beta.double())
     want = srcs[0].double() + y
     sd = [s.to(dev) for s in srcs]
-    w1f, w2f = fz.prep_w1_fragments(w1.to(dev)), fz.prep_w2_fragments(w2.to(dev))
+    w1f, w2f = fz.prep_w1_node(w1.to(dev)), fz.prep_w2_fragments(w2.to(dev))
     tab = [t.to(dev) for t in (b1, b2, gamma, beta)]
     out = torch.full((rows + 3, L), 7.0, device=dev)                                               # rows beyond `rows` must stay untouched
     ops.hip.gc_node_mlp(sd, [0] * n_src, [L] * n_src, w1f, w2f, *tab, sd[0], 0, L, out, 0, L, rows)
@@ -130,7 +130,7 @@ def test_hi_lo_split_is_consistent_for_every_element():
     rows, dev = 4096, torch.device("cuda:0")
     x = (3.0 * torch.randn(rows, L, generator=gen, dtype=torch.float64)).float()
     eye, zero, one = torch.eye(L), torch.zeros(L), torch.ones(L)
-    w1f, w2f = fz.prep_w1_fragments(eye.to(dev)), fz.prep_w2_fragments(eye.to(dev))
+    w1f, w2f = fz.prep_w1_node(eye.to(dev)), fz.prep_w2_fragments(eye.to(dev))
     out = torch.zeros(rows, L, device=dev)
     ops.hip.gc_node_mlp([x.to(dev)], [0], [L], w1f, w2f, zero.to(dev), zero.to(dev), one.to(dev), zero.to(dev), None, 0, L, out, 0, L, rows)
     torch.cuda.synchronize()

@@ -268,3 +268,43 @@ def test_node_kernel_index_algebra():
         for i in range(8):
             got[L15, 32 * bp + 8 * G + i] = (yacc[2 * bp] if i < 4 else yacc[2 * bp + 1])[:, i & 3]
     assert np.abs(got - z).max() < 1e-9
+
+
+def test_node_kernel_second_form_index_algebra():
+    """node_mlp2_kernel (build-time variant SKGC_NODE_V2): the first Linear K-OUTER on two row groups -- a stage = one k-step of all 512 hidden
+    units in [n][plane] order (prep_w1_fragments_kouter), the accumulators hp[t][half][j] are the hidden units 32 j + 16 half + 4 g + r and
+    become the second Linear's k-step-j fragments in place -- then the first form's second Linear, one row group after the other."""
+    rng = np.random.default_rng(4)
+    x = rng.normal(size=(32, 2 * L)); w1 = rng.normal(size=(L, 2 * L)) / np.sqrt(2 * L); w2 = rng.normal(size=(L, L)) / np.sqrt(L)
+    b1 = rng.normal(size=L) * 0.1
+    w1k, w2f = _frag64(fz.prep_w1_fragments_kouter, w1), _frag64(fz.prep_w2_fragments, w2)
+    hp = np.zeros((2, 2, 16, 64, 4))                               # [t][half][j][lane][r]
+    for it in range(32):                                           # (source, k-step): one 64 KiB stage each
+        s, ks = divmod(it, 16)
+        xk = [x[16 * t + L15][np.arange(64)[:, None], 512 * s + 32 * ks + 8 * G[:, None] + np.arange(8)[None, :]] for t in range(2)]
+        for q in range(16):                                        # step q: unit groups 2 q, 2 q + 1 = chunk q, halves 0 / 1
+            for half in range(2):
+                blk = it * 64 + (q * 2 + half) * 2
+                w = frag(w1k, blk) + frag(w1k, blk + 1)
+                for t in range(2):
+                    hp[t][half][q] = mfma(w, xk[t], hp[t][half][q])
+    z = swish(x @ w1.T + b1) @ w2.T
+    for t in range(2):
+        hh = np.zeros((16, 64, 8))
+        for j in range(16):
+            hh[j][:, :4] = swish(hp[t][0][j] + b1[32 * j + 4 * G[:, None] + np.arange(4)[None, :]])
+            hh[j][:, 4:] = swish(hp[t][1][j] + b1[32 * j + 16 + 4 * G[:, None] + np.arange(4)[None, :]])
+        yacc = np.zeros((32, 64, 4))
+        for j in range(16):
+            for q in range(8):
+                for i in range(4):
+                    blk = j * 64 + q * 8 + i * 2
+                    yacc[4 * q + i] = mfma(frag(w2f, blk) + frag(w2f, blk + 1), hh[j], yacc[4 * q + i])
+        got = np.zeros((16, L))
+        for bp in range(16):
+            for i in range(8):
+                got[L15, 32 * bp + 8 * G + i] = (yacc[2 * bp] if i < 4 else yacc[2 * bp + 1])[:, i & 3]
+        assert np.abs(got - z[16 * t:16 * t + 16]).max() < 1e-9, t
+    # the K-outer order is a permutation of the first form's blocks
+    a, b = fz.prep_w1_fragments(torch.from_numpy(w1).float()), fz.prep_w1_fragments_kouter(torch.from_numpy(w1).float())
+    assert a.numel() == b.numel() and torch.equal(torch.sort(a.reshape(-1, 512).float().sum(1))[0], torch.sort(b.reshape(-1, 512).float().sum(1))[0])
