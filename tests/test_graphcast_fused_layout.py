@@ -308,3 +308,42 @@ def test_node_kernel_second_form_index_algebra():
     # the K-outer order is a permutation of the first form's blocks
     a, b = fz.prep_w1_fragments(torch.from_numpy(w1).float()), fz.prep_w1_fragments_kouter(torch.from_numpy(w1).float())
     assert a.numel() == b.numel() and torch.equal(torch.sort(a.reshape(-1, 512).float().sum(1))[0], torch.sort(b.reshape(-1, 512).float().sum(1))[0])
+
+
+def test_node_kernel_third_form_index_algebra():
+    """node_mlp3_kernel (build-time variant SKGC_NODE_V3): the hidden units in two halves -- first Linear of a half K-outer (32 KiB stages in
+    prep_w1_fragments_khalves order, accumulators hq[t][hh][q] = units 256 half + 32 q + 16 hh + 4 g + r), swish, then that half's chunks of the
+    second Linear into BOTH row groups' output accumulators."""
+    rng = np.random.default_rng(5)
+    x = rng.normal(size=(32, 2 * L)); w1 = rng.normal(size=(L, 2 * L)) / np.sqrt(2 * L); w2 = rng.normal(size=(L, L)) / np.sqrt(L)
+    b1 = rng.normal(size=L) * 0.1
+    w1h, w2f = _frag64(fz.prep_w1_fragments_khalves, w1), _frag64(fz.prep_w2_fragments, w2)
+    yacc = np.zeros((2, 32, 64, 4))
+    for half in range(2):
+        hq = np.zeros((2, 2, 8, 64, 4))
+        for it in range(32):                                       # (source, k-step): one 32 KiB stage = 32 blocks
+            s, ks = divmod(it, 16)
+            xk = [x[16 * t + L15][np.arange(64)[:, None], 512 * s + 32 * ks + 8 * G[:, None] + np.arange(8)[None, :]] for t in range(2)]
+            for q in range(8):
+                for hh in range(2):
+                    blk = (half * 32 + it) * 32 + (q * 2 + hh) * 2
+                    w = frag(w1h, blk) + frag(w1h, blk + 1)
+                    for t in range(2):
+                        hq[t][hh][q] = mfma(w, xk[t], hq[t][hh][q])
+        for q in range(8):
+            j = 8 * half + q
+            for t in range(2):
+                hfrag = np.zeros((64, 8))
+                hfrag[:, :4] = swish(hq[t][0][q] + b1[32 * j + 4 * G[:, None] + np.arange(4)[None, :]])
+                hfrag[:, 4:] = swish(hq[t][1][q] + b1[32 * j + 16 + 4 * G[:, None] + np.arange(4)[None, :]])
+                for c4 in range(8):
+                    for i in range(4):
+                        blk = j * 64 + c4 * 8 + i * 2
+                        yacc[t][4 * c4 + i] = mfma(frag(w2f, blk) + frag(w2f, blk + 1), hfrag, yacc[t][4 * c4 + i])
+    z = swish(x @ w1.T + b1) @ w2.T
+    for t in range(2):
+        got = np.zeros((16, L))
+        for bp in range(16):
+            for i in range(8):
+                got[L15, 32 * bp + 8 * G + i] = (yacc[t][2 * bp] if i < 4 else yacc[t][2 * bp + 1])[:, i & 3]
+        assert np.abs(got - z[16 * t:16 * t + 16]).max() < 1e-9, t
