@@ -347,3 +347,21 @@ def test_node_kernel_third_form_index_algebra():
             for i in range(8):
                 got[L15, 32 * bp + 8 * G + i] = (yacc[t][2 * bp] if i < 4 else yacc[t][2 * bp + 1])[:, i & 3]
         assert np.abs(got - z[16 * t:16 * t + 16]).max() < 1e-9, t
+
+
+def test_prep_w1_node_follows_the_variant_switches(monkeypatch):
+    """fused.prep_w1_node: the first form's order by default; SKGC_NODE_V2 / SKGC_NODE_V3 (set together with a variant library) select the
+    K-outer orders -- all three are permutations of the same 1 KiB blocks."""
+    w = torch.randn(512, 1024, generator=torch.Generator().manual_seed(0))
+    for k in ("SKGC_NODE_V2", "SKGC_NODE_V3"):
+        monkeypatch.delenv(k, raising=False)
+    base = fz.prep_w1_node(w)
+    assert torch.equal(base, fz.prep_w1_fragments(w))
+    monkeypatch.setenv("SKGC_NODE_V2", "1")
+    v2 = fz.prep_w1_node(w)
+    assert torch.equal(v2, fz.prep_w1_fragments_kouter(w)) and not torch.equal(v2, base)
+    monkeypatch.setenv("SKGC_NODE_V3", "1")
+    v3 = fz.prep_w1_node(w)
+    assert torch.equal(v3, fz.prep_w1_fragments_khalves(w)) and not torch.equal(v3, v2)
+    key = lambda t: sorted(map(bytes, t.reshape(-1, 512).numpy().view(np.uint8)))  # noqa: E731
+    assert key(base) == key(v2) == key(v3)
