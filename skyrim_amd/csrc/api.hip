@@ -423,7 +423,10 @@ struct Engine : IEngine {
         if constexpr (std::is_same<P, PrecF16x3>::value) {
             if (two_term(layer0)) {               // ... with two MFMA terms and the halves of the workgroup half a chunk apart
                 mark(C_FC1_0 + o, s);
-                CK(op_proj_mlp_skew(g, bw, w.winv[res][i & 1], res, xs, wk, s, block_one(layer0)));
+                const char* wv = getenv("SKP_BLK_WIDE");                   // bit res: wide row tiles (read per launch: round-5 A/B script)
+                const int wide = wv ? atoi(wv) : 0;
+                if ((wide >> res) & 1) CK(op_proj_mlp_wide(g, bw, w.winv[res][i & 1], res, xs, wk, s, block_one(layer0)));
+                else CK(op_proj_mlp_skew(g, bw, w.winv[res][i & 1], res, xs, wk, s, block_one(layer0)));
                 mark(-1, s);
                 return hipSuccess;
             }

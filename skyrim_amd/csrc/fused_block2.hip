@@ -29,7 +29,7 @@
 // 5 % SLOWER.  With two waves per SIMD the partner wave's MFMAs fill the dependent-issue gaps (graphcast_fused.hip runs ONE wave per SIMD, where
 // they are exposed); what the variant adds -- 168 bytes more scratch per lane, the accumulator adds -- is pure cost here.  Not built by default.
 #include <cstdlib>
-#include "gemm_dma.h"
+#include "blockrow.h"
 #include "launchers.h"
 
 namespace skp {
@@ -61,44 +61,6 @@ struct Blk2Shape {
     static_assert((2 * SLOT_KIB) % NWAVES == 0 && NPB % 2 == 0 && NCH >= 3 && !(SKEW_ && DUO_), "DMA pieces per wave; even projection block count");
     static_assert(SMEM <= (DUO_ ? 80 : 160) * 1024, "LDS");
 };
-
-template <class T>
-struct Block2Args {
-    const T* ao; long long ao_plane;       // attention output, window-ordered rows, blocked layout, hi / lo planes
-    int M;                                 // stream tokens (multiple of 16)
-    T* xs; long long xs_plane;             // residual stream planes, blocked layout
-    const int* winv;                       // stream token -> window row of the attention output
-    const T *projh, *w1h, *w2h;            // fragment-order weights, hi plane only (prep_rowtile_weights / prep_mlp_weights with planes = 1)
-    const float *proj_b, *g1, *e1, *b1, *b2, *g2, *e2;
-    float eps;
-};
-
-// two consecutive 1 KiB fragments; the scheduling barrier pins the reads HERE in program order (fused_mlp.hip: ld_pair)
-__device__ __forceinline__ void sk_ld2(const char* p, uint4 (&w)[2]) {
-    w[0] = *reinterpret_cast<const uint4*>(p);
-    w[1] = *reinterpret_cast<const uint4*>(p + 1024);
-    __builtin_amdgcn_sched_barrier(0);
-}
-
-// NP fragment pairs at consecutive KiB of `st`, through a ring of RD register pairs read RD - 1 pairs ahead of their MFMAs
-template <int NP, int RD, bool ONE = false, class Body>
-__device__ __forceinline__ void sk_stream(const char* st, Body&& body) {
-    uint4 ring[RD][2];
-    if constexpr (ONE) {                         // probe: one pair read, every step computes on it
-        sk_ld2(st, ring[0]);
-#pragma unroll
-        for (int p = 0; p < NP; ++p) { body(p, ring[0][0], ring[0][1]); __builtin_amdgcn_sched_barrier(0); }
-        return;
-    }
-#pragma unroll
-    for (int p = 0; p < RD - 1 && p < NP; ++p) sk_ld2(st + (p << 11), ring[p % RD]);
-#pragma unroll
-    for (int p = 0; p < NP; ++p) {
-        if (p + RD - 1 < NP) sk_ld2(st + ((p + RD - 1) << 11), ring[(p + RD - 1) % RD]);
-        body(p, ring[p % RD][0], ring[p % RD][1]);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
 
 template <class T, class S>
 __global__ void __launch_bounds__(S::THREADS) __attribute__((amdgpu_waves_per_eu(2, 2)))

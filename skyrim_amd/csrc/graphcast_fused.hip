@@ -586,10 +586,15 @@ __global__ void __launch_bounds__(128) segment_fixup_kernel(float* __restrict__ 
 
 // ---- node update:  out = res + LayerNorm(W2 swish(W1 concat(src...) + b1) + b2)  on fp32 rows, three MFMA terms ------------------------ //
 // The node latents are the network's residual streams; rounding them (or the node MLPs' hidden activations) to one fp16 plane costs
-// 4-5e-4 of the predicted increment (tools/graphcast_numerics.py), so this form splits every fp32 operand into fp16 hi/lo fragments on the
-// fly: A W^T ~ A_hi W_lo^T + A_lo W_hi^T + A_hi W_hi^T.  One 16-row group per wave, 64 rows per tile.  Concatenated sources are taken one
-// after the other (W1 = [W1_0 | W1_1], prepared source by source): after source 0 the 512 partial pre-activations wait in the registers
-// that become the hidden fragments after the last source, so a wave never holds more than one source's 128 operand registers.
+// 4-5e-4 of the predicted increment (tools/graphcast_numerics.py), so the kernel splits every fp32 operand into fp16 hi/lo fragments on the
+// fly: A W^T ~ A_hi W_lo^T + A_lo W_hi^T + A_hi W_hi^T.  128-row tiles, 2 x 16 rows per wave.  The first Linear runs K-OUTER: the 512 hidden
+// pre-activations of both row groups are the accumulators (256 registers), a 64 KiB LDS stage is ONE k-step of all 512 hidden units (fragment
+// order [source][ks][n = 32 unit groups][plane], fused.py: prep_w1_fragments_kouter) and feeds 192 MFMAs; the operand's 32 columns of the next
+// k-step are loaded and split while the current one computes; concatenated sources are further k-steps.  The second Linear walks W2 chunk by
+// chunk once per row group (its LayerNorm needs a group's 512 outputs in registers, and two groups' outputs do not fit beside the hidden
+// activations).  Round 5, 1 038 240 rows: 4.07 ms (one source) / 5.21 ms (two) against 4.71 / 6.76 ms for the form that held one row group's
+// whole operand and walked the hidden units chunk by chunk (96 MFMAs per stage), 41 k rows: 0.24 / 0.32 against 0.22 / 0.32; a third form
+// (hidden units in two halves, every stage against both row groups) measured 4.66 / 6.30 and 0.29 / 0.38 (docs/experiments.md).
 struct NodeArgs {
     const float* src[2];    // fp32 rows, 512 columns each (concatenated along K)
     long long ld[2];
@@ -606,160 +611,6 @@ struct NodeArgs {
 template <int NS>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 node_mlp_kernel(const NodeArgs a) {
-    constexpr int KS = FZ_KS, CF = FZ_CF, NCH = FZ_NCH, RD = FZ_RD;
-    typedef typename OpT<f16>::v8 v8;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* tab = reinterpret_cast<float*>(smem + FZ_YBUF);            // b2 | gamma | beta | b1
-    const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, g = lane >> 4;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const unsigned lds_base = (unsigned)(size_t)smem;
-    const char* lrd = smem + lane * 16;
-
-#pragma unroll
-    for (int k = 0; k < 16; ++k) fz_piece(a.w1f, lds_base, k, wave, lane, true);
-    for (int i = tid; i < FZ_L; i += 256) { tab[i] = a.b2[i]; tab[FZ_L + i] = a.gamma[i]; tab[2 * FZ_L + i] = a.beta[i]; tab[3 * FZ_L + i] = a.b1[i]; }
-
-    const long long row = (long long)blockIdx.x * 64 + wave * 16 + l15;
-    const bool live = row < a.rows;
-    const long long rr = live ? row : a.rows - 1;
-
-    // part[j]: chunk j's 2 x 4 pre-activations after the sources so far; after the last source the same registers hold the hidden
-    // activation's hi / lo fragments (bit patterns: 8 fp32 <-> 2 x 8 fp16)
-    f32x4 part[2][NCH];
-    static_assert(NCH == 16, "fz_pick / fz_put");
-    int stage = 0;                                                    // LDS stage of the chunk being read
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-        v8 xh[KS], xl[KS];
-        {
-            const float* p = a.src[s] + rr * a.ld[s] + 8 * g;
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const float4 u0 = *reinterpret_cast<const float4*>(p + 32 * ks), u1 = *reinterpret_cast<const float4*>(p + 32 * ks + 4);
-                const float v[8] = {u0.x, u0.y, u0.z, u0.w, u1.x, u1.y, u1.z, u1.w};
-                fz_split8(v, xh[ks], xl[ks]);
-            }
-        }
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) { asm volatile("" : "+v"(xh[ks])); asm volatile("" : "+v"(xl[ks])); }
-#pragma unroll 1
-        for (int j = 0; j < NCH; ++j) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();                           // this chunk's weights landed; every wave is done with the other stage
-            const bool last = s == NS - 1 && j == NCH - 1;
-            const f16* nsrc = last ? a.w2f : a.w1f + (long long)(s * NCH + j + 1) * (FZ_STAGE / 2);
-            const unsigned ndst = lds_base + (stage ^ 1) * FZ_STAGE;
-            // four accumulator chains: 16-unit half n x parity of the k-step; a step = two k-steps = 8 fragments [ks][n][plane]
-            f32x4 acc[2][2];
-            if (s == 0) {
-                const float4 b0 = *reinterpret_cast<const float4*>(tab + 3 * FZ_L + 32 * j + 4 * g), b1 = *reinterpret_cast<const float4*>(tab + 3 * FZ_L + 32 * j + 16 + 4 * g);
-                acc[0][0] = f32x4{b0.x, b0.y, b0.z, b0.w};
-                acc[1][0] = f32x4{b1.x, b1.y, b1.z, b1.w};
-            } else {
-                acc[0][0] = fz_pick(part[0], j);
-                acc[1][0] = fz_pick(part[1], j);
-            }
-            acc[0][1] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[1][1] = acc[0][1];
-            if (FZ_DBG & 1) {
-#pragma unroll
-                for (int k = 0; k < 16; ++k) fz_piece(nsrc, ndst, k, wave, lane);
-            }
-            fz_steps<KS / 2, 8, (FZ_DBG & 4) ? 1 : RD>(lrd + stage * FZ_STAGE, [&](int q, const uint4 (&w)[8]) {
-                const int k0 = 2 * q, k1 = 2 * q + 1;
-                acc[0][0] = fz_mfma(w[1], xh[k0], acc[0][0]);
-                acc[1][0] = fz_mfma(w[3], xh[k0], acc[1][0]);
-                acc[0][1] = fz_mfma(w[5], xh[k1], acc[0][1]);
-                acc[1][1] = fz_mfma(w[7], xh[k1], acc[1][1]);
-                if (q < 4 && !(FZ_DBG & 1)) { fz_piece(nsrc, ndst, 4 * q, wave, lane); fz_piece(nsrc, ndst, 4 * q + 1, wave, lane); }
-                acc[0][0] = fz_mfma(w[0], xl[k0], acc[0][0]);
-                acc[1][0] = fz_mfma(w[2], xl[k0], acc[1][0]);
-                acc[0][1] = fz_mfma(w[4], xl[k1], acc[0][1]);
-                acc[1][1] = fz_mfma(w[6], xl[k1], acc[1][1]);
-                if (q < 4 && !(FZ_DBG & 1)) { fz_piece(nsrc, ndst, 4 * q + 2, wave, lane); fz_piece(nsrc, ndst, 4 * q + 3, wave, lane); }
-                acc[0][0] = fz_mfma(w[0], xh[k0], acc[0][0]);
-                acc[1][0] = fz_mfma(w[2], xh[k0], acc[1][0]);
-                acc[0][1] = fz_mfma(w[4], xh[k1], acc[0][1]);
-                acc[1][1] = fz_mfma(w[6], xh[k1], acc[1][1]);
-            });
-            f32x4 lo = acc[0][0] + acc[0][1], hi = acc[1][0] + acc[1][1];
-            if (s == NS - 1) {                          // swish, hi / lo split: the hidden fragments of k-step j of the second Linear
-                float v[8];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { v[r] = swish_f(lo[r]); v[4 + r] = swish_f(hi[r]); }
-                f16x8 o0, o1;
-                fz_split8(v, o0, o1);
-                lo = __builtin_bit_cast(f32x4, o0);
-                hi = __builtin_bit_cast(f32x4, o1);
-            }
-            fz_put(part[0], j, lo);
-            fz_put(part[1], j, hi);
-            stage ^= 1;
-        }
-    }
-
-    f32x4 yacc[CF];
-#pragma unroll
-    for (int c = 0; c < CF; ++c) yacc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
-    for (int j = 0; j < NCH; ++j) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        const bool more = j + 1 < NCH;
-        const f16* nsrc = a.w2f + (long long)(j + 1) * (FZ_STAGE / 2);
-        const unsigned ndst = lds_base + (stage ^ 1) * FZ_STAGE;
-        const v8 h = __builtin_bit_cast(v8, fz_pick(part[0], j)), l = __builtin_bit_cast(v8, fz_pick(part[1], j));
-        if ((FZ_DBG & 1) && more) {
-#pragma unroll
-            for (int k = 0; k < 16; ++k) fz_piece(nsrc, ndst, k, wave, lane);
-        }
-        // step q: output fragments 4 q .. 4 q + 3 (hi, lo planes each): four accumulator chains, three terms each
-        fz_steps<CF / 4, 8, (FZ_DBG & 4) ? 1 : RD>(lrd + stage * FZ_STAGE, [&](int q, const uint4 (&w)[8]) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) yacc[4 * q + i] = fz_mfma(w[2 * i + 1], h, yacc[4 * q + i]);
-            if (more && q < 4 && !(FZ_DBG & 1)) { fz_piece(nsrc, ndst, 4 * q, wave, lane); fz_piece(nsrc, ndst, 4 * q + 1, wave, lane); }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) yacc[4 * q + i] = fz_mfma(w[2 * i], l, yacc[4 * q + i]);
-            if (more && q < 4 && !(FZ_DBG & 1)) { fz_piece(nsrc, ndst, 4 * q + 2, wave, lane); fz_piece(nsrc, ndst, 4 * q + 3, wave, lane); }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) yacc[4 * q + i] = fz_mfma(w[2 * i], h, yacc[4 * q + i]);
-        });
-        stage ^= 1;
-    }
-
-    // epilogue: all loads before the first store (epilogues.h: stores share the VMEM counter with loads)
-    float4 r0[FZ_KS], r1[FZ_KS];
-    if (a.res != nullptr) {
-        const float* p = a.res + rr * a.ld_res + 8 * g;
-#pragma unroll
-        for (int bp = 0; bp < FZ_KS; ++bp) { r0[bp] = *reinterpret_cast<const float4*>(p + 32 * bp); r1[bp] = *reinterpret_cast<const float4*>(p + 32 * bp + 4); }
-    } else {
-#pragma unroll
-        for (int bp = 0; bp < FZ_KS; ++bp) { r0[bp] = make_float4(0.f, 0.f, 0.f, 0.f); r1[bp] = r0[bp]; }
-    }
-    fz_layer_norm(yacc, tab, g, a.eps);
-    if (live) {
-        float* dst = a.out + row * a.ld_out + 8 * g;
-#pragma unroll
-        for (int bp = 0; bp < FZ_KS; ++bp) {
-            const f32x4 &x = yacc[2 * bp], &z = yacc[2 * bp + 1];
-            *reinterpret_cast<float4*>(dst + 32 * bp) = make_float4(r0[bp].x + x[0], r0[bp].y + x[1], r0[bp].z + x[2], r0[bp].w + x[3]);
-            *reinterpret_cast<float4*>(dst + 32 * bp + 4) = make_float4(r1[bp].x + z[0], r1[bp].y + z[1], r1[bp].z + z[2], r1[bp].w + z[3]);
-        }
-    }
-}
-
-#ifdef SKGC_NODE_V2
-// ---- node update, second form (build-time variant -DSKGC_NODE_V2, tools/node_v2.sh; NOT in the default build) ------------------------------ //
-// The first form holds a 16-row group's whole operand (128 registers of hi / lo fragments) and walks the hidden units chunk by chunk: every
-// 64 KiB stage of W1 feeds 96 MFMAs of ONE row group, and a stage costs ~4.5 k clocks against 1.5 k of matrix pipe (one wave per SIMD: the DMA
-// requests, the LDS read latency and the barrier are all exposed).  Here the first Linear runs K-OUTER on 2 x 16 rows per wave: the 512 hidden
-// pre-activations of both row groups are the accumulators (256 registers), a stage is ONE k-step of all 512 hidden units (fragment order
-// [ks][n = 32 unit groups][plane], fused.py: prep_w1_fragments_kouter) and feeds 192 MFMAs, the operand's 32 columns of the next k-step are loaded
-// and split while the current one computes.  Half the W1 stages per row.  The second Linear keeps the first form's loop, once per row group
-// (its LayerNorm needs a group's 512 outputs in registers, and two groups' outputs do not fit beside the hidden activations).
-template <int NS>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
-node_mlp2_kernel(const NodeArgs a) {
     constexpr int KS = FZ_KS, CF = FZ_CF, NCH = FZ_NCH, RD = FZ_RD, FM = 2;
     typedef typename OpT<f16>::v8 v8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -904,185 +755,6 @@ node_mlp2_kernel(const NodeArgs a) {
         }
     }
 }
-#endif  // SKGC_NODE_V2
-
-#ifdef SKGC_NODE_V3
-// ---- node update, third form (build-time variant -DSKGC_NODE_V3, tools/node_v2.sh v3; NOT in the default build) ---------------------------- //
-// Every weight stage feeds BOTH row groups of a wave (192 MFMAs per 64 KiB everywhere; the first form: 96).  What stops the second form from
-// doing that in the second Linear is registers: two groups' 512 outputs (256) beside two groups' 512 hidden activations (256).  Here the hidden
-// units go in two HALVES: first Linear of units [0, 256) K-outer (accumulators = 128 registers, a stage = one k-step of 256 units, 32 KiB),
-// swish, then their share of the second Linear (W2's chunks 0 .. 7, whole 64 KiB stages) into the 2 x 512 output accumulators; then the same for
-// units [256, 512).  Live at any time: 256 output accumulators + 128 registers of the current half.  The operand's columns are read once per
-// half (twice in all: 4 KiB per row out of L2).  Weight order: fused.py prep_w1_fragments_khalves ([half][source][ks][n][plane]).
-#define FZ_CASES8(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
-template <class V>
-__device__ __forceinline__ V fz_pick8(const V (&a)[8], int j) {
-    V r = a[0];
-    switch (j) {
-#define X(i) case i: r = a[i]; asm volatile("" : "+v"(r)); break;
-        FZ_CASES8(X)
-#undef X
-        default: break;
-    }
-    return r;
-}
-
-template <int NS>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
-node_mlp3_kernel(const NodeArgs a) {
-    constexpr int KS = FZ_KS, CF = FZ_CF, RD = FZ_RD, FM = 2, HCH = FZ_NCH / 2;      // HCH: chunks of 32 hidden units per half
-    constexpr int HSTAGE = FZ_STAGE / 2;                                             // a first-Linear stage: one k-step of 256 units, 32 KiB
-    typedef typename OpT<f16>::v8 v8;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* tab = reinterpret_cast<float*>(smem + FZ_YBUF);            // b2 | gamma | beta | b1
-    const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, g = lane >> 4;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const unsigned lds_base = (unsigned)(size_t)smem;
-    const char* lrd = smem + lane * 16;
-
-#pragma unroll
-    for (int k = 0; k < 8; ++k) fz_piece(a.w1f, lds_base, k, wave, lane, true);
-    for (int i = tid; i < FZ_L; i += 256) { tab[i] = a.b2[i]; tab[FZ_L + i] = a.gamma[i]; tab[2 * FZ_L + i] = a.beta[i]; tab[3 * FZ_L + i] = a.b1[i]; }
-
-    long long row[FM], rr[FM];
-    bool live[FM];
-#pragma unroll
-    for (int t = 0; t < FM; ++t) {
-        row[t] = (long long)blockIdx.x * FZ_TILE + wave * 32 + t * 16 + l15;
-        live[t] = row[t] < a.rows;
-        rr[t] = live[t] ? row[t] : a.rows - 1;
-    }
-    f32x4 yacc[FM][CF];
-#pragma unroll
-    for (int t = 0; t < FM; ++t)
-#pragma unroll
-        for (int c = 0; c < CF; ++c) yacc[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    int stage = 0;
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        // hq[t][hh][q]: accumulators of hidden units 256 half + 32 q + 16 hh + 4 g + r, then the hi (hh 0) / lo (hh 1) fragment of k-step 8 half + q
-        f32x4 hq[FM][2][HCH];
-#pragma unroll
-        for (int t = 0; t < FM; ++t)
-#pragma unroll
-            for (int q = 0; q < HCH; ++q) { hq[t][0][q] = f32x4{0.f, 0.f, 0.f, 0.f}; hq[t][1][q] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-        float4 u[FM][2];
-#pragma unroll
-        for (int t = 0; t < FM; ++t) {
-            const float* p = a.src[0] + rr[t] * a.ld[0] + 8 * g;
-            u[t][0] = *reinterpret_cast<const float4*>(p);
-            u[t][1] = *reinterpret_cast<const float4*>(p + 4);
-        }
-        const f16* w1h = a.w1f + (long long)half * (NS * KS) * (HSTAGE / 2);          // this half's stages: [source][ks], 32 KiB each
-#pragma unroll 1
-        for (int it = 0; it < NS * KS; ++it) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            v8 xh[FM], xl[FM];
-#pragma unroll
-            for (int t = 0; t < FM; ++t) {
-                const float v[8] = {u[t][0].x, u[t][0].y, u[t][0].z, u[t][0].w, u[t][1].x, u[t][1].y, u[t][1].z, u[t][1].w};
-                fz_split8(v, xh[t], xl[t]);
-            }
-            const bool last = it + 1 == NS * KS;
-            {
-                const int nx = last ? it : it + 1;
-                const int s1 = NS > 1 && nx >= KS ? 1 : 0, k1 = nx - s1 * KS;
-                const float* base = s1 ? a.src[NS - 1] : a.src[0];
-                const long long ld = s1 ? a.ld[NS - 1] : a.ld[0];
-#pragma unroll
-                for (int t = 0; t < FM; ++t) {
-                    const float* p = base + rr[t] * ld + 32 * k1 + 8 * g;
-                    u[t][0] = *reinterpret_cast<const float4*>(p);
-                    u[t][1] = *reinterpret_cast<const float4*>(p + 4);
-                }
-            }
-            // next: this half's next k-step (32 KiB: 8 pieces per wave) or, after the last one, W2's first chunk of this half (64 KiB: 16 pieces)
-            const f16* nsrc = last ? a.w2f + (long long)(half * HCH) * (FZ_STAGE / 2) : w1h + (long long)(it + 1) * (HSTAGE / 2);
-            const unsigned ndst = lds_base + (stage ^ 1) * FZ_STAGE;
-            fz_steps<HCH, 4, RD>(lrd + stage * FZ_STAGE, [&](int q, const uint4 (&w)[4]) {
-                hq[0][0][q] = fz_mfma(w[0], xh[0], hq[0][0][q]);
-                hq[1][0][q] = fz_mfma(w[0], xh[1], hq[1][0][q]);
-                hq[0][1][q] = fz_mfma(w[2], xh[0], hq[0][1][q]);
-                hq[1][1][q] = fz_mfma(w[2], xh[1], hq[1][1][q]);
-                fz_piece(nsrc, ndst, q, wave, lane);
-                hq[0][0][q] = fz_mfma(w[0], xl[0], hq[0][0][q]);
-                hq[1][0][q] = fz_mfma(w[0], xl[1], hq[1][0][q]);
-                hq[0][1][q] = fz_mfma(w[2], xl[0], hq[0][1][q]);
-                hq[1][1][q] = fz_mfma(w[2], xl[1], hq[1][1][q]);
-                if (last) fz_piece(nsrc, ndst, 8 + q, wave, lane);
-                hq[0][0][q] = fz_mfma(w[1], xh[0], hq[0][0][q]);
-                hq[1][0][q] = fz_mfma(w[1], xh[1], hq[1][0][q]);
-                hq[0][1][q] = fz_mfma(w[3], xh[0], hq[0][1][q]);
-                hq[1][1][q] = fz_mfma(w[3], xh[1], hq[1][1][q]);
-            });
-            stage ^= 1;
-        }
-#pragma unroll
-        for (int t = 0; t < FM; ++t)
-#pragma unroll
-            for (int q = 0; q < HCH; ++q) {
-                const int j = half * HCH + q;
-                const float4 b0 = *reinterpret_cast<const float4*>(tab + 3 * FZ_L + 32 * j + 4 * g), b1 = *reinterpret_cast<const float4*>(tab + 3 * FZ_L + 32 * j + 16 + 4 * g);
-                const f32x4 lo = hq[t][0][q], hi = hq[t][1][q];
-                const float v[8] = {swish_f(lo[0] + b0.x), swish_f(lo[1] + b0.y), swish_f(lo[2] + b0.z), swish_f(lo[3] + b0.w),
-                                    swish_f(hi[0] + b1.x), swish_f(hi[1] + b1.y), swish_f(hi[2] + b1.z), swish_f(hi[3] + b1.w)};
-                f16x8 o0, o1;
-                fz_split8(v, o0, o1);
-                hq[t][0][q] = __builtin_bit_cast(f32x4, o0);
-                hq[t][1][q] = __builtin_bit_cast(f32x4, o1);
-            }
-        // this half's share of the second Linear: k-steps 8 half .. 8 half + 7, every fragment against both row groups
-#pragma unroll 1
-        for (int q = 0; q < HCH; ++q) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            const int j = half * HCH + q;
-            const bool wlast = q + 1 == HCH;                       // after this half's last chunk: the other half's first k-step (32 KiB), or nothing
-            const bool more = !(wlast && half == 1);
-            const f16* nsrc = wlast ? a.w1f + (long long)(NS * KS) * (HSTAGE / 2) : a.w2f + (long long)(j + 1) * (FZ_STAGE / 2);
-            const unsigned ndst = lds_base + (stage ^ 1) * FZ_STAGE;
-            const v8 h0 = __builtin_bit_cast(v8, fz_pick8(hq[0][0], q)), l0 = __builtin_bit_cast(v8, fz_pick8(hq[0][1], q));
-            const v8 h1 = __builtin_bit_cast(v8, fz_pick8(hq[1][0], q)), l1 = __builtin_bit_cast(v8, fz_pick8(hq[1][1], q));
-            fz_steps<CF / 4, 8, RD>(lrd + stage * FZ_STAGE, [&](int c4, const uint4 (&w)[8]) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) { yacc[0][4 * c4 + i] = fz_mfma(w[2 * i + 1], h0, yacc[0][4 * c4 + i]); yacc[1][4 * c4 + i] = fz_mfma(w[2 * i + 1], h1, yacc[1][4 * c4 + i]); }
-                if (more) fz_piece(nsrc, ndst, c4, wave, lane);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) { yacc[0][4 * c4 + i] = fz_mfma(w[2 * i], l0, yacc[0][4 * c4 + i]); yacc[1][4 * c4 + i] = fz_mfma(w[2 * i], l1, yacc[1][4 * c4 + i]); }
-                if (more && !wlast) fz_piece(nsrc, ndst, 8 + c4, wave, lane);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) { yacc[0][4 * c4 + i] = fz_mfma(w[2 * i], h0, yacc[0][4 * c4 + i]); yacc[1][4 * c4 + i] = fz_mfma(w[2 * i], h1, yacc[1][4 * c4 + i]); }
-            });
-            stage ^= 1;
-        }
-    }
-
-#pragma unroll
-    for (int t = 0; t < FM; ++t) {
-        float4 r0[FZ_KS], r1[FZ_KS];
-        if (a.res != nullptr) {
-            const float* p = a.res + rr[t] * a.ld_res + 8 * g;
-#pragma unroll
-            for (int bp = 0; bp < FZ_KS; ++bp) { r0[bp] = *reinterpret_cast<const float4*>(p + 32 * bp); r1[bp] = *reinterpret_cast<const float4*>(p + 32 * bp + 4); }
-        } else {
-#pragma unroll
-            for (int bp = 0; bp < FZ_KS; ++bp) { r0[bp] = make_float4(0.f, 0.f, 0.f, 0.f); r1[bp] = r0[bp]; }
-        }
-        fz_layer_norm(yacc[t], tab, g, a.eps);
-        if (live[t]) {
-            float* dst = a.out + row[t] * a.ld_out + 8 * g;
-#pragma unroll
-            for (int bp = 0; bp < FZ_KS; ++bp) {
-                const f32x4 &x = yacc[t][2 * bp], &z = yacc[t][2 * bp + 1];
-                *reinterpret_cast<float4*>(dst + 32 * bp) = make_float4(r0[bp].x + x[0], r0[bp].y + x[1], r0[bp].z + x[2], r0[bp].w + x[3]);
-                *reinterpret_cast<float4*>(dst + 32 * bp + 4) = make_float4(r1[bp].x + z[0], r1[bp].y + z[1], r1[bp].z + z[2], r1[bp].w + z[3]);
-            }
-        }
-    }
-}
-#endif  // SKGC_NODE_V3
 
 }  // namespace skp
 
@@ -1150,11 +822,7 @@ int skgc_node_mlp(const skgc_node_desc* d, void* stream) {
     a.w1f = static_cast<const f16*>(d->w1f); a.w2f = static_cast<const f16*>(d->w2f);
     a.b1 = d->b1; a.b2 = d->b2; a.gamma = d->gamma; a.beta = d->beta;
     a.res = d->res; a.ld_res = d->ld_res; a.out = d->out; a.ld_out = d->ld_out; a.rows = d->rows; a.eps = 1e-5f;
-#if defined(SKGC_NODE_V2) || defined(SKGC_NODE_V3)
-    const long long tiles = (d->rows + FZ_TILE - 1) / FZ_TILE;      // the variant libraries: 128-row tiles, w1f in prep_w1_fragments_kouter / _khalves order
-#else
-    const long long tiles = (d->rows + 63) / 64;
-#endif
+    const long long tiles = (d->rows + FZ_TILE - 1) / FZ_TILE;
     if (tiles > 0x7fffffff) return SKGC_E_ARG;
     hipStream_t st = static_cast<hipStream_t>(stream);
     auto go = [&](auto kern) {
@@ -1162,13 +830,7 @@ int skgc_node_mlp(const skgc_node_desc* d, void* stream) {
         hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), FZ_SMEM, st, a);
         return hipGetLastError() == hipSuccess ? 0 : SKGC_E_HIP;
     };
-#if defined(SKGC_NODE_V3)
-    return d->n_src == 2 ? go(node_mlp3_kernel<2>) : go(node_mlp3_kernel<1>);
-#elif defined(SKGC_NODE_V2)
-    return d->n_src == 2 ? go(node_mlp2_kernel<2>) : go(node_mlp2_kernel<1>);
-#else
     return d->n_src == 2 ? go(node_mlp_kernel<2>) : go(node_mlp_kernel<1>);
-#endif
 }
 
 int skgc_segment_fixup(float* agg, const float* heads, const int* nodes, const int* first, const int* tiles, int n_nodes, void* stream) {

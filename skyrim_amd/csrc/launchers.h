@@ -103,6 +103,8 @@ template <class T> hipError_t prep_rowtile_weights(const float* w, T* wf, int N,
 template <class P> hipError_t op_proj_mlp_fused(const Geom&, const BlockW<typename P::T>&, const int* winv, int res, typename P::T* Xs, const Work<P>&, hipStream_t);
 // the same with TWO MFMA terms (weights as one fp16 plane) and the two waves of a SIMD half a chunk apart (fused_block2.hip)
 hipError_t op_proj_mlp_skew(const Geom&, const BlockW<f16>&, const int* winv, int res, f16* Xs, const Work<PrecF16x3>&, hipStream_t, int one = 0);   // one: the activation operands as one fp16 plane too
+// the same on WIDE row tiles: one wave per SIMD, 32 / 64 rows per wave, persistent workgroups (fused_block_wide.hip)
+hipError_t op_proj_mlp_wide(const Geom&, const BlockW<f16>&, const int* winv, int res, f16* Xs, const Work<PrecF16x3>&, hipStream_t, int one = 0);
 template <class T, int NPL> hipError_t split_planes(const float* x, T* planes, long long plane, long long n, int C, hipStream_t);
 template <class T> hipError_t merge_planes(const T* planes, long long plane, float* x, long long n, int C, hipStream_t);
 

@@ -135,10 +135,6 @@ class GraphcastEngine:
         self.fused = self.split_edges and not os.environ.get("SKGC_UNFUSED")
         # planes of the processor edge MLPs' first Linear (edge part): 1 = W_e as one fp16 plane (one MFMA term: +1.4e-4 of the predicted
         # increment at production width and depth, tools/graphcast_numerics.py), 2 = hi/lo planes (two terms)
-        # SKGC_NODE_V2=1 / SKGC_NODE_V3=1: the node kernels' first Linear in the fragment order of their second / third form (fused.py:
-        # prep_w1_node) -- ONLY together with a library built with -DSKGC_NODE_V2 / -DSKGC_NODE_V3 (SKYRIM_GRAPHCAST_LIB; tools/node_v2.sh):
-        # measurement variants that are not in the default build
-        self.node_form = 3 if os.environ.get("SKGC_NODE_V3") else 2 if os.environ.get("SKGC_NODE_V2") else 1
         self.w1_planes = int(os.environ.get("SKGC_W1_PLANES", "1"))
         if self.w1_planes not in (1, 2):
             raise ValueError("SKGC_W1_PLANES is 1 or 2")

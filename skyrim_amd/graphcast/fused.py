@@ -145,9 +145,9 @@ def prep_w1_fragments(w1: torch.Tensor, planes: int = 2) -> torch.Tensor:
 
 
 def prep_w1_fragments_kouter(w1: torch.Tensor, planes: int = 2) -> torch.Tensor:
-    """The same 1 KiB blocks as ``prep_w1_fragments`` in K-OUTER order, for the second form of the node kernel (csrc/graphcast_fused.hip,
-    build-time variant SKGC_NODE_V2): per source, block ((ks 32 + n) planes + p) with n = 2 j + half the 16-unit group -- one LDS stage
-    (64 KiB with two planes, H = 512) = ONE k-step of all hidden units."""
+    """The same 1 KiB blocks as ``prep_w1_fragments`` in K-OUTER order, for the node kernel (csrc/graphcast_fused.hip: node_mlp_kernel): per
+    source, block ((ks 32 + n) planes + p) with n = 2 j + half the 16-unit group -- one LDS stage (64 KiB with two planes, H = 512) = ONE
+    k-step of all hidden units."""
     H, K = w1.shape
     if H != 512 or K % 512:
         raise ValueError("prep_w1_fragments_kouter: [512][512 n_src]")
@@ -160,26 +160,9 @@ def prep_w1_fragments_kouter(w1: torch.Tensor, planes: int = 2) -> torch.Tensor:
     return torch.cat(out)
 
 
-def prep_w1_fragments_khalves(w1: torch.Tensor, planes: int = 2) -> torch.Tensor:
-    """K-outer order in two HALVES of the hidden units, for the third form of the node kernel (build-time variant SKGC_NODE_V3):
-    block ((((half n_src + s) 16 + ks) 8 + q) 2 + hh) planes + p  =  the first form's block of chunk j = 8 half + q -- a stage = one k-step
-    of one half's 256 hidden units (32 KiB with two planes), all of a half's stages before the other half's."""
-    H, K = w1.shape
-    if H != 512 or K % 512:
-        raise ValueError("prep_w1_fragments_khalves: [512][512 n_src]")
-    per = (H // 32) * 16 * 2 * planes * 512
-    flat = prep_w1_fragments(w1, planes)
-    src = [flat[s * per:(s + 1) * per].reshape(2, 8, 16, 2, planes, 512).permute(0, 2, 1, 3, 4, 5) for s in range(K // 512)]   # [half][ks][q][hh][p]
-    return torch.cat([src[s][half].contiguous().reshape(-1) for half in range(2) for s in range(K // 512)])
-
-
 def prep_w1_node(w1: torch.Tensor) -> torch.Tensor:
-    """The node kernel's first Linear in the order the loaded library's node kernel reads: the first form's chunk order, or -- SKGC_NODE_V2=1 /
-    SKGC_NODE_V3=1, together with a library built with -DSKGC_NODE_V2 / -DSKGC_NODE_V3 -- the order of its second / third form."""
-    import os
-    if os.environ.get("SKGC_NODE_V3"):
-        return prep_w1_fragments_khalves(w1)
-    return prep_w1_fragments_kouter(w1) if os.environ.get("SKGC_NODE_V2") else prep_w1_fragments(w1)
+    """The node kernel's first Linear, hi/lo planes, in the order ``skgc_node_mlp`` reads (K-outer)."""
+    return prep_w1_fragments_kouter(w1)
 
 
 def prep_w2_fragments(w2: torch.Tensor, planes: int = 2) -> torch.Tensor:

@@ -121,14 +121,33 @@ def forcings(cfg: GraphcastConfig, hours_since_epoch: float) -> torch.Tensor:
     return torch.stack(out).float().contiguous()
 
 
-def flops_per_step(cfg: GraphcastConfig, n_grid: int, n_mesh: int, e_mesh: int, e_g2m: int, e_m2g: int) -> float:
-    """Dense FLOPs of the input-dependent MLPs (2 d_in L + 2 L d_out per row)."""
+def flops_per_stage(cfg: GraphcastConfig, n_grid: int, n_mesh: int, e_mesh: int, e_g2m: int, e_m2g: int, executed: bool = False) -> dict:
+    """Dense FLOPs of the input-dependent MLPs (2 d_in L + 2 L d_out per row), per stage of the step (bench.py's stage names).
+    ``executed=False``: the network as published -- every edge MLP on its concatenated 3L-wide row.  ``executed=True``: what the engine runs
+    for the same result, the first Linear of every edge MLP taken apart by distributivity (engine.py: node terms once per node,
+    input-independent edge terms once per model)."""
     L = cfg.latent
+    lin = lambda rows, d_in, d_out: 2.0 * rows * d_in * d_out  # noqa: E731
     mlp = lambda rows, d_in, d_out: 2.0 * rows * (d_in * L + L * d_out)  # noqa: E731
-    f = mlp(n_grid, cfg.grid_in, L) + mlp(e_g2m, 3 * L, L) + mlp(n_mesh, 2 * L, L) + mlp(n_grid, L, L)
-    f += cfg.steps * (mlp(e_mesh, 3 * L, L) + mlp(n_mesh, 2 * L, L))
-    f += mlp(e_m2g, 3 * L, L) + mlp(n_grid, 2 * L, L) + mlp(n_grid, L, cfg.n_vars)
-    return f
+    if executed:
+        st = {"embed": mlp(n_grid, cfg.grid_in, L),
+              # grid->mesh edges: sender term per grid node + second Linear per edge; encoder node updates
+              "encoder": lin(n_grid, L, L) + lin(e_g2m, L, L) + mlp(n_mesh, 2 * L, L) + mlp(n_grid, L, L),
+              "processor": cfg.steps * (lin(e_mesh, L, L) + lin(n_mesh, L, 2 * L) + lin(e_mesh, L, L) + mlp(n_mesh, 2 * L, L)),
+              "decoder": lin(n_mesh, L, L) + lin(n_grid, L, L) + lin(e_m2g, L, L) + mlp(n_grid, 2 * L, L),
+              "output": mlp(n_grid, L, cfg.n_vars)}
+    else:
+        st = {"embed": mlp(n_grid, cfg.grid_in, L),
+              "encoder": mlp(e_g2m, 3 * L, L) + mlp(n_mesh, 2 * L, L) + mlp(n_grid, L, L),
+              "processor": cfg.steps * (mlp(e_mesh, 3 * L, L) + mlp(n_mesh, 2 * L, L)),
+              "decoder": mlp(e_m2g, 3 * L, L) + mlp(n_grid, 2 * L, L),
+              "output": mlp(n_grid, L, cfg.n_vars)}
+    return {k: float(v) for k, v in st.items()}
+
+
+def flops_per_step(cfg: GraphcastConfig, n_grid: int, n_mesh: int, e_mesh: int, e_g2m: int, e_m2g: int) -> float:
+    """Dense FLOPs of one step of the network as published."""
+    return sum(flops_per_stage(cfg, n_grid, n_mesh, e_mesh, e_g2m, e_m2g).values())
 
 
 def alg_bytes_per_step(cfg: GraphcastConfig, n_grid: int, n_mesh: int, e_mesh: int, e_g2m: int, e_m2g: int, latent_bytes: int = 4, edge_bytes: int | None = None) -> dict:
@@ -156,15 +175,5 @@ def alg_bytes_per_step(cfg: GraphcastConfig, n_grid: int, n_mesh: int, e_mesh: i
 
 
 def flops_per_step_executed(cfg: GraphcastConfig, n_grid: int, n_mesh: int, e_mesh: int, e_g2m: int, e_m2g: int) -> float:
-    """FLOPs the engine actually executes for the same result: the first Linear of every edge MLP taken apart by distributivity
-    (engine.py: node terms once per node, input-independent edge terms once per model), everything else as in ``flops_per_step``."""
-    L = cfg.latent
-    lin = lambda rows, d_in, d_out: 2.0 * rows * d_in * d_out  # noqa: E731
-    mlp = lambda rows, d_in, d_out: 2.0 * rows * (d_in * L + L * d_out)  # noqa: E731
-    f = mlp(n_grid, cfg.grid_in, L)                                                   # grid embedder
-    f += lin(n_grid, L, L) + lin(e_g2m, L, L)                                         # grid->mesh edges: sender term per grid node + second Linear
-    f += mlp(n_mesh, 2 * L, L) + mlp(n_grid, L, L)                                    # encoder node updates
-    f += cfg.steps * (lin(e_mesh, L, L) + lin(n_mesh, L, 2 * L) + lin(e_mesh, L, L) + mlp(n_mesh, 2 * L, L))
-    f += lin(n_mesh, L, L) + lin(n_grid, L, L) + lin(e_m2g, L, L)                     # mesh->grid edges
-    f += mlp(n_grid, 2 * L, L) + mlp(n_grid, L, cfg.n_vars)
-    return f
+    """FLOPs the engine actually executes for the same result (``flops_per_stage(..., executed=True)``)."""
+    return sum(flops_per_stage(cfg, n_grid, n_mesh, e_mesh, e_g2m, e_m2g, executed=True).values())

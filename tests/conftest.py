@@ -17,26 +17,51 @@ os.environ.setdefault("SKYRIM_SYNTHETIC_WEIGHTS", "1")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # a GPU run: the full-size oracle jobs start NOW (tests/_oracle_jobs.py; Pangu's rollout, the longest, first) -- they compute in host
+    # processes while pytest collects and the small-grid parity tests run
+    expr = getattr(config.option, "markexpr", "") or ""
+    if "gpu" in expr and "not gpu" not in expr and os.environ.get("SKYRIM_TEST_ORACLE_JOBS", "1") != "0" and not config.option.collectonly:
+        import torch
+        if torch.cuda.is_available():
+            import _oracle_jobs
+            _oracle_jobs.start(list(_oracle_jobs.WANTED_BY))
+
+
+# Collection order of the GPU suite (the driver runs `pytest -x`: whatever fails first hides the rest, so the parity evidence goes first):
+#   0  small-grid oracle parity of the three default modes (the native library test first)
+#   1  the full-size comparisons with the oracles (BASELINE.json's sizes; each waits for its host job -- SFNO's is ready first)
+#   2  everything else, in file order
+_TIER0 = ("test_pangu_gpu.py::test_native_library_is_the_path_that_runs[{d}]", "test_pangu_gpu.py::test_full_step_per_channel[{d}]",
+          "test_pangu_gpu.py::test_step_matches_golden_fixture[{d}]", "test_pangu_gpu.py::test_earth_specific_block[{d}-",
+          "test_sfno_gpu.py::test_step_vs_oracle_per_channel[", "test_sfno_gpu.py::test_step_matches_golden_fixture",
+          "test_graphcast_gpu.py::test_step_vs_oracle[", "test_graphcast_gpu.py::test_matches_golden_fixture")
+_TIER1 = ("test_pangu_gpu.py::test_full_size_step_vs_oracle", "test_sfno_gpu.py::test_full_size", "test_graphcast_gpu.py::test_full_size",
+          "test_pangu_gpu.py::test_full_size_24h_rollout", "test_pangu_gpu.py::test_full_size_term_plans", "test_pangu_gpu.py::test_full_size")
+
+
+def _tier(nodeid, default_mode):
+    for t, frags in enumerate((_TIER0, _TIER1)):
+        for rank, f in enumerate(frags):
+            if f.format(d=default_mode) in nodeid:
+                return t, rank
+    return 2, 0
 
 
 def pytest_collection_modifyitems(config, items):
-    """The full-size oracle comparisons run last: their oracle results come from host processes started when collection finishes
-    (tests/_oracle_jobs.py, four minutes of host time), and every other GPU test runs while those compute."""
-    last = [i for i in items if "_gpu.py::test_full_size" in i.nodeid]
-    if last:
-        items[:] = [i for i in items if "_gpu.py::test_full_size" not in i.nodeid] + last
+    if not any("_gpu.py::" in i.nodeid for i in items):
+        return
+    from skyrim_amd.pangu.engine import DEFAULT_PRECISION
+    order = {id(i): (*_tier(i.nodeid, DEFAULT_PRECISION), n) for n, i in enumerate(items)}
+    items.sort(key=lambda i: order[id(i)])
 
 
 def pytest_collection_finish(session):
-    """The full-size oracle runs the selected GPU tests will ask for start now, in host processes of their own (tests/_oracle_jobs.py)."""
+    """Oracle jobs that no selected test asks for stop here."""
+    mod = sys.modules.get("_oracle_jobs")
+    if mod is None:
+        return
     ids = [item.nodeid for item in session.items]
-    if not any("_gpu.py::test_full_size" in i for i in ids):
-        return
-    import torch
-    if not torch.cuda.is_available() or os.environ.get("SKYRIM_TEST_ORACLE_JOBS", "1") == "0":
-        return
-    import _oracle_jobs
-    _oracle_jobs.start([k for k, frags in _oracle_jobs.WANTED_BY.items() if any(f in i for f in frags for i in ids)])
+    mod.stop([k for k, frags in mod.WANTED_BY.items() if not any(f in i for f in frags for i in ids)])
 
 
 def pytest_sessionfinish(session, exitstatus):

@@ -230,50 +230,10 @@ def _frag64(prep, w):
 
 
 def test_node_kernel_index_algebra():
-    """node_mlp_kernel with two sources: source by source against W1 = [W1_0 | W1_1] (a chunk = 64 KiB of [ks][n][plane] blocks, two k-steps
-    per step with split accumulators), partial pre-activations carried between the sources; epilogue rows are fp32 row-major."""
-    rng = np.random.default_rng(3)
-    x = rng.normal(size=(16, 2 * L)); w1 = rng.normal(size=(L, 2 * L)) / np.sqrt(2 * L); w2 = rng.normal(size=(L, L)) / np.sqrt(L)
-    b1, b2, gamma, beta = (rng.normal(size=L) * 0.1 for _ in range(4))
-    w1f, w2f = _frag64(fz.prep_w1_fragments, w1), _frag64(fz.prep_w2_fragments, w2)
-    part = np.zeros((16, 2, 64, 4))
-    for s in range(2):
-        xh = np.stack([x[L15][np.arange(64)[:, None], 512 * s + 32 * ks + 8 * G[:, None] + np.arange(8)[None, :]] for ks in range(16)])
-        for j in range(16):
-            acc = np.zeros((2, 2, 64, 4))                          # [n][parity of ks]
-            if s == 0:
-                acc[0][0] = b1[32 * j + 4 * G[:, None] + np.arange(4)[None, :]]
-                acc[1][0] = b1[32 * j + 16 + 4 * G[:, None] + np.arange(4)[None, :]]
-            else:
-                acc[0][0], acc[1][0] = part[j][0], part[j][1]
-            for q in range(8):
-                for kk in range(2):
-                    ks = 2 * q + kk
-                    for n in range(2):
-                        blk = (s * 16 + j) * 64 + q * 8 + (kk * 2 + n) * 2
-                        acc[n][kk] = mfma(frag(w1f, blk) + frag(w1f, blk + 1), xh[ks], acc[n][kk])
-            part[j][0], part[j][1] = acc[0][0] + acc[0][1], acc[1][0] + acc[1][1]
-    hh = np.zeros((16, 64, 8))
-    for j in range(16):
-        hh[j][:, :4], hh[j][:, 4:] = swish(part[j][0]), swish(part[j][1])
-    yacc = np.zeros((32, 64, 4))
-    for j in range(16):
-        for q in range(8):
-            for i in range(4):
-                blk = j * 64 + q * 8 + i * 2
-                yacc[4 * q + i] = mfma(frag(w2f, blk) + frag(w2f, blk + 1), hh[j], yacc[4 * q + i])
-    z = swish(x @ w1.T + b1) @ w2.T
-    got = np.zeros((16, L))
-    for bp in range(16):
-        for i in range(8):
-            got[L15, 32 * bp + 8 * G + i] = (yacc[2 * bp] if i < 4 else yacc[2 * bp + 1])[:, i & 3]
-    assert np.abs(got - z).max() < 1e-9
-
-
-def test_node_kernel_second_form_index_algebra():
-    """node_mlp2_kernel (build-time variant SKGC_NODE_V2): the first Linear K-OUTER on two row groups -- a stage = one k-step of all 512 hidden
-    units in [n][plane] order (prep_w1_fragments_kouter), the accumulators hp[t][half][j] are the hidden units 32 j + 16 half + 4 g + r and
-    become the second Linear's k-step-j fragments in place -- then the first form's second Linear, one row group after the other."""
+    """node_mlp_kernel with two sources: the first Linear K-OUTER on two row groups -- a stage = one k-step of all 512 hidden units in
+    [n][plane] order (prep_w1_fragments_kouter), concatenated sources are further k-steps; the accumulators hp[t][half][j] are the hidden
+    units 32 j + 16 half + 4 g + r and become the second Linear's k-step-j fragments in place -- then the second Linear chunk by chunk, one
+    row group after the other; epilogue rows are fp32 row-major."""
     rng = np.random.default_rng(4)
     x = rng.normal(size=(32, 2 * L)); w1 = rng.normal(size=(L, 2 * L)) / np.sqrt(2 * L); w2 = rng.normal(size=(L, L)) / np.sqrt(L)
     b1 = rng.normal(size=L) * 0.1
@@ -305,63 +265,15 @@ def test_node_kernel_second_form_index_algebra():
             for i in range(8):
                 got[L15, 32 * bp + 8 * G + i] = (yacc[2 * bp] if i < 4 else yacc[2 * bp + 1])[:, i & 3]
         assert np.abs(got - z[16 * t:16 * t + 16]).max() < 1e-9, t
-    # the K-outer order is a permutation of the first form's blocks
+    # the K-outer order is a permutation of the chunk order's blocks
     a, b = fz.prep_w1_fragments(torch.from_numpy(w1).float()), fz.prep_w1_fragments_kouter(torch.from_numpy(w1).float())
     assert a.numel() == b.numel() and torch.equal(torch.sort(a.reshape(-1, 512).float().sum(1))[0], torch.sort(b.reshape(-1, 512).float().sum(1))[0])
 
 
-def test_node_kernel_third_form_index_algebra():
-    """node_mlp3_kernel (build-time variant SKGC_NODE_V3): the hidden units in two halves -- first Linear of a half K-outer (32 KiB stages in
-    prep_w1_fragments_khalves order, accumulators hq[t][hh][q] = units 256 half + 32 q + 16 hh + 4 g + r), swish, then that half's chunks of the
-    second Linear into BOTH row groups' output accumulators."""
-    rng = np.random.default_rng(5)
-    x = rng.normal(size=(32, 2 * L)); w1 = rng.normal(size=(L, 2 * L)) / np.sqrt(2 * L); w2 = rng.normal(size=(L, L)) / np.sqrt(L)
-    b1 = rng.normal(size=L) * 0.1
-    w1h, w2f = _frag64(fz.prep_w1_fragments_khalves, w1), _frag64(fz.prep_w2_fragments, w2)
-    yacc = np.zeros((2, 32, 64, 4))
-    for half in range(2):
-        hq = np.zeros((2, 2, 8, 64, 4))
-        for it in range(32):                                       # (source, k-step): one 32 KiB stage = 32 blocks
-            s, ks = divmod(it, 16)
-            xk = [x[16 * t + L15][np.arange(64)[:, None], 512 * s + 32 * ks + 8 * G[:, None] + np.arange(8)[None, :]] for t in range(2)]
-            for q in range(8):
-                for hh in range(2):
-                    blk = (half * 32 + it) * 32 + (q * 2 + hh) * 2
-                    w = frag(w1h, blk) + frag(w1h, blk + 1)
-                    for t in range(2):
-                        hq[t][hh][q] = mfma(w, xk[t], hq[t][hh][q])
-        for q in range(8):
-            j = 8 * half + q
-            for t in range(2):
-                hfrag = np.zeros((64, 8))
-                hfrag[:, :4] = swish(hq[t][0][q] + b1[32 * j + 4 * G[:, None] + np.arange(4)[None, :]])
-                hfrag[:, 4:] = swish(hq[t][1][q] + b1[32 * j + 16 + 4 * G[:, None] + np.arange(4)[None, :]])
-                for c4 in range(8):
-                    for i in range(4):
-                        blk = j * 64 + c4 * 8 + i * 2
-                        yacc[t][4 * c4 + i] = mfma(frag(w2f, blk) + frag(w2f, blk + 1), hfrag, yacc[t][4 * c4 + i])
-    z = swish(x @ w1.T + b1) @ w2.T
-    for t in range(2):
-        got = np.zeros((16, L))
-        for bp in range(16):
-            for i in range(8):
-                got[L15, 32 * bp + 8 * G + i] = (yacc[t][2 * bp] if i < 4 else yacc[t][2 * bp + 1])[:, i & 3]
-        assert np.abs(got - z[16 * t:16 * t + 16]).max() < 1e-9, t
-
-
-def test_prep_w1_node_follows_the_variant_switches(monkeypatch):
-    """fused.prep_w1_node: the first form's order by default; SKGC_NODE_V2 / SKGC_NODE_V3 (set together with a variant library) select the
-    K-outer orders -- all three are permutations of the same 1 KiB blocks."""
+def test_prep_w1_node_is_the_k_outer_order():
+    """fused.prep_w1_node: what skgc_node_mlp reads -- a permutation of the chunk-order 1 KiB blocks."""
     w = torch.randn(512, 1024, generator=torch.Generator().manual_seed(0))
-    for k in ("SKGC_NODE_V2", "SKGC_NODE_V3"):
-        monkeypatch.delenv(k, raising=False)
-    base = fz.prep_w1_node(w)
-    assert torch.equal(base, fz.prep_w1_fragments(w))
-    monkeypatch.setenv("SKGC_NODE_V2", "1")
-    v2 = fz.prep_w1_node(w)
-    assert torch.equal(v2, fz.prep_w1_fragments_kouter(w)) and not torch.equal(v2, base)
-    monkeypatch.setenv("SKGC_NODE_V3", "1")
-    v3 = fz.prep_w1_node(w)
-    assert torch.equal(v3, fz.prep_w1_fragments_khalves(w)) and not torch.equal(v3, v2)
+    got = fz.prep_w1_node(w)
+    assert torch.equal(got, fz.prep_w1_fragments_kouter(w)) and not torch.equal(got, fz.prep_w1_fragments(w))
     key = lambda t: sorted(map(bytes, t.reshape(-1, 512).numpy().view(np.uint8)))  # noqa: E731
-    assert key(base) == key(v2) == key(v3)
+    assert key(got) == key(fz.prep_w1_fragments(w))

@@ -69,7 +69,7 @@ def main():
         print(f"{name}: {tiles} tiles, {ms:.3f} ms, {mf / ms / 1e9:.0f} TFLOP/s executed (W1 planes {planes}); {ms * 1e3 / (tiles / 256):.1f} us per tile round;  {phases(probe)}")
     for ns in (1, 2):
         srcs = [torch.randn(node_rows, L, generator=gen).to(dev) for _ in range(ns)]
-        n1 = fz.prep_w1_node((torch.randn(L, L * ns, generator=gen) / (L * ns) ** 0.5).to(dev))     # (SKGC_NODE_V2=1: K-outer order)
+        n1 = fz.prep_w1_node((torch.randn(L, L * ns, generator=gen) / (L * ns) ** 0.5).to(dev))
         out = torch.empty(node_rows, L, device=dev)
         b1 = torch.zeros(L, device=dev)
         ms = timed(lambda: ops.hip.gc_node_mlp(srcs, [0] * ns, [L] * ns, n1, w2f, b1, *tab, srcs[0], 0, L, out, 0, L, node_rows))
