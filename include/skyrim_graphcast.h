@@ -118,7 +118,8 @@ typedef struct skgc_edge_desc {
     const float* gamma;
     const float* beta;
     float* agg;
-    float* heads;            /* [rows / 128][512]; may be NULL when no tile continues its predecessor */
+    float* heads;            /* [rows / 128][512].  NULL only if NO tile's first receiver equals the previous tile's last (recv[128 t] != recv[128 t - 1]
+                              * for every t): the piece of a run that continues into a tile is then dropped, not written (never a wild store) */
     long long rows;
     int has_fc1;
     int w1_planes;           /* has_fc1: planes of w1f -- 2 = fp16 hi/lo (two MFMA terms), 1 = W_e rounded to fp16 (one term) */

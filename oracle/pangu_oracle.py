@@ -371,3 +371,11 @@ def per_channel_rel_err(y: torch.Tensor, ref: torch.Tensor) -> torch.Tensor:
     num = (y.double() - ref.double()).abs().flatten(1).max(1).values
     den = ref.double().abs().flatten(1).max(1).values
     return num / den
+
+
+def per_channel_sigma_err(y: torch.Tensor, ref: torch.Tensor, std: torch.Tensor) -> torch.Tensor:
+    """The same difference in the network's own units: max|y - ref| / sigma_c with sigma_c the channel's normalisation constant
+    (params["norm.std"]).  max|ref| flatters channels that sit on a large offset (msl: mean 1.0e5 Pa, sigma 1.3e3 Pa -- the 1e-3 bar of
+    ``per_channel_rel_err`` is 7.5 % of sigma there); this figure does not.  Reported beside the SURVEY.md 8(d) metric, never instead of it."""
+    return (y - ref).abs().flatten(1).max(1).values / std.reshape(-1).to(y.dtype)
+

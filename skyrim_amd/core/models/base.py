@@ -101,7 +101,9 @@ class GlobalModel:
         # the page cache takes ONE file's bytes at ~6 GB/s however many threads push them (buffered writes serialise on the inode,
         # tools/predict_cost.py), different files do not share that lock.  zarr appends to one store and keeps a single worker, in step
         # order.  At most ``workers + 1`` predictions wait for the disk, so a slow target throttles the rollout instead of filling host
-        # memory.  Same files, same paths, returned in step order.
+        # memory.  Same files, same paths, returned in step order.  Divergences from the reference's serial loop, both opt-out: a
+        # user-supplied ``save_config["mapping_func"]`` runs on the save threads, several at once (SKYRIM_SAVE_WORKERS=1 restores one file
+        # at a time, in step order); once a step's write has failed no further step is submitted, but writes already running finish.
         workers = 1
         if save and (cfg.get("file_type") or "netcdf") == "netcdf" and "://" not in str(cfg.get("output_dir", "")):
             workers = max(1, int(os.environ.get("SKYRIM_SAVE_WORKERS", SAVE_WORKERS)))
@@ -111,6 +113,9 @@ class GlobalModel:
                 pred = self.predict_one_step(start_time, initial_condition=pred)
                 pred_time = start_time + self.time_step
                 if save:
+                    failed = next((f for f in pending if f.done() and f.exception() is not None), None)
+                    if failed is not None:
+                        failed.result()                            # a writer failed: stop the rollout here instead of writing later steps
                     pending.append(pool.submit(save_forecast, pred, self.model_name, start_time, pred_time, source, config=cfg))
                     if len(pending) > workers + 1:
                         pending[-(workers + 2)].result()

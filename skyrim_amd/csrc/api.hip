@@ -128,7 +128,6 @@ struct Engine : IEngine {
     size_t prep_bytes = 0, ws_bytes = 0;
     size_t bias_exp_elems[16];
     size_t q_elems = 0, ao_elems = 0, hid_elems = 0;
-    int hid16 = 0;            // fp16-hidden mode (bf16x3 engines only)
     bool fused_mlp = false;   // one-kernel MLP (fused_mlp.hip): 3-term modes with the hidden as hi/lo pair
     bool rt_proj = false, rt_qkv = false;   // row-tile proj / QKV kernels (rowtile.hip)
     bool fused_block = false;               // proj + LayerNorm + residual + MLP as one kernel (fused_block.hip)
@@ -236,8 +235,6 @@ struct Engine : IEngine {
                 BlockW<T>& bw = w.blk[b];
                 bw.qkv = take_lin(a, 3 * c, c); bw.proj = take_lin(a, c, c);
                 bw.fc1 = take_lin(a, 4 * c, c); bw.fc2 = take_lin(a, c, 4 * c);
-                bw.fc2h = LinW<f16>{nullptr, 0, 4 * c};
-                if (hid16 && !std::is_same<T, f16>::value) { bw.fc2h.plane = (long long)c * 4 * c; bw.fc2h.w = a.take<f16>((size_t)bw.fc2h.plane * 2); }
                 const bool t2 = two_term(layer);
                 bw.w1f = fused_mlp && !t2 ? a.take<T>((size_t)8 * c * c) : nullptr;      // 4c x c elements, hi + lo
                 bw.w2f = fused_mlp && !t2 ? a.take<T>((size_t)8 * c * c) : nullptr;
@@ -292,16 +289,15 @@ struct Engine : IEngine {
         ws_bytes = (a.off + 255) / 256 * 256;
     }
 
-    explicit Engine(const Geom& geom, int hid16_ = 0, int qkv_a1 = 0, int mlp_mode = 0, int term_plan = 0) : g(geom), hid16(hid16_) {
+    explicit Engine(const Geom& geom, int qkv_a1 = 0, int mlp_mode = 0, int term_plan = 0) : g(geom) {
         attn2 = getenv("SKP_ATTN_V1") == nullptr;
-        fused_mlp = (P::NA == 2 && P::NW == 2 && !hid16_ && mlp_mode == 0);
+        fused_mlp = (P::NA == 2 && P::NW == 2 && mlp_mode == 0);
         // proj in row-tile form measures the same as the tiled GEMM (0.199 vs 0.197 ms at C = 384, 0.264 vs 0.264 at C = 192: with 16 rows
         // per wave its LDS reads run at 2/3 of the LDS rate): kept behind SKP_RT_PROJ=1, the tiled LayerNorm GEMM stays the default
         rt_proj = (P::NA == 2 && P::NW == 2 && mlp_mode == 0 && getenv("SKP_RT_PROJ") != nullptr);
         fused_block = fused_mlp && getenv("SKP_SPLIT_BLOCK") == nullptr;
         rt_qkv = (std::is_same<P, PrecF16x3>::value && qkv_a1 && mlp_mode == 0);
         plan2 = (std::is_same<P, PrecF16x3>::value && fused_block) ? term_plan : 0;     // the two-term kernel exists for fp16 planes, fused form
-        wk.hid16 = hid16_;
         wk.qkv_a1 = qkv_a1;
         params = build_params(g, nullptr);
         plan_prepared(nullptr);
@@ -353,7 +349,6 @@ struct Engine : IEngine {
                 CK(lin(bw.proj, P_(m, p + "attn.proj.weight"), c, c, c, 1, s));
                 CK(lin(bw.fc1, P_(m, p + "mlp.fc1.weight"), 4 * c, c, c, 1, s));
                 CK(lin(bw.fc2, P_(m, p + "mlp.fc2.weight"), c, 4 * c, 4 * c, 1, s));
-                if (hid16 && !std::is_same<T, f16>::value) CK((prep_weight<f16, 2>(P_(m, p + "mlp.fc2.weight"), const_cast<f16*>(bw.fc2h.w), bw.fc2h.plane, c, 4 * c, 4 * c, 4 * c, 1, 1, 1, s)));
                 if constexpr (P::NA == 2 && P::NW == 2) {
                     if (bw.projf) CK(prep_rowtile_weights<T>(P_(m, p + "attn.proj.weight"), const_cast<T*>(bw.projf), c, c, s));
                     if (bw.qkvf) CK(prep_rowtile_weights<T>(qkv_w, const_cast<T*>(bw.qkvf), 3 * c, c, s));
@@ -419,14 +414,12 @@ struct Engine : IEngine {
         }
         mark(C_ATTN0 + o, s);
         AttnArgs<P> a{wk.q, wk.k, wk.vt, wk.qkv_plane, bw.bias_exp, bw.bias_cmp, wk.ao, wk.ao_plane, C, g.nwin[res], g.nW[res], heads};
+        a.out_planes = block_one(layer0) ? 1 : 0;           // a one-term block kernel reads the hi plane only
         CK(launch_attention<P>(a, s));
         if constexpr (std::is_same<P, PrecF16x3>::value) {
-            if (two_term(layer0)) {               // ... with two MFMA terms and the halves of the workgroup half a chunk apart
+            if (two_term(layer0)) {               // ... with the weights as one fp16 plane: two MFMA terms, or one
                 mark(C_FC1_0 + o, s);
-                const char* wv = getenv("SKP_BLK_WIDE");                   // bit res: wide row tiles (read per launch: round-5 A/B script)
-                const int wide = wv ? atoi(wv) : 0;
-                if ((wide >> res) & 1) CK(op_proj_mlp_wide(g, bw, w.winv[res][i & 1], res, xs, wk, s, block_one(layer0)));
-                else CK(op_proj_mlp_skew(g, bw, w.winv[res][i & 1], res, xs, wk, s, block_one(layer0)));
+                CK(op_proj_mlp2(g, bw, w.winv[res][i & 1], res, xs, wk, s, block_one(layer0)));
                 mark(-1, s);
                 return hipSuccess;
             }
@@ -614,12 +607,10 @@ struct Engine : IEngine {
 
 IEngine* make_engine(const skpangu_config& cfg, const Geom& g) {
     switch (cfg.precision) {
-        case SKPANGU_PREC_BF16X3: return new Engine<PrecBF16x3>(g, 0, 0, cfg.mlp_mode);
+        case SKPANGU_PREC_BF16X3: return new Engine<PrecBF16x3>(g, 0, cfg.mlp_mode);
         case SKPANGU_PREC_F16: return new Engine<PrecF16>(g);
-        case SKPANGU_PREC_BF16X3_H16: return new Engine<PrecBF16x3>(g, 1);
-        case SKPANGU_PREC_F16X3: return new Engine<PrecF16x3>(g, 0, 0, cfg.mlp_mode, cfg.term_plan);
-        case SKPANGU_PREC_F16X3_Q: return new Engine<PrecF16x3>(g, 0, 1, cfg.mlp_mode, cfg.term_plan);
-        case SKPANGU_PREC_F16X3_QH: return new Engine<PrecF16x3>(g, 1, 1);
+        case SKPANGU_PREC_F16X3: return new Engine<PrecF16x3>(g, 0, cfg.mlp_mode, cfg.term_plan);
+        case SKPANGU_PREC_F16X3_Q: return new Engine<PrecF16x3>(g, 1, cfg.mlp_mode, cfg.term_plan);
         default: return nullptr;
     }
 }

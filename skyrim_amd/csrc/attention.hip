@@ -271,8 +271,12 @@ hipError_t launch_attention(const AttnArgs<P>& a, hipStream_t stream) {
     constexpr int NPL_O = (P::NA > P::NW ? P::NA : P::NW);
     if (a.bias_cmp) {
         const int types = a.n_win / a.nW;
-        hipLaunchKernelGGL((earth_attention2_kernel<typename P::T, NPL_O>), dim3((unsigned)(types * a.heads)), dim3(256), 0, stream,
-                           a.q, a.k, a.vt, a.bias_cmp, a.out, a.out_plane, a.ld_out, a.nW, a.heads);
+        if (a.out_planes == 1)
+            hipLaunchKernelGGL((earth_attention2_kernel<typename P::T, 1>), dim3((unsigned)(types * a.heads)), dim3(256), 0, stream,
+                               a.q, a.k, a.vt, a.bias_cmp, a.out, a.out_plane, a.ld_out, a.nW, a.heads);
+        else
+            hipLaunchKernelGGL((earth_attention2_kernel<typename P::T, NPL_O>), dim3((unsigned)(types * a.heads)), dim3(256), 0, stream,
+                               a.q, a.k, a.vt, a.bias_cmp, a.out, a.out_plane, a.ld_out, a.nW, a.heads);
         return hipGetLastError();
     }
     const long long waves = (long long)a.n_win * a.heads;

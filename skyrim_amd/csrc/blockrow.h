@@ -1,5 +1,5 @@
-// What the row-tile block kernels share (fused_block2.hip: two 4-wave workgroups per CU, 16 / 32 rows per wave; fused_block_wide.hip: one wave
-// per SIMD, 32 / 64 rows per wave): the argument block and the register ring through which weight fragments leave LDS.  gfx950 only.
+// The argument block of the one-plane-weight block kernel (fused_block2.hip) and the register ring through which its weight fragments leave
+// LDS.  gfx950 only.
 #pragma once
 #include "gemm_dma.h"
 
@@ -24,15 +24,9 @@ __device__ __forceinline__ void sk_ld2(const char* p, uint4 (&w)[2]) {
 }
 
 // NP fragment pairs at consecutive KiB of `st`, through a ring of RD register pairs read RD - 1 pairs ahead of their MFMAs
-template <int NP, int RD, bool ONE = false, class Body>
+template <int NP, int RD, class Body>
 __device__ __forceinline__ void sk_stream(const char* st, Body&& body) {
     uint4 ring[RD][2];
-    if constexpr (ONE) {                         // probe: one pair read, every step computes on it
-        sk_ld2(st, ring[0]);
-#pragma unroll
-        for (int p = 0; p < NP; ++p) { body(p, ring[0][0], ring[0][1]); __builtin_amdgcn_sched_barrier(0); }
-        return;
-    }
 #pragma unroll
     for (int p = 0; p < RD - 1 && p < NP; ++p) sk_ld2(st + (p << 11), ring[p % RD]);
 #pragma unroll

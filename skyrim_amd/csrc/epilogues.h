@@ -102,15 +102,8 @@ struct EpGelu {
                 const int n = n0w + bp * 32 + l8;
                 if (n >= N) continue;
                 const f32x4 &x = acc[a][2 * bp], &y = acc[a][2 * bp + 1];
-#ifdef SKP_DEBUG_NOGELU
-                float v[8] = {x[0], x[1], x[2], x[3], y[0], y[1], y[2], y[3]};
-#else
                 float v[8];
                 gelu_erf8(x, y, v);
-#endif
-#ifdef SKP_DEBUG_NOSTORE
-                if (v[0] == 123.456f)
-#endif
                 store8_planes<T, NPL>(out + blk_off(m, n, ld), plane, v);
             }
         }

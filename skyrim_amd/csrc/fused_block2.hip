@@ -7,66 +7,44 @@
 // error after one step, 5.3e-4 after four, bar 1e-3).  It removes a third of the MFMAs, HALF of the bytes that cross LDS
 // (the token tile lives in registers, only weights stream through LDS) and half of the LDS-DMA traffic.
 //
-// Two launch shapes (DESIGN.md 5.4 has the measurements, including what did NOT help):
-//   DUO (default)   4-wave workgroups, TWO per CU (one wave of each on every SIMD), two LDS slots of one chunk each and two barriers per
-//                   32-unit chunk, exactly fused_block.hip's loop:  | fc1(j) | GELU(j) | fc2(j) |.  The hi-only chunk is 24 KB at C = 384,
-//                   so two workgroups fit a CU where the three-term kernel fits one; the two run free of each other.
-//   one 8-wave workgroup per CU, a five-slot ring (W1(j) in slot j & 1, W2(j) in slot 2 + j % 3) and ONE barrier per chunk, optionally
-//                   with the halves of the workgroup (waves 0-3 / 4-7 = the two waves of each SIMD) taking the chunk in different orders
-//                   (lead: fc1(j) GELU(j) fc2(j); trail: GELU(j-1) fc2(j-1) fc1(j)) -- measured equal to the plain order.
+// Launch shape: 4-wave workgroups, TWO per CU (one wave of each on every SIMD), two LDS slots of one chunk each and two barriers per
+// 32-unit chunk:  | fc1(j) | GELU(j) | fc2(j) |.  The hi-only chunk is 24 KB at C = 384, so two workgroups fit a CU where the three-term
+// kernel (fused_block.hip) fits one; the two run free of each other and drift out of phase, so that one's GELU / LayerNorm / row I/O runs
+// under the other's MFMAs.  What else was measured -- one 8-wave workgroup with a five-slot ring, its halves half a chunk apart, four
+// accumulator chains, a one-wave-per-SIMD form with 32 / 64 rows per wave, software pipelining inside the wave, and the per-phase timing
+// probes -- is in docs/experiments.md; none of it is in the tree.
+//
+// ONE (term-plan bits 8-11): the ACTIVATION operands too as one fp16 plane -- A_hi W only: attention output, mid-block stream and hidden
+// activation are rounded to fp16 where they enter a GEMM (the residual path keeps the hi/lo pair), the attention output's lo plane is
+// neither written nor read.  Half of the two-term form's MFMAs; meant for weights rounded with error feedback against these very operands
+// (pangu/calibration.py), which is what pays for the activation rounding.
 //
 // Row-tile structure, epilogues and data layouts are fused_block.hip's: a wave owns FM x 16 stream tokens, their attention rows are
 // gathered through the inverse window table as MFMA B-operand fragments, x_mid = x + LayerNorm(proj) becomes the MLP's operand in
 // registers (perm8), the stream is read once and written once.  gfx950 only.
-//
-// SKP_BLK2_CHAINS4 (build-time variant, tools/blk2_chains.sh): a v_mfma_f32_16x16x32_f16 that accumulates into the result of an earlier one
-// issues ~47 clocks after it (measured in graphcast_fused.hip's loops: two alternating accumulator chains run at 23.7 clocks per MFMA, four at
-// the pipe's 16).  With FM = 1 (C = 384: 12 of the 16 blocks) every loop below alternates between exactly TWO accumulators per k-step; the
-// variant gives each loop four chains without more live registers: the lo-plane terms of the projection and of fc1 go to accumulators of their
-// own (added once per block / chunk; they live where the fc2 operand fragments are dead), and fc2 issues the hi-plane terms of column pair
-// p - 1 after the lo-plane terms of pair p (the previous fragment pair stays in registers where fc1's accumulators are dead).
-// MEASURED (round 4, 721x1440, same box, back to back): 19.48 ms per step against 18.56 for the plain order, toy parity 1.23e-4 against 1.19e-4 --
-// 5 % SLOWER.  With two waves per SIMD the partner wave's MFMAs fill the dependent-issue gaps (graphcast_fused.hip runs ONE wave per SIMD, where
-// they are exposed); what the variant adds -- 168 bytes more scratch per lane, the accumulator adds -- is pure cost here.  Not built by default.
-#include <cstdlib>
 #include "blockrow.h"
 #include "launchers.h"
 
 namespace skp {
 
-#ifdef SKP_BLK2_CHAINS4
-constexpr bool kBlk2Chains4 = true;
-#else
-constexpr bool kBlk2Chains4 = false;
-#endif
-
-template <int C_, int FM_, int RD_, bool SKEW_, bool DUO_, int PROBE_ = 0, bool ONE_ = false>
+template <int C_, int FM_, bool ONE_>
 struct Blk2Shape {
-    // ONE: the ACTIVATION operands too as one fp16 plane -- A_hi W only: attention output, mid-block stream and hidden activation are rounded
-    // to fp16 where they enter a GEMM (the residual path keeps the hi/lo pair).  Half of the two-term form's MFMAs; meant for weights rounded
-    // with error feedback against these very operands (pangu/calibration.py), which is what pays for the activation rounding
     static constexpr bool ONE = ONE_;
-    // timing probes (measurement only; results are wrong): 1 no GELU polynomial, 2 one fragment pair read per phase, 4 no weight DMA
-    // in the MLP loop, 8 no barrier in the MLP loop, 16 no row gathers / stores
-    static constexpr int PROBE = PROBE_;
-    static constexpr bool SKEW = SKEW_, DUO = DUO_;
-    static constexpr int C = C_, FM = FM_, NWAVES = DUO_ ? 4 : 8, THREADS = 64 * NWAVES, RD = RD_;
+    static constexpr int C = C_, FM = FM_, NWAVES = 4, THREADS = 64 * NWAVES, RD = 2;
     static constexpr int KS = C / 32, CF = C / 16, HID = 4 * C, NCH = HID / 32, NPB = C / 32, BM = NWAVES * FM * 16;
     static constexpr int SLOT_KIB = KS * 2;          // KiB of a projection block [ks][n] = of an fc1 chunk [ks][n] = of an fc2 chunk [c]
-    static constexpr int SLOT = SLOT_KIB * 1024, NSLOT = DUO_ ? 2 : 5;
-    static constexpr int PSLOT0 = DUO_ ? 0 : 3;      // the projection's blocks alternate between slots PSLOT0 and PSLOT0 + 1
+    static constexpr int SLOT = SLOT_KIB * 1024, NSLOT = 2;
     static constexpr int T_PB = 0, T_G1 = C, T_E1 = 2 * C, T_B1 = 3 * C, T_B2 = 3 * C + HID, T_G2 = T_B2 + C, T_E2 = T_G2 + C;
     static constexpr int TAB = T_E2 + C;
     static constexpr int SMEM = NSLOT * SLOT + TAB * 4;
-    static_assert((2 * SLOT_KIB) % NWAVES == 0 && NPB % 2 == 0 && NCH >= 3 && !(SKEW_ && DUO_), "DMA pieces per wave; even projection block count");
-    static_assert(SMEM <= (DUO_ ? 80 : 160) * 1024, "LDS");
+    static_assert(SLOT_KIB % NWAVES == 0 && NPB % 2 == 0 && NCH >= 3, "DMA pieces per wave; even projection block count");
+    static_assert(SMEM <= 80 * 1024, "two workgroups per CU");
 };
 
 template <class T, class S>
 __global__ void __launch_bounds__(S::THREADS) __attribute__((amdgpu_waves_per_eu(2, 2)))
 proj_mlp2_kernel(const Block2Args<T> a) {
     constexpr int C = S::C, FM = S::FM, KS = S::KS, CF = S::CF, NCH = S::NCH, NPB = S::NPB, NWAVES = S::NWAVES, RD = S::RD;
-    constexpr bool P_GELU = S::PROBE & 1, P_LDS = S::PROBE & 2, P_DMA = S::PROBE & 4, P_BAR = S::PROBE & 8, P_IO = S::PROBE & 16;
     typedef typename OpT<T>::v8 v8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* tab = reinterpret_cast<float*>(smem + S::NSLOT * S::SLOT);
@@ -74,31 +52,17 @@ proj_mlp2_kernel(const Block2Args<T> a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const unsigned lds_base = (unsigned)(size_t)smem;
     const char* lrd = smem + lane * 16;                          // a lane's 16 bytes of every fragment
-    const bool lead = !S::SKEW || wave < 4;
 
     // SLOT_KIB consecutive KiB of `src` -> LDS `dst`, piece q by wave q % NWAVES
     auto dma1 = [&](const T* src, unsigned dst) {
         const T* s = src + lane * 8;
 #pragma unroll
-        for (int i = 0; i < (S::SLOT_KIB + NWAVES - 1) / NWAVES; ++i) {
+        for (int i = 0; i < S::SLOT_KIB / NWAVES; ++i) {
             const int q = wave + i * NWAVES;
-            if (q < S::SLOT_KIB) glds16(s + (q << 9), dst + (unsigned)(q << 10));
+            glds16(s + (q << 9), dst + (unsigned)(q << 10));
         }
     };
-    // the weights of chunk j: W1(j) -> slot j & 1, W2(j) -> slot 2 + j % 3 (m3 = j % 3); 2 SLOT_KIB pieces over the 8 waves
-    auto dma_chunk = [&](int j, int m3) {
-        const T* s1 = a.w1h + ((long long)j * S::SLOT_KIB << 9) + lane * 8;
-        const T* s2 = a.w2h + ((long long)j * S::SLOT_KIB << 9) + lane * 8;
-        const unsigned d1 = lds_base + (unsigned)((j & 1) * S::SLOT), d2 = lds_base + (unsigned)((2 + m3) * S::SLOT);
-#pragma unroll
-        for (int i = 0; i < 2 * S::SLOT_KIB / NWAVES; ++i) {
-            const int q = wave + i * NWAVES;
-            if (q < S::SLOT_KIB) glds16(s1 + (q << 9), d1 + (unsigned)(q << 10));
-            else glds16(s2 + ((q - S::SLOT_KIB) << 9), d2 + (unsigned)((q - S::SLOT_KIB) << 10));
-        }
-    };
-    dma1(a.projh, lds_base + S::PSLOT0 * S::SLOT);
-    if constexpr (!S::DUO) dma_chunk(0, 0);
+    dma1(a.projh, lds_base);
 
     for (int i = tid; i < C; i += S::THREADS) {
         tab[S::T_PB + i] = a.proj_b[i]; tab[S::T_G1 + i] = a.g1[i]; tab[S::T_E1 + i] = a.e1[i];
@@ -113,11 +77,10 @@ proj_mlp2_kernel(const Block2Args<T> a) {
 #pragma unroll
     for (int t = 0; t < FM; ++t) {
         live[t] = (rb0 + t) * 16 < a.M;
-        const int src = live[t] && !P_IO ? a.winv[(rb0 + t) * 16 + l15] : 0;
+        const int src = live[t] ? a.winv[(rb0 + t) * 16 + l15] : 0;
         const T* p = a.ao + blk_off(src, g * 8, C);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            if constexpr (P_IO) { xh[t][ks] = v8{}; xl[t][ks] = v8{}; xh[t][ks][0] = (T)(float)lane; continue; }
             xh[t][ks] = *reinterpret_cast<const v8*>(p + (ks << 9));
             if constexpr (S::ONE) xl[t][ks] = v8{};              // the lo plane of the attention output is not read at all
             else xl[t][ks] = *reinterpret_cast<const v8*>(p + (ks << 9) + a.ao_plane);
@@ -135,25 +98,14 @@ proj_mlp2_kernel(const Block2Args<T> a) {
 #pragma unroll
         for (int c = 0; c < CF; ++c) yacc[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // ---- phase 1: projection, blocks of 32 output columns alternating between two slots (no VALU phase: lock-step is harmless here) -- //
+    // ---- phase 1: projection, blocks of 32 output columns alternating between the two slots -------------------------------------- //
 #pragma unroll
     for (int j = 0; j < NPB; ++j) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                               // block j landed; every wave is done with block j - 1
-        if (j + 1 < NPB) dma1(a.projh + ((long long)(j + 1) * S::SLOT_KIB << 9), lds_base + (unsigned)((S::PSLOT0 + ((j + 1) & 1)) * S::SLOT));
-        else if constexpr (S::DUO) dma1(a.w1h, lds_base);      // NPB is even: the last block sits in slot 1, slot 0 is free for fc1's chunk 0
-        if constexpr (kBlk2Chains4 && FM == 1 && !S::ONE) {
-            f32x4 plo[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};          // the lo-plane terms: two chains of their own
-            sk_stream<KS, RD>(lrd + (S::PSLOT0 + (j & 1)) * S::SLOT, [&](int ks, const uint4& w0, const uint4& w1) {
-                plo[0] = OpT<T>::mfma(as_v8<T>(w0), xl[0][ks], plo[0]);
-                plo[1] = OpT<T>::mfma(as_v8<T>(w1), xl[0][ks], plo[1]);
-                yacc[0][2 * j] = OpT<T>::mfma(as_v8<T>(w0), xh[0][ks], yacc[0][2 * j]);
-                yacc[0][2 * j + 1] = OpT<T>::mfma(as_v8<T>(w1), xh[0][ks], yacc[0][2 * j + 1]);
-            });
-            yacc[0][2 * j] += plo[0];
-            yacc[0][2 * j + 1] += plo[1];
-        } else
-        sk_stream<KS, RD>(lrd + (S::PSLOT0 + (j & 1)) * S::SLOT, [&](int ks, const uint4& w0, const uint4& w1) {
+        if (j + 1 < NPB) dma1(a.projh + ((long long)(j + 1) * S::SLOT_KIB << 9), lds_base + (unsigned)(((j + 1) & 1) * S::SLOT));
+        else dma1(a.w1h, lds_base);                    // NPB is even: the last block sits in slot 1, slot 0 is free for fc1's chunk 0
+        sk_stream<KS, RD>(lrd + (j & 1) * S::SLOT, [&](int ks, const uint4& w0, const uint4& w1) {
             if constexpr (!S::ONE) {
 #pragma unroll
                 for (int t = 0; t < FM; ++t) yacc[t][2 * j] = OpT<T>::mfma(as_v8<T>(w0), xl[t][ks], yacc[t][2 * j]);
@@ -174,7 +126,6 @@ proj_mlp2_kernel(const Block2Args<T> a) {
         v8 oh[KS], ol[KS];
 #pragma unroll
         for (int bp = 0; bp < KS; ++bp) {
-            if constexpr (P_IO) { oh[bp] = xh[t][bp]; ol[bp] = xl[t][bp]; continue; }
             oh[bp] = *reinterpret_cast<const v8*>(old + (bp << 9));
             ol[bp] = *reinterpret_cast<const v8*>(old + (bp << 9) + a.xs_plane);
         }
@@ -218,25 +169,16 @@ proj_mlp2_kernel(const Block2Args<T> a) {
         for (int c = 0; c < CF; ++c) yacc[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 
-    // ---- phase 2: the MLP ------------------------------------------------------------------------------------------------------------ //
+    // ---- phase 2: the MLP, W1(j) in slot 0 and W2(j) in slot 1 ---------------------------------------------------------------------- //
     f32x4 hacc[FM][2];
     uint4 hh[FM], hl[FM];
-    auto fc1 = [&](int slot) {                          // W1 chunk in `slot` -> hacc
+    for (int j = 0; j < NCH; ++j) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                               // W1(j) landed in slot 0; every wave is done with W2(j - 1) / the projection in slot 1
+        dma1(a.w2h + ((long long)j * S::SLOT_KIB << 9), lds_base + S::SLOT);
 #pragma unroll
         for (int t = 0; t < FM; ++t) { hacc[t][0] = f32x4{0.f, 0.f, 0.f, 0.f}; hacc[t][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-        if constexpr (kBlk2Chains4 && FM == 1 && !S::ONE) {
-            f32x4 hlo[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-            sk_stream<KS, RD, P_LDS>(lrd + slot * S::SLOT, [&](int ks, const uint4& w0, const uint4& w1) {
-                hlo[0] = OpT<T>::mfma(as_v8<T>(w0), xl[0][ks], hlo[0]);
-                hlo[1] = OpT<T>::mfma(as_v8<T>(w1), xl[0][ks], hlo[1]);
-                hacc[0][0] = OpT<T>::mfma(as_v8<T>(w0), xh[0][ks], hacc[0][0]);
-                hacc[0][1] = OpT<T>::mfma(as_v8<T>(w1), xh[0][ks], hacc[0][1]);
-            });
-            hacc[0][0] += hlo[0];
-            hacc[0][1] += hlo[1];
-            return;
-        }
-        sk_stream<KS, RD, P_LDS>(lrd + slot * S::SLOT, [&](int ks, const uint4& w0, const uint4& w1) {
+        sk_stream<KS, RD>(lrd, [&](int ks, const uint4& w0, const uint4& w1) {
             if constexpr (!S::ONE) {
 #pragma unroll
                 for (int t = 0; t < FM; ++t) hacc[t][0] = OpT<T>::mfma(as_v8<T>(w0), xl[t][ks], hacc[t][0]);
@@ -248,38 +190,22 @@ proj_mlp2_kernel(const Block2Args<T> a) {
 #pragma unroll
             for (int t = 0; t < FM; ++t) hacc[t][1] = OpT<T>::mfma(as_v8<T>(w1), xh[t][ks], hacc[t][1]);
         });
-    };
-    // bias + GELU + hi/lo split of chunk j: the lane's 8 hidden units 16 n + 4 g + r become k-slots 8 g + 4 n + r of fc2
-    auto gelu = [&](int j) {
-        const float4 bb0 = *reinterpret_cast<const float4*>(tab + S::T_B1 + j * 32 + 4 * g), bb1 = *reinterpret_cast<const float4*>(tab + S::T_B1 + j * 32 + 16 + 4 * g);
+        {   // bias + GELU + hi/lo split: the lane's 8 hidden units 16 n + 4 g + r become k-slots 8 g + 4 n + r of fc2
+            const float4 bb0 = *reinterpret_cast<const float4*>(tab + S::T_B1 + j * 32 + 4 * g), bb1 = *reinterpret_cast<const float4*>(tab + S::T_B1 + j * 32 + 16 + 4 * g);
 #pragma unroll
-        for (int t = 0; t < FM; ++t) {
-            auto act = [](f32x2 v) { if constexpr (P_GELU) return v; else return gelu_erf2(v); };
-            const f32x2 a0 = act(f32x2{hacc[t][0][0] + bb0.x, hacc[t][0][1] + bb0.y}), a1 = act(f32x2{hacc[t][0][2] + bb0.z, hacc[t][0][3] + bb0.w});
-            const f32x2 a2 = act(f32x2{hacc[t][1][0] + bb1.x, hacc[t][1][1] + bb1.y}), a3 = act(f32x2{hacc[t][1][2] + bb1.z, hacc[t][1][3] + bb1.w});
-            const float v[8] = {a0.x, a0.y, a1.x, a1.y, a2.x, a2.y, a3.x, a3.y};
-            uint4 o[2];
-            split8<T, 2>(v, o);
-            hh[t] = o[0]; hl[t] = o[1];
+            for (int t = 0; t < FM; ++t) {
+                const f32x2 a0 = gelu_erf2(f32x2{hacc[t][0][0] + bb0.x, hacc[t][0][1] + bb0.y}), a1 = gelu_erf2(f32x2{hacc[t][0][2] + bb0.z, hacc[t][0][3] + bb0.w});
+                const f32x2 a2 = gelu_erf2(f32x2{hacc[t][1][0] + bb1.x, hacc[t][1][1] + bb1.y}), a3 = gelu_erf2(f32x2{hacc[t][1][2] + bb1.z, hacc[t][1][3] + bb1.w});
+                const float v[8] = {a0.x, a0.y, a1.x, a1.y, a2.x, a2.y, a3.x, a3.y};
+                uint4 o[2];
+                split8<T, 2>(v, o);
+                hh[t] = o[0]; hl[t] = o[1];
+            }
         }
-    };
-    auto fc2 = [&](int slot) {                          // W2 chunk in `slot`, operand hh / hl -> yacc
-        if constexpr (kBlk2Chains4 && FM == 1 && !S::ONE) {
-            uint4 pw0 = make_uint4(0, 0, 0, 0), pw1 = pw0;          // the fragment pair of step p - 1: its hi-plane terms follow step p's lo-plane terms
-            sk_stream<CF / 2, RD, P_LDS>(lrd + slot * S::SLOT, [&](int p, const uint4& w0, const uint4& w1) {
-                yacc[0][2 * p] = OpT<T>::mfma(as_v8<T>(w0), as_v8<T>(hl[0]), yacc[0][2 * p]);
-                yacc[0][2 * p + 1] = OpT<T>::mfma(as_v8<T>(w1), as_v8<T>(hl[0]), yacc[0][2 * p + 1]);
-                if (p > 0) {
-                    yacc[0][2 * p - 2] = OpT<T>::mfma(as_v8<T>(pw0), as_v8<T>(hh[0]), yacc[0][2 * p - 2]);
-                    yacc[0][2 * p - 1] = OpT<T>::mfma(as_v8<T>(pw1), as_v8<T>(hh[0]), yacc[0][2 * p - 1]);
-                }
-                pw0 = w0; pw1 = w1;
-            });
-            yacc[0][CF - 2] = OpT<T>::mfma(as_v8<T>(pw0), as_v8<T>(hh[0]), yacc[0][CF - 2]);
-            yacc[0][CF - 1] = OpT<T>::mfma(as_v8<T>(pw1), as_v8<T>(hh[0]), yacc[0][CF - 1]);
-            return;
-        }
-        sk_stream<CF / 2, RD, P_LDS>(lrd + slot * S::SLOT, [&](int p, const uint4& w0, const uint4& w1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                               // W2(j) landed; every wave is done with W1(j)
+        if (j + 1 < NCH) dma1(a.w1h + ((long long)(j + 1) * S::SLOT_KIB << 9), lds_base);
+        sk_stream<CF / 2, RD>(lrd + S::SLOT, [&](int p, const uint4& w0, const uint4& w1) {
             if constexpr (!S::ONE) {
 #pragma unroll
                 for (int t = 0; t < FM; ++t) yacc[t][2 * p] = OpT<T>::mfma(as_v8<T>(w0), as_v8<T>(hl[t]), yacc[t][2 * p]);
@@ -291,57 +217,6 @@ proj_mlp2_kernel(const Block2Args<T> a) {
 #pragma unroll
             for (int t = 0; t < FM; ++t) yacc[t][2 * p + 1] = OpT<T>::mfma(as_v8<T>(w1), as_v8<T>(hh[t]), yacc[t][2 * p + 1]);
         });
-    };
-    // 8-wave form, top of interval j: chunk j's weights landed (requested one interval ago), every wave is done with interval j - 1;
-    // request chunk j + 1 into the slots of W1(j - 1) and W2(j - 2)
-    auto top = [&](int j, int m3n) {
-        if constexpr (!P_BAR) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-        }
-        if constexpr (!P_DMA) { if (j + 1 < NCH) dma_chunk(j + 1, m3n); }
-    };
-
-    if constexpr (S::DUO) {
-        for (int j = 0; j < NCH; ++j) {
-            if constexpr (!P_BAR) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();                           // W1(j) landed in slot 0; every wave is done with W2(j - 1) / the projection in slot 1
-            }
-            if constexpr (!P_DMA) dma1(a.w2h + ((long long)j * S::SLOT_KIB << 9), lds_base + S::SLOT);
-            fc1(0);
-            gelu(j);
-            if constexpr (!P_BAR) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();                           // W2(j) landed; every wave is done with W1(j)
-            }
-            if constexpr (!P_DMA) { if (j + 1 < NCH) dma1(a.w1h + ((long long)(j + 1) * S::SLOT_KIB << 9), lds_base); }
-            fc2(1);
-        }
-    } else if (lead) {
-        int m3 = 0;                                     // j % 3
-        for (int j = 0; j < NCH; ++j) {
-            const int m3n = m3 == 2 ? 0 : m3 + 1;
-            top(j, m3n);
-            fc1(j & 1);
-            gelu(j);
-            fc2(2 + m3);
-            m3 = m3n;
-        }
-    } else {
-        top(0, 1);
-        fc1(0);
-        int m3 = 0;                                     // (j - 1) % 3
-        for (int j = 1; j < NCH; ++j) {
-            const int m3j = m3 == 2 ? 0 : m3 + 1, m3n = m3j == 2 ? 0 : m3j + 1;
-            top(j, m3n);
-            gelu(j - 1);
-            fc2(2 + m3);
-            fc1(j & 1);
-            m3 = m3j;
-        }
-        gelu(NCH - 1);
-        fc2(2 + m3);
     }
 
     // ---- epilogue: + fc2 bias, LayerNorm(norm2), + x_mid (registers), whole blocks of the stream ------------------------------------ //
@@ -367,7 +242,7 @@ proj_mlp2_kernel(const Block2Args<T> a) {
         q += __shfl_xor(q, 16);
         q += __shfl_xor(q, 32);
         const float rstd = rsqrtf(q * (1.0f / C) + a.eps);
-        if (!live[t] || (P_IO && rstd != 12345.f)) continue;
+        if (!live[t]) continue;
         T* dst = a.xs + ((rb0 + t) * KS << 9) + l15 * 32 + g * 8;
 #pragma unroll
         for (int bp = 0; bp < KS; ++bp) {
@@ -398,34 +273,14 @@ static hipError_t launch_blk2(const Block2Args<T>& a, hipStream_t s) {
     return hipGetLastError();
 }
 
-// SKP_BLK2_VARIANT (measurement only): 0 default (two 4-wave workgroups per CU) | 1 one 8-wave workgroup, one barrier per chunk | 2 ... with the
-// halves of the workgroup half a chunk apart | 10.. timing probes of variant 1 (C = 384)
-hipError_t op_proj_mlp_skew(const Geom& g, const BlockW<f16>& b, const int* winv, int res, f16* Xs, const Work<PrecF16x3>& wk, hipStream_t s, int one) {
+// `one`: the layer's term-plan bit 8 + l -- the activation operands as one fp16 plane too
+hipError_t op_proj_mlp2(const Geom& g, const BlockW<f16>& b, const int* winv, int res, f16* Xs, const Work<PrecF16x3>& wk, hipStream_t s, int one) {
     typedef f16 T;
     Block2Args<T> a{wk.ao, wk.ao_plane, g.ntok[res], Xs, wk.xs_plane[res], winv, b.projh, b.w1h, b.w2h,
                     b.proj_b, b.n1_g, b.n1_b, b.fc1_b, b.fc2_b, b.n2_g, b.n2_b, 1e-5f};
     if (a.M % 16 != 0) return hipErrorInvalidValue;
-    static const int variant = [] { const char* v = getenv("SKP_BLK2_VARIANT"); return v ? atoi(v) : 0; }();
-    if (one) return res == 0 ? launch_blk2<T, Blk2Shape<192, 2, 2, false, true, 0, true>>(a, s) : launch_blk2<T, Blk2Shape<384, 1, 2, false, true, 0, true>>(a, s);
-    if (res == 0) {
-        switch (variant) {
-            case 1: return launch_blk2<T, Blk2Shape<192, 2, 2, false, false>>(a, s);
-            case 2: return launch_blk2<T, Blk2Shape<192, 2, 2, true, false>>(a, s);
-            default: return launch_blk2<T, Blk2Shape<192, 2, 2, false, true>>(a, s);
-        }
-    }
-    switch (variant) {
-        case 1: return launch_blk2<T, Blk2Shape<384, 1, 2, false, false>>(a, s);
-        case 2: return launch_blk2<T, Blk2Shape<384, 1, 2, true, false>>(a, s);
-        case 10: return launch_blk2<T, Blk2Shape<384, 1, 2, false, false, 1>>(a, s);
-        case 11: return launch_blk2<T, Blk2Shape<384, 1, 2, false, false, 2>>(a, s);
-        case 12: return launch_blk2<T, Blk2Shape<384, 1, 2, false, false, 4>>(a, s);
-        case 13: return launch_blk2<T, Blk2Shape<384, 1, 2, false, false, 8>>(a, s);
-        case 14: return launch_blk2<T, Blk2Shape<384, 1, 2, false, false, 16>>(a, s);
-        case 15: return launch_blk2<T, Blk2Shape<384, 1, 2, false, false, 15>>(a, s);
-        case 16: return launch_blk2<T, Blk2Shape<384, 1, 2, false, false, 31>>(a, s);
-        default: return launch_blk2<T, Blk2Shape<384, 1, 2, false, true>>(a, s);
-    }
+    if (res == 0) return one ? launch_blk2<T, Blk2Shape<192, 2, true>>(a, s) : launch_blk2<T, Blk2Shape<192, 2, false>>(a, s);
+    return one ? launch_blk2<T, Blk2Shape<384, 1, true>>(a, s) : launch_blk2<T, Blk2Shape<384, 1, false>>(a, s);
 }
 
 }  // namespace skp

@@ -139,21 +139,12 @@ __device__ __forceinline__ void gemm_body(const GemmArgs<P, AL, EP>& g, char* sm
 
     const int nk = (g.K + BK - 1) / BK;
     const int fr_row = lane & 15, fr_grp = lane >> 4;
-#ifdef SKP_PROBE_NO_LOAD      // timing probe (tools/sfno_probe.sh): the operands are fetched once, every k-tile reuses them
     load_tile(0);
-#define SKP_PROBE_LOAD(kt) ((void)0)
-#else
-#define SKP_PROBE_LOAD(kt) load_tile(kt)
-    load_tile(0);
-#endif
     g.ep.template init<TC>(smem + gemm_smem_bytes<P, TC>() + kEpiReduceBytes, tid, n0);   // ordered by the loop's first barrier
     for (int kt = 0; kt < nk; ++kt) {
         stage_tile();
         __syncthreads();
-        if (kt + 1 < nk) SKP_PROBE_LOAD(kt + 1);
-#ifdef SKP_PROBE_NO_MFMA
-        if (kt >= 0) { __syncthreads(); continue; }
-#endif
+        if (kt + 1 < nk) load_tile(kt + 1);
 #pragma unroll
         for (int ks = 0; ks < BK / 32; ++ks) {
             const int slot = ks * 4 + fr_grp;
@@ -191,9 +182,6 @@ __device__ __forceinline__ void gemm_body(const GemmArgs<P, AL, EP>& g, char* sm
         }
         __syncthreads();
     }
-#ifdef SKP_PROBE_NO_EPILOGUE
-    if (g.M > 0) { if (acc[0][0][0] == 12345.678f) g.ep.template run<TC, SWAP>(acc, m0 + wm * TC::WTM, n0 + wn * TC::WTN, lane, wm, wn, smem + gemm_smem_bytes<P, TC>(), g.M, g.N, tile_x); return; }
-#endif
     g.ep.template run<TC, SWAP>(acc, m0 + wm * TC::WTM, n0 + wn * TC::WTN, lane, wm, wn, smem + gemm_smem_bytes<P, TC>(), g.M, g.N, tile_x);
 }
 

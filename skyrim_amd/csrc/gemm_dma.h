@@ -189,11 +189,7 @@ __device__ __forceinline__ void gemm_dma_body(const DmaArgs<P, AS, EP>& g, char*
 
     const unsigned lds_base = (unsigned)(size_t)smem;     // LDS byte address of the dynamic region (low 32 bits of the flat pointer)
     auto issue = [&](int kt, int stage) {
-#ifdef SKP_DEBUG_SAMETILE
-        const int k = 0;   // speed experiment only: every k-tile re-reads tile 0 (memory system out of the picture)
-#else
         const int k = kt * BK;
-#endif
 #pragma unroll
         for (int i = 0; i < CNT; ++i) {
             if (wave + i * NWAVES < NI) {
@@ -216,16 +212,9 @@ __device__ __forceinline__ void gemm_dma_body(const DmaArgs<P, AS, EP>& g, char*
         __syncthreads();
         if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
         const char* st = smem + (kt & 1) * STAGE;
-#ifndef SKP_DEBUG_NOMMA
         mma_tile<P, TC, SWAP>(st, st + A_BYTES, acc, wm, wn, lane);
-#else
-        if (kt == 0) mma_tile<P, TC, SWAP>(st, st + A_BYTES, acc, wm, wn, lane);
-#endif
     }
     __syncthreads();
-#ifdef SKP_DEBUG_NOEPI
-    if (acc[0][0][0] != 123.456f) return;
-#endif
     g.ep.template run<TC, SWAP>(acc, m0 + wm * TC::WTM, n0 + wn * TC::WTN, lane, wm, wn, smem + 2 * STAGE, g.M, g.N, n_tile);
 }
 

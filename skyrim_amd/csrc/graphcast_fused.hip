@@ -40,19 +40,14 @@ namespace skp {
 
 __device__ __forceinline__ float swish_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }
 
-// build-time variants for measurements (tools/gc_edge_probe.py, tools/build_gc_variants.sh)
-#ifndef FZ_RD
-#define FZ_RD 2                    // steps of weight fragments in flight per wave (register ring)
-#endif
-// timing probes (results are WRONG): FZ_PROBE & 1 -- no weight DMA after a kernel's first stages; & 2 -- no MFMAs in the chunk loops
-#ifndef FZ_PROBE
-#define FZ_PROBE 0
-#endif
-#ifndef FZ_DBG
-#define FZ_DBG 0                   // & 1: node kernel requests a stage's 16 DMA pieces in one burst at the chunk top; & 4: RD = 1 (no read-ahead)
+constexpr int FZ_RD = 2;           // steps of weight fragments in flight per wave (register ring)
+// The ONE build-time switch of the library's measurement paths (never set by the Makefile): -DSKP_PROBES=<bits> compiles timing probes whose
+// RESULTS ARE WRONG -- & 1: no weight DMA after a kernel's first stages; & 2: no MFMAs in the chunk loops (tools/gc_edge_probe.py).
+#ifndef SKP_PROBES
+#define SKP_PROBES 0
 #endif
 __device__ __forceinline__ f32x4 fz_mfma(const uint4& a, const OpT<f16>::v8& b, const f32x4& c) {
-    if (FZ_PROBE & 2) return c;
+    if (SKP_PROBES & 2) return c;
     return OpT<f16>::mfma(as_v8<f16>(a), b, c);
 }
 constexpr int FZ_L = 512, FZ_KS = 16, FZ_CF = 32, FZ_NCH = 16, FZ_TILE = 128;
@@ -105,7 +100,7 @@ __device__ __forceinline__ void fz_steps(const char* st, Body&& body) {
 // A TIME between MFMAs: issuing one costs the wave ~60-85 clocks (measured: 16 in a burst add 1.4 k clocks per stage to a wave that has
 // the SIMD to itself), which the matrix pipe covers only when it has work queued.
 __device__ __forceinline__ void fz_piece(const f16* src, unsigned dst, int k, int wave, int lane, bool first = false) {
-    if ((FZ_PROBE & 1) && !first) return;
+    if ((SKP_PROBES & 1) && !first) return;
     const int q = wave + 4 * k;
     glds16(src + (q << 9) + lane * 8, dst + (unsigned)(q << 10));
 }
@@ -561,7 +556,7 @@ edge_update_kernel(const EdgeArgs a) {
                 if (ends & (1u << i)) {                    // the run ends with row r0 + i (uniform branch)
                     const int cur = __builtin_amdgcn_readlane(r0 < 64 ? rv0 : rv1, (r0 + i) & 63);
                     if (cur >= 0) {
-                        if (tile_cont && cur == first) *head_c = acc;
+                        if (tile_cont && cur == first) { if (a.heads) *head_c = acc; }      // heads == NULL: the caller vouched that no tile continues (header)
                         else out_c[(long long)cur * FZ_L] = acc;
                     }
                     acc = 0.f;

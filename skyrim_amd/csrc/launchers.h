@@ -23,7 +23,6 @@ struct LinW { const T* w; long long plane; int ldw; };   // [N][ldw] hi plane (+
 template <class T>
 struct BlockW {
     LinW<T> qkv, proj, fc1, fc2;
-    LinW<f16> fc2h;          // fc2 weight as fp16 hi/lo planes (only in the fp16-hidden mode)
     const T *w1f, *w2f;      // fc1 / fc2 in the fused MLP's fragment order (fused_mlp.hip), or null
     const T *projf, *qkvf;   // proj / qkv in the row-tile kernels' fragment order (rowtile.hip), or null
     const T *projh, *w1h, *w2h;   // proj / fc1 / fc2 in fragment order, HI PLANE ONLY: the two-term block kernel (fused_block2.hip), or null
@@ -59,7 +58,6 @@ struct Work {
     T *ao, *hid, *u;         // hi/lo planes: + ao_plane / hid_plane / u_plane
     long long ao_plane, hid_plane, u_plane;
     const T* zrow;           // zeros (padding rows of the DMA GEMMs)
-    int hid16;               // 1: MLP hidden stored as ONE fp16 plane (hid reinterpreted as f16*), fc2 runs 2-term fp16
     int qkv_a1;              // 1 (fp16 planes only): QKV reads only the hi plane of the stream (2 MFMA terms)
     float2* stats;
 };
@@ -73,6 +71,7 @@ struct AttnArgs {
     typename P::T* out;
     long long out_plane;
     int ld_out, n_win, nW, heads;
+    int out_planes = 0;      // 1: only the hi plane of the output is written (its reader is a one-term block kernel); 0: the mode's own
 };
 
 // layer index 0..3 -> resolution 0/1, channels, heads
@@ -101,10 +100,8 @@ hipError_t op_qkv_rowtile(const Geom&, const BlockW<f16>&, const int* widx, int 
 template <class T> hipError_t prep_rowtile_weights(const float* w, T* wf, int N, int K, hipStream_t, int planes = 2);
 // proj + LayerNorm + residual + MLP + LayerNorm + residual in one kernel (fused_block.hip): weights from prep_rowtile_weights / prep_mlp_weights
 template <class P> hipError_t op_proj_mlp_fused(const Geom&, const BlockW<typename P::T>&, const int* winv, int res, typename P::T* Xs, const Work<P>&, hipStream_t);
-// the same with TWO MFMA terms (weights as one fp16 plane) and the two waves of a SIMD half a chunk apart (fused_block2.hip)
-hipError_t op_proj_mlp_skew(const Geom&, const BlockW<f16>&, const int* winv, int res, f16* Xs, const Work<PrecF16x3>&, hipStream_t, int one = 0);   // one: the activation operands as one fp16 plane too
-// the same on WIDE row tiles: one wave per SIMD, 32 / 64 rows per wave, persistent workgroups (fused_block_wide.hip)
-hipError_t op_proj_mlp_wide(const Geom&, const BlockW<f16>&, const int* winv, int res, f16* Xs, const Work<PrecF16x3>&, hipStream_t, int one = 0);
+// the same with the weights as ONE fp16 plane: two MFMA terms, or -- `one` -- a single term (activation operands as one fp16 plane too) (fused_block2.hip)
+hipError_t op_proj_mlp2(const Geom&, const BlockW<f16>&, const int* winv, int res, f16* Xs, const Work<PrecF16x3>&, hipStream_t, int one = 0);
 template <class T, int NPL> hipError_t split_planes(const float* x, T* planes, long long plane, long long n, int C, hipStream_t);
 template <class T> hipError_t merge_planes(const T* planes, long long plane, float* x, long long n, int C, hipStream_t);
 

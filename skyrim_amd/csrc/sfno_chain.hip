@@ -121,11 +121,7 @@ __device__ __forceinline__ void run_pair(const v8 (&xh)[S::FM][KS], const v8 (&x
                                          const float* b1, const char* stA, const char* stB, unsigned ldsA, unsigned ldsB, int wave, int lane, After&& after_last) {
     constexpr int FM = S::FM, DEPTH = 3, NS = KS * 2, W1_BLK = KS * 4, W2_BLK = CF * 2;
     const int g = lane >> 4;
-#ifdef SKP_PROBE_NO_COMPUTE      // timing probe: one chunk instead of NCH
-    for (int j = 0; j < 1; ++j) {
-#else
     for (int j = 0; j < NCH; ++j) {
-#endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                               // W1 block j landed; every wave is done with W2 block j - 1
         dma_blocks<W2_BLK, S::NWAVES>(w2f + ((long long)j * W2_BLK << 9), ldsB, wave, lane);

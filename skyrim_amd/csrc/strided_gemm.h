@@ -209,13 +209,7 @@ struct EpStrided {
     }
 };
 
-#ifndef SKP_STRIDED_BK
-#define SKP_STRIDED_BK 32
-#endif
-#ifndef SKP_STRIDED_TILE
-#define SKP_STRIDED_TILE 128, 256, SKP_STRIDED_BK, 2, 4
-#endif
-typedef TileCfg<SKP_STRIDED_TILE> TG;      // wide N: the fp32 A operand is fetched and split once per 256 output columns
+typedef TileCfg<128, 256, 32, 2, 4> TG;      // wide N: the fp32 A operand is fetched and split once per 256 output columns
 
 struct BatchStrides { long long a, w, o; int k_lo_step, m_cap0, m_cap_step, xcd_remap; };
 

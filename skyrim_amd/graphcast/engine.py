@@ -98,7 +98,7 @@ class GraphcastEngine:
         mesh->grid edges they receive.  MESH side ("all-gather of the small mesh latent"): it owns a contiguous range of mesh
         nodes with the multi-mesh edges they RECEIVE (owner computes: edge update, receiver sum, node update), and after each of the 16
         processor layers the ranks all-gather the updated node latents (n_mesh x latent fp32 = 84 MB at full size; 0.27 ms per layer
-        over one xGMI link at 2 GPUs) -- ``gather_fn(out [world, per, latent], mine [per, latent])``, default
+        over one xGMI link at 2 GPUs) -- ``gather_fn(out [world, per, latent], mine [per, latent])`` with ``mine`` a view of ``out[rank]`` (in place), default
         ``torch.distributed.all_gather_into_tensor``.  The other exchange of a step
         is ``reduce_fn(agg)`` = the sum over ranks of the (n_mesh, latent) aggregate of the grid->mesh messages (default:
         ``torch.distributed.all_reduce`` = RCCL over xGMI; 84 MB at full size).  ``graph``: the FULL graph (built if omitted)."""
@@ -373,18 +373,16 @@ class GraphcastEngine:
 
     def _exchange_nodes(self, nl):
         """all-gather of the updated node latents of a mesh-sharded step (84 MB at full size)."""
-        L = self.cfg.latent
         self._mark("exchange")
-        self.xmine[:nl].copy_(self.vm[self.mn0:self.mn1])
+        # IN PLACE: the node latents live in a buffer of world x mn_per rows (the last rank's share padded), every rank's share at its own
+        # offset, so the collective's output IS ``vm`` and its input is this rank's slice of it (ncclAllGather's in-place form:
+        # sendbuff = recvbuff + rank x count) -- no staging copy, no scatter loop
+        mine = self.vm_store[self.rank * self.mn_per:(self.rank + 1) * self.mn_per]
         if self.gather_fn is not None:
-            self.gather_fn(self.xbuf, self.xmine)
+            self.gather_fn(self.vm_store.view(self.world, self.mn_per, self.cfg.latent), mine)
         else:
             import torch.distributed as dist
-            dist.all_gather_into_tensor(self.xbuf.view(self.world * self.mn_per, L), self.xmine)
-        for r in range(self.world):
-            n0, n1 = min(r * self.mn_per, self.graph.n_mesh), min((r + 1) * self.mn_per, self.graph.n_mesh)
-            if r != self.rank and n1 > n0:
-                self.vm[n0:n1].copy_(self.xbuf[r, :n1 - n0])
+            dist.all_gather_into_tensor(self.vm_store, mine)
 
     # ---- prepare ------------------------------------------------------------------------------------- #
     def load_params(self, params: dict):
@@ -446,8 +444,6 @@ class GraphcastEngine:
                 self.me_s, self.me_r = self.me_s[self.me0:self.me1].contiguous(), self.me_r[self.me0:self.me1].contiguous()
                 self.me_off = i32(off[self.mn0:self.mn1 + 1] - self.me0)
                 EM = self.me1 - self.me0
-                self.xbuf = torch.zeros(self.world, self.mn_per, L, dtype=torch.float32, device=dev)
-                self.xmine = torch.zeros(self.mn_per, L, dtype=torch.float32, device=dev)
             self.P, self.E1, self.EM, self.E2 = P, E1, EM, E2
             # mesh -> grid: every grid node receives exactly three edges (the corners of its triangle), stored receiver by receiver.
             # The edge MLP then runs in "virtual row" order -- row 48 t + 16 a + l = edge a of grid node 16 t + l -- so that its epilogue
@@ -463,7 +459,9 @@ class GraphcastEngine:
             self.feat = torch.zeros(c.grid_in, P, dtype=torch.float32, device=dev)          # [186][n_grid]: states, forcings, static, structural
             self.feat[n_state + N_FORCING:n_state + N_FORCING + N_STATIC] = f32(params["static"][:, self.lat0:self.lat1]).reshape(N_STATIC, P)
             self.feat[n_state + N_FORCING + N_STATIC:] = torch.from_numpy(g.grid_node_feat.T.copy()).to(dev)
-            self.vg, self.vm = buf(P, L), buf(g.n_mesh, L)
+            # mesh-node latents: in a mesh-sharded run the buffer holds world x mn_per rows (>= n_mesh) so that the all-gather writes it in place
+            self.vm_store = torch.zeros(self.world * self.mn_per if self.shard_mesh else g.n_mesh, L, dtype=torch.float32, device=dev)
+            self.vg, self.vm = buf(P, L), self.vm_store[:g.n_mesh]
             self.agg_m, self.agg_g = buf(g.n_mesh, L), buf(P, L)
             if self.fused:                                       # the fused path keeps no fp32 edge latents at all
                 self.e1 = self.em = self.e2 = self.de = None
@@ -558,17 +556,7 @@ class GraphcastEngine:
                     self._segsum(de, self.me_off, agg_own, nl, acc=self.em)                      # receiver sum; em += de rides along
                     self._mlp(f"proc.{i}.node", [(vm_own, None, L), (agg_own, None, L)], nl, vm_own, res=vm_own, label="processor")
                     if self.shard_mesh:                  # all-gather of the updated node latents (84 MB at full size)
-                        self._mark("exchange")
-                        self.xmine[:nl].copy_(vm_own)
-                        if self.gather_fn is not None:
-                            self.gather_fn(self.xbuf, self.xmine)
-                        else:
-                            import torch.distributed as dist
-                            dist.all_gather_into_tensor(self.xbuf.view(self.world * self.mn_per, L), self.xmine)
-                        for r in range(self.world):
-                            n0, n1 = min(r * self.mn_per, self.graph.n_mesh), min((r + 1) * self.mn_per, self.graph.n_mesh)
-                            if r != self.rank and n1 > n0:
-                                self.vm[n0:n1].copy_(self.xbuf[r, :n1 - n0])
+                        self._exchange_nodes(nl)
                 # decoder: mesh -> grid
                 if self.m2g_group is not None:
                     # edge update + receiver sum in one kernel: node terms once per node, then sum over a node's three edges of

@@ -68,17 +68,21 @@ def _parallel_payload_write(path, offset: int, payload: np.ndarray, threads: int
             except (OSError, ValueError):
                 view = None                                            # not mappable (some network / FUSE targets): pwrite below
         if view is not None:
+            dst = np.frombuffer(view, dtype=">f4", count=n, offset=offset - base)
             try:
-                dst = np.frombuffer(view, dtype=">f4", count=n, offset=offset - base)
-
                 def put(i0):
                     dst[i0:i0 + chunk] = flat[i0:i0 + chunk]           # cast + byte swap in one pass, into the mapping
 
                 with ThreadPoolExecutor(max_workers=threads) as pool:
                     list(pool.map(put, range(0, n, chunk)))
-                del dst
             finally:
-                view.close()                                           # (a failed store -- SIGBUS on ENOSPC aside -- raises above; close never hides it)
+                # the array exports the mapping's buffer: it has to go BEFORE close(), also when a store raised -- otherwise close() raises
+                # BufferError on top of (and instead of) the store's own error
+                del dst, put
+                try:
+                    view.close()
+                except BufferError:                                    # a traceback still holds a frame that holds the array: leave the unmap to the GC
+                    pass
             return
 
         def put(i0):

@@ -256,6 +256,14 @@ def _gc_edge_update(e_in, e_out, term, term_off, ld, idx, recv, w1f, w2f, b2, ga
     d.w2f = _f16(w2f, "w2f", dev)
     d.b2, d.gamma, d.beta = _f32(b2, "b2", dev).value, _f32(gamma, "gamma", dev).value, _f32(beta, "beta", dev).value
     d.agg = _f32(agg, "agg").value
+    if heads is not None:
+        if heads.numel() < rows // 128 * 512:
+            raise ValueError("gc_edge_update: heads holds one 512-wide row per 128-row tile")
+    elif rows > 128 and bool((recv[127:rows - 1:128] == recv[128:rows:128]).any().item()):
+        # (one device sync, on this path only: the engine's packed orders always come with their heads buffer)
+        raise ValueError("gc_edge_update: a receiver's run continues across a tile boundary -- pass a heads buffer (and run gc_segment_fixup)")
+    if agg.numel() < 512 or any(t.numel() - off < l for t, off, l in zip(term, term_off, ld)):
+        raise ValueError("gc_edge_update: agg / term buffers are smaller than one row")
     d.heads = _f32(heads, "heads", dev).value if heads is not None else None
     d.rows, d.has_fc1, d.w1_planes = rows, int(w1f is not None), w1_planes
     if w1f is not None and w1f.numel() != w1_planes * 512 * 512:

@@ -18,31 +18,33 @@ from .spec import PanguGeometry
 
 PREC_BF16X3 = 0
 PREC_F16 = 1
-PREC_BF16X3_H16 = 2
 PREC_F16X3 = 3
 PREC_F16X3_Q = 4
-PREC_F16X3_QH = 5
 # per-layer MFMA term plan (skpangu_config.term_plan): bit l = layer l + 1 runs proj / fc1 / fc2 with two terms (weights as ONE fp16 plane);
-# bits 4-7: the layer's QKV with ONE term (stream hi plane x weight hi plane)
-TERM_PLANS = {"f16x2m": 0x6F, "f16x2c": 0x66, "f16x2": 0x0F, "f16x2q": 0xFF, "f16x1m": 0x66F}
-PRECISIONS = {"bf16x3": PREC_BF16X3, "f16": PREC_F16, "bf16x3h": PREC_BF16X3_H16,
-              "f16x3": PREC_F16X3, "f16x3q": PREC_F16X3_Q, "f16x3qh": PREC_F16X3_QH, **{m: PREC_F16X3_Q for m in TERM_PLANS}}
-# default "f16x2m" (plan 0x6F): fp16 hi/lo ACTIVATION planes everywhere; proj / fc1 / fc2 of EVERY block with their weights as ONE fp16 plane
-# (2 MFMA terms, A_hi W + A_lo W); QKV with one term in layers 2 / 3 (C = 384: 12 of the 16 blocks) and two (hi/lo weights) in the
-# full-resolution layers 1 / 4, whose QKV rounding is what costs accuracy at 721x1440.  The term a one-plane Linear drops,
-# A x (W - fp16(W)), has its mean over a calibration state folded into the bias at load time (``PanguEngine.calibrate``): measured at
-# 721x1440 over four steps, plan 0xFF 8.4e-4 -> 7.4e-4, 0x66 5.0e-4 -> 2.9e-4, 0x0F 5.0e-4 (calibrated).  "f16x2c" keeps layers 1 / 4 at three
-# terms (0x66, round 3's first default), "f16x2q" / "f16x2" are the all-layers plans 0xFF / 0x0F, "f16x3q" is three terms everywhere
-# (~1e-4), "bf16x3" the wide-range alternative (activations beyond fp16's 65504).  "f16x1m" (0x66F; bits 8-11: the layer's proj / fc1 / fc2 with
-# ONE term, the activation operands as their fp16 hi plane) is f16x2m with the coarse layers 2 / 3 at half the MFMAs again; it wants
-# rounding="compensated" (pangu/calibration.py fits the weights to the rounded operands): oracle emulation 1.3e-4 against 6.5e-5.
-DEFAULT_PRECISION = "f16x2m"
+# bits 4-7: the layer's QKV with ONE term (stream hi plane x weight hi plane); bits 8-11: the layer's proj / fc1 / fc2 with ONE term (the
+# activation operands as their fp16 hi plane too).  Any other plan: PanguEngine(geom, "f16x3q", term_plan=...).
+TERM_PLANS = {"f16x1m": 0x66F, "f16x2m": 0x6F, "f16x2c": 0x66}
+PRECISIONS = {"bf16x3": PREC_BF16X3, "f16": PREC_F16, "f16x3": PREC_F16X3, "f16x3q": PREC_F16X3_Q, **{m: PREC_F16X3_Q for m in TERM_PLANS}}
+# Modes (all: fp16 hi/lo ACTIVATION planes in the residual stream, fp32 accumulation / LayerNorm / softmax / GELU, fp16 attention core):
+#   "f16x1m"  DEFAULT since round 5 (plan 0x66F).  Every block's proj / fc1 / fc2 weights are ONE fp16 plane; in the coarse layers 2 / 3 (C = 384:
+#             12 of the 16 blocks, 72 % of the FLOPs) those GEMMs read the activations' hi plane only -- ONE MFMA term, A_hi W -- and the QKV
+#             is one term too; the full-resolution layers 1 / 4 keep two terms (A_hi W + A_lo W) and hi/lo QKV weights.  The one-plane
+#             weights are rounded with error feedback against the (rounded) operands' statistics (rounding="compensated", below), which is
+#             what pays for the activation rounding.  16.2 ms per step at 721x1440 against 18.4 for "f16x2m"; per-channel error over the
+#             full-size 24-h rollout 2.5 / 2.8 / 2.7 / 2.8e-4 (f16x2m: 1.4 / 1.7 / 1.6 / 1.7e-4), on states the calibration never saw
+#             (power-law spectrum, other smoothing scales, meridional structure) 1.6 - 2.0e-4, on a gain-1 network over 20 steps <= 4.2e-4
+#             (tests/test_pangu_numerics_gpu.py) -- three times inside the 1e-3 bar everywhere it was looked at.
+#   "f16x2m"  round 3 / 4's default (0x6F): two terms in every block, one-term QKV in layers 2 / 3.
+#   "f16x2c"  0x66: layers 1 / 4 at three terms.   "f16x3q": three terms everywhere (~1e-4), QKV from the stream's hi plane.
+#   "f16x3"   three terms, hi/lo QKV operand.      "bf16x3": the wide-range alternative (activations beyond fp16's 65504).
+#   "f16"     single fp16 plane everywhere: a speed probe, NOT inside the bar (~1.2e-3).
+# The term a one-plane Linear drops, A x (W - fp16(W)), has its mean over a calibration state folded into the bias at load time
+# (``PanguEngine.calibrate``).
+DEFAULT_PRECISION = "f16x1m"
 # Rounding of the one-plane weights (PanguEngine.load_params).  "compensated" (pangu/calibration.py: error feedback against the operand
 # statistics of the calibration state and of its own forecast) is the default since round 4: a load-time choice, the kernels and the step time
-# are the same, and at 721x1440 the default plan's error over the 24-h rollout is 1.4 / 1.7 / 1.6 / 1.7e-4 instead of 4.2 / 5.9 / 5.8 / 5.4e-4
-# with "nearest" (three terms everywhere: 1.0 / 1.2 / 1.2 / 1.2e-4) -- the margin the two-term plan gave away.  With 1 % of the weight rows
-# scaled x5 it holds 9e-5 (nearest: 2.8e-4); x30 on every Linear class at once breaks EVERY mode, three-term and bf16x3 included, at ~1e-2
-# (tools/pangu_outlier_scan.py: the attention's one-plane fp16 operands, not the term plan).
+# are the same.  With 1 % of the weight rows scaled x5 the two-term plan holds 9e-5 (nearest: 2.8e-4); x30 on every Linear class at once
+# breaks EVERY mode, three-term and bf16x3 included, at ~1e-2 (tools/pangu_outlier_scan.py: the attention's one-plane fp16 operands).
 DEFAULT_ROUNDING = "compensated"
 
 _LIB_PATH = Path(__file__).resolve().parent.parent / "lib" / "libskyrim_pangu.so"
@@ -182,7 +184,7 @@ class PanguEngine:
                  surface: str = "first", qkv_order: str = "3hd", bias_index: str = "qk"):
         """``roll_sign`` / ``mask_value`` / ``geom.pad``: the conventions the public pseudocode leaves open.
         ``mlp``: "fused" (default; one kernel per MLP in the 3-term modes, csrc/fused_mlp.hip) or "split" (two tiled GEMMs).
-        ``term_plan``: per-layer two-term mask (include/skyrim_pangu.h); None = the precision name's own ("f16x2": all four layers).
+        ``term_plan``: per-layer two-term mask (include/skyrim_pangu.h); None = the precision name's own.
         ``surface`` / ``qkv_order`` / ``bias_index``: three more open conventions (oracle: Conventions of the same names), prepare-time only."""
         self.lib = load_library()
         if not torch.cuda.is_available():
@@ -191,7 +193,7 @@ class PanguEngine:
         self.precision = precision
         self.device = torch.device(device)
         if mlp != "fused" and precision in TERM_PLANS and term_plan is None:
-            term_plan = 0                                   # the tiled-GEMM path has no two-term kernels: "f16x2" + split = f16x3q + split
+            term_plan = 0                                   # the tiled-GEMM path has no two-term kernels: a plan name + split = f16x3q + split
         self.cfg = make_config(self.geom, precision, roll_sign, mask_value, mlp, term_plan, surface, qkv_order, bias_index)
         self._conventions = dict(roll_sign=roll_sign, mask_value=mask_value, surface=surface, qkv_order=qkv_order, bias_index=bias_index)
         self.mlp = mlp
@@ -205,6 +207,8 @@ class PanguEngine:
                                        self._workspace.data_ptr(), self.sizes.workspace_bytes, ctypes.byref(self._ctx)),
                "skpangu_create")
         self.state_shape = (self.geom.n_channels, self.geom.n_lat, self.geom.n_lon)
+        # compensated rounding pools the operand statistics of the calibration state and of this many of its successive 6-h forecasts
+        self.calibration_forecasts = int(os.environ.get("SKYRIM_PANGU_CALIBRATION_FORECASTS", "1"))
 
     def __del__(self):
         ctx = getattr(self, "_ctx", None)
@@ -285,8 +289,9 @@ class PanguEngine:
                 tap = PanguEngine(self.geom, "f16x3q", self.device, mlp="split", **self._conventions)
                 tap.load_params(self._params, calibration="off")
                 with torch.no_grad(), torch.cuda.device(self.device):
-                    first = state.to(self.device, torch.float32).contiguous()
-                    states = [first, tap.step(first)]           # the state and its own 6-h forecast: a rollout's later inputs are model outputs
+                    states = [state.to(self.device, torch.float32).contiguous()]
+                    for _ in range(self.calibration_forecasts):  # the state and its own forecast(s): a rollout's later inputs are model outputs
+                        states.append(tap.step(states[-1]))
                     params = calibrated_params(self._params, self.term_plan, engine_taps(tap, self._params, states))
                 del tap
             self._prepare(params)                               # fp16-grid weights: the library's own rounding leaves them as they are

@@ -70,7 +70,9 @@ def _load_state(path: str, geom: PanguGeometry) -> torch.Tensor:
 
 
 class PanguTimeLoop:
-    RANGE_LIMIT = 512.0          # sigma: 512 x 2^-22 = 1.2e-4 of an O(1) signal
+    # sigma: 512 x 2^-22 = 1.2e-4 of an O(1) signal.  An API divergence: the reference accepts any state; here an initial condition beyond the
+    # limit raises FloatingPointError (one blocking .item() per forecast).  SKYRIM_PANGU_RANGE_LIMIT=<sigma> (or `inf`) overrides it.
+    RANGE_LIMIT = float(os.environ.get("SKYRIM_PANGU_RANGE_LIMIT", "512"))
     n_history_levels = 1
     time_step = datetime.timedelta(hours=6)
     in_channel_names = list(CHANNELS)

@@ -25,10 +25,10 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in skyrim_pangu.h but not exported"
     assert set(syms) == set(E.EXPORTS)
-    assert lib.skpangu_abi_version() == 4
+    assert lib.skpangu_abi_version() == 5
 
 
-@pytest.mark.parametrize("prec", ["bf16x3", "f16", "f16x3q", "f16x3qh", "f16x2", "f16x2q", "f16x2m", "f16x2c", "f16x1m"])
+@pytest.mark.parametrize("prec", ["bf16x3", "f16", "f16x3", "f16x3q", "f16x2m", "f16x2c", "f16x1m"])
 @pytest.mark.parametrize("grid", [(49, 192), (721, 1440)])
 def test_param_table_matches_host_spec(grid, prec):
     g = PanguGeometry(*grid)
@@ -52,18 +52,18 @@ def test_term_plan_sizes_and_validation():
     g = PanguGeometry(721, 1440)
     lib = E.load_library()
     sizes = {}
-    for prec in ("f16x3q", "f16x2", "f16x2q"):
-        sizes[prec] = E.query_sizes(g, prec, E.make_config(g, prec)).prepared_bytes
+    for prec, plan in (("f16x3q", 0), ("f16x2", 0x0F), ("f16x2q", 0xFF)):
+        sizes[prec] = E.query_sizes(g, "f16x3q", E.make_config(g, "f16x3q", term_plan=plan)).prepared_bytes
     assert sizes["f16x2q"] < sizes["f16x2"] < sizes["f16x3q"]
-    assert E.make_config(g, "f16x2").term_plan == 0x0F and E.make_config(g, "f16x2q").term_plan == 0xFF and E.make_config(g, "f16x3q").term_plan == 0
-    assert E.make_config(g).term_plan == 0x6F and E.make_config(g, "f16x2c").term_plan == 0x66
+    assert E.make_config(g, "f16x3q").term_plan == 0 and E.make_config(g, "f16x2m").term_plan == 0x6F and E.make_config(g, "f16x2c").term_plan == 0x66
+    assert E.DEFAULT_PRECISION == "f16x1m" and E.make_config(g).term_plan == 0x66F
     assert E.make_config(g, "f16x3q", term_plan=0x3).term_plan == 3
     with pytest.raises(ValueError):
         E.make_config(g, "bf16x3", term_plan=1)
     with pytest.raises(ValueError):
-        E.make_config(g, "f16x2", mlp="split")
+        E.make_config(g, "f16x2m", mlp="split")
     out = E.SkSizes()
-    bad = E.make_config(g, "f16x2")
+    bad = E.make_config(g, "f16x2m")
     for plan, ok in ((0x100, False), (0x1000, False), (0x210, False), (0x101, True), (0x66F, True), (0xFFF, True)):
         bad.term_plan = plan                  # bits 8-11 (one-term block GEMMs) need the layer's two-term bit; nothing beyond 12 bits
         assert (lib.skpangu_query_sizes(ctypes.byref(bad), ctypes.byref(out)) == 0) == ok, hex(plan)

@@ -2,13 +2,12 @@
 
 Tolerances (floating point; stated per the north star): per-channel max|y - ref| / max|ref| <= 1e-3.
 Modes (skyrim_amd/pangu/engine.py PRECISIONS): hi/lo split GEMMs with fp16 single-term attention --
-"f16x2m" (default: term plan 0x6F -- proj / fc1 / fc2 of every block with ONE fp16 weight plane, 2 MFMA terms; QKV one term in layers 2 / 3, two in
-layers 1 / 4; the dropped weight residue's mean folded into the biases on a calibration state (skpangu_calibrate); 4.2e-4 .. 5.9e-4 measured over
-four full-size steps -> asserted <= 7e-4), "f16x2c" (0x66: layers 1 / 4 at three terms; 1.7e-4 .. 3.1e-4 -> <= 7e-4), "f16x2q" / "f16x2" (the
-all-layers plans 0xFF / 0x0F: 5.2e-4 .. 7.2e-4 / 3.7e-4 .. 4.7e-4 at full size -> held to the 1e-3 bar only),
-"f16x3q" (the same with 3 terms; observed ~1e-4 -> asserted <= 3e-4), "f16x3", "bf16x3" (3 terms
-everywhere; ~8e-5 -> <= 3e-4), "bf16x3h" / "f16x3qh" (additionally the MLP hidden as one fp16 plane; ~4e-4 ->
-asserted <= 1e-3), and "f16" (single-term speed mode, observed ~1.2e-3, does NOT meet the bar -> held to 5e-3).
+"f16x1m" (DEFAULT since round 5: term plan 0x66F -- proj / fc1 / fc2 of every block with ONE fp16 weight plane; the coarse layers 2 / 3 read the
+activation operands' hi plane only, ONE MFMA term, and their QKV is one term; layers 1 / 4 keep two terms; weights rounded with error
+feedback (compensated) on the built-in calibration state; 2.5 .. 2.8e-4 measured over the full-size 24-h rollout -> asserted <= 3.2e-4),
+"f16x2m" (round 4's default, 0x6F: two terms everywhere; 1.4 .. 1.7e-4 -> <= 3e-4), "f16x2c" (0x66: layers 1 / 4 at three terms),
+"f16x3q" (3 terms; observed ~1e-4 -> asserted <= 3e-4), "f16x3", "bf16x3" (3 terms everywhere; ~8e-5 -> <= 3e-4), and "f16" (single-term
+speed probe, observed ~1.2e-3, does NOT meet the bar -> held to 5e-3).  Other plans: PanguEngine(g, "f16x3q", term_plan=...).
 Stage-level tests use max-abs / max-abs-ref.
 """
 import os
@@ -24,11 +23,12 @@ from skyrim_amd.pangu.spec import PanguGeometry, init_synthetic, synthetic_state
 
 pytestmark = pytest.mark.gpu
 
-STAGE_TOL = {"f16x2m": 1.5e-3, "f16x2c": 1.5e-3, "f16x2q": 1.5e-3, "f16x2": 1.5e-3, "bf16x3": 5e-4, "f16x3": 5e-4, "f16x3q": 5e-4, "bf16x3h": 2e-3, "f16x3qh": 2e-3, "f16": 4e-3}
-# the default mode's asserted step error (STEP_TOL[DEFAULT_PRECISION]): the two-term plan with compensated rounding (the default since round 4),
-# measured at 721x1440 at 1.4e-4 (1 step) .. 1.7e-4 (4 steps) -- 3x inside the bar, where nearest rounding (4.2 .. 5.9e-4) needed 7e-4
-DEF_TOL = 3e-4
-STEP_TOL = {"f16x2m": 3e-4, "f16x2c": 3e-4, "f16x2q": 1e-3, "f16x2": 1e-3, "bf16x3": 3e-4, "f16x3": 3e-4, "f16x3q": 3e-4, "bf16x3h": 1e-3, "f16x3qh": 1e-3, "f16": 5e-3}   # 3-term modes: 3x inside the bar
+STAGE_TOL = {"f16x1m": 1.5e-3, "f16x2m": 1.5e-3, "f16x2c": 1.5e-3, "bf16x3": 5e-4, "f16x3": 5e-4, "f16x3q": 5e-4, "f16": 4e-3}
+# the default mode's asserted error per step (STEP_TOL[DEFAULT_PRECISION]).  Round 5: the one-term coarse layers, measured at 721x1440 over the 24-h
+# rollout at 2.50 / 2.78 / 2.75 / 2.84e-4 (2.0 .. 3.05e-4 across what the rounding is fitted on: tools/r5_x1m_full.py), toy grid 1.5e-4 -- three
+# times inside the bar; the two-term plan (round 4's default) sits at 1.4 .. 1.7e-4 and is held to 3e-4.
+DEF_TOL = 3.2e-4
+STEP_TOL = {"f16x1m": DEF_TOL, "f16x2m": 3e-4, "f16x2c": 3e-4, "bf16x3": 3e-4, "f16x3": 3e-4, "f16x3q": 3e-4, "f16": 5e-3}   # 3-term modes: 3x inside the bar
 
 
 def rel(a, b):
@@ -180,7 +180,7 @@ def test_profile_hooks_cover_the_step(eng, toy):
     eng.profile(False)
     by = {s["name"]: s for s in stats}
     # 3-term modes: projection + MLP as one kernel per block (fused_block.hip); the others: proj, fc1, fc2 as separate launches
-    mlp = "proj_mlp_r1" if eng.precision in ("f16x2m", "f16x2c", "f16x2q", "f16x2", "f16x3q", "f16x3", "bf16x3") else "fc1_r1"
+    mlp = "proj_mlp_r1" if eng.precision != "f16" else "fc1_r1"
     assert by[mlp]["launches"] == 12 and by["qkv_r0"]["launches"] == 4 and by["embed"]["launches"] == 1
     assert by["fc2_r1"]["launches"] == by["proj_r1"]["launches"] == (0 if mlp == "proj_mlp_r1" else 12)
     assert all(s["total_ms"] > 0 for s in stats if s["launches"])
@@ -241,11 +241,11 @@ def test_full_size_term_plans_vs_oracle(full, full_ref):
     from skyrim_amd.pangu.engine import PanguEngine
     g, params, x, _ = full
     import os
-    # (plan, calibration, rounding, asserted bound at EVERY step): the default (two-term plan, compensated rounding) 3x inside the bar; the same
-    # plan with nearest rounding (round 3's default) and the one-term coarse layers ("f16x1m", compensated) inside the bar; three terms everywhere
-    plans = [(0x6F, "synthetic", "compensated", 3e-4), (0x6F, "synthetic", "nearest", 1e-3), (0x66F, "synthetic", "compensated", 1e-3), (0x00, "off", "nearest", 3e-4)]
+    # (plan, calibration, rounding, asserted bound at EVERY step): the two-term plan of round 4's default 3x inside the bar; three terms everywhere;
+    # (the default plan 0x66F itself is test_full_size_24h_rollout_vs_oracle).  SKYRIM_TEST_ALL_PLANS=1: the rest of DESIGN.md 3's table
+    plans = [(0x6F, "synthetic", "compensated", 3e-4), (0x00, "off", "nearest", 3e-4)]
     if os.environ.get("SKYRIM_TEST_ALL_PLANS"):             # the rest of the table of DESIGN.md 3 (13 s of calibration per compensated plan)
-        plans += [(0x6F, "off", "nearest", 1e-3), (0xFF, "synthetic", "nearest", 1e-3), (0xFF, "off", "nearest", 1e-3), (0x0F, "synthetic", "nearest", 1e-3),
+        plans += [(0x6F, "synthetic", "nearest", 1e-3), (0x66F, "synthetic", "compensated", 1e-3), (0x6F, "off", "nearest", 1e-3), (0xFF, "synthetic", "nearest", 1e-3), (0xFF, "off", "nearest", 1e-3), (0x0F, "synthetic", "nearest", 1e-3),
                   (0x66, "synthetic", "nearest", 1e-3), (0x66, "off", "nearest", 1e-3), (0xFF, "synthetic", "compensated", 1e-3), (0x66F, "synthetic", "nearest", 1e-3)]
     for plan, cal, rounding, bound in plans:
         e = PanguEngine(g, "f16x3q", "cuda:0", term_plan=plan)
@@ -528,12 +528,12 @@ def test_calibration_folds_the_dropped_weight_term_into_the_biases(toy, ref):
     _, y_ref = ref
     errs, outs = {}, {}
     for cal in ("off", "synthetic"):
-        eng = PanguEngine(g, "f16x2q", "cuda:0")
+        eng = PanguEngine(g, "f16x3q", "cuda:0", term_plan=0xFF)
         eng.load_params(params, calibration=cal)
         assert eng.calibrated_on == (None if cal == "off" else "synthetic")
         outs[cal] = eng.step(x.cuda()).cpu()
         errs[cal] = O.per_channel_rel_err(outs[cal], y_ref).max().item()
-    print(f"f16x2q one step: uncalibrated {errs['off']:.2e}, calibrated {errs['synthetic']:.2e}")
+    print(f"plan 0xFF one step: uncalibrated {errs['off']:.2e}, calibrated {errs['synthetic']:.2e}")
     assert errs["synthetic"] < 0.85 * errs["off"], errs         # measured 5.0e-4 -> 3.8e-4 (the CPU emulation of the same: 4.9e-4 -> 2.8e-4)
     cs = calibration_state(g, params["norm.mean"], params["norm.std"])
     assert not torch.equal(cs, x)
@@ -551,7 +551,7 @@ def test_calibration_folds_the_dropped_weight_term_into_the_biases(toy, ref):
     e3.calibrate(cs)
     assert e3.calibrated_on is None and torch.equal(e3.step(x.cuda()), y3)
     with pytest.raises(ValueError):
-        PanguEngine(g, "f16x2q", "cuda:0").load_params(params, calibration="era5")
+        PanguEngine(g, "f16x3q", "cuda:0", term_plan=0xFF).load_params(params, calibration="era5")
 
 
 def test_calibration_taps_are_the_oracles_operands(toy, monkeypatch):
@@ -602,7 +602,7 @@ def test_compensated_rounding_of_the_one_plane_weights(toy, ref):
     taps, y_ref = ref
     errs = {}
     for rounding in ("nearest", "compensated"):
-        eng = PanguEngine(g, "f16x2q", "cuda:0")
+        eng = PanguEngine(g, "f16x3q", "cuda:0", term_plan=0xFF)
         eng.load_params(params, rounding=rounding)
         assert eng.rounding == rounding and eng.calibrated_on == "synthetic"
         state = x.cuda().clone()
@@ -614,10 +614,10 @@ def test_compensated_rounding_of_the_one_plane_weights(toy, ref):
     e3 = PanguEngine(g, "f16x3q", "cuda:0")
     e3.load_params(params)
     errs["three terms"] = O.per_channel_rel_err(e3.step(x.cuda()).cpu(), y_ref).max().item()
-    print("f16x2q one step: " + ", ".join(f"{k} {v:.2e}" for k, v in errs.items()))
+    print("plan 0xFF one step: " + ", ".join(f"{k} {v:.2e}" for k, v in errs.items()))
     assert errs["compensated"] < 0.6 * errs["nearest"] and errs["compensated"] < 3 * errs["three terms"], errs
     eng.calibrate(None)                                             # back to nearest rounding, master biases
-    off = PanguEngine(g, "f16x2q", "cuda:0")
+    off = PanguEngine(g, "f16x3q", "cuda:0", term_plan=0xFF)
     off.load_params(params, calibration="off")
     assert torch.equal(eng.step(x.cuda()), off.step(x.cuda()))
     # the operands the statistics are taken from are the oracle's (attention output, mid-block stream, hidden activation of block 0)

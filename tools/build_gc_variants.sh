@@ -1,6 +1,6 @@
 #!/bin/bash
 # Build-time variants of the fused GraphCast kernels for tools/gc_edge_probe.py (here, before gpurun: hipcc cross-compiles).
-#   bash tools/build_gc_variants.sh "name:flags" ...      e.g.  "unrolled:-DFZ_UNROLLED" "rd5:-DFZ_RD=5"
+#   bash tools/build_gc_variants.sh "name:flags" ...      e.g.  "nodma:-DSKP_PROBES=1" "nomfma:-DSKP_PROBES=2"
 set -eu
 cd "$(dirname "$0")/../skyrim_amd/csrc"
 mkdir -p ../lib/variants ../lib/obj

@@ -2,7 +2,7 @@
 
     SKYRIM_GRAPHCAST_LIB=skyrim_amd/lib/variants/libgc_<v>.so python tools/gc_edge_probe.py [tiles_fc1 tiles_static node_rows]
 
-Variants are built by tools/build_gc_variants.sh (-DFZ_UNROLLED, -DFZ_RD=n).  Measurement only; results are not checked here.
+Probe variants are built by tools/build_gc_variants.sh (-DSKP_PROBES=<bits>).  Measurement only; results are not checked here.
 """
 import os
 import sys

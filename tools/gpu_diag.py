@@ -168,7 +168,7 @@ if __name__ == "__main__":
     g = PanguGeometry(nlat, nlon)
     params = init_synthetic(g, 0)
     x = synthetic_state(g, 0)
-    for prec in (sys.argv[3:] or ["bf16x3", "bf16x3h", "f16"]):
+    for prec in (sys.argv[3:] or ["bf16x3", "f16x3q", "f16"]):
         try:
             run(prec, g, params, x)
         except Exception:
