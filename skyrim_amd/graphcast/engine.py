@@ -23,7 +23,7 @@ import torch
 from .. import ops
 from ..sfno import engine as _sf
 from . import fused as _fz
-from .mesh import GraphStructure, build_graph, grouped_rows_by3, latitude_band, shard_graph
+from .mesh import renumber_mesh, spatial_order, GraphStructure, build_graph, grouped_rows_by3, latitude_band, shard_graph
 from .spec import N_FORCING, N_STATIC, GraphcastConfig, mlp_names, param_spec
 
 _LIB_PATH = Path(__file__).resolve().parent.parent / "lib" / "libskyrim_graphcast.so"
@@ -120,6 +120,11 @@ class GraphcastEngine:
         self.sf = _sf.load_library()
         self.device = torch.device(device)
         full = graph or build_graph(self.cfg.n_lat, self.cfg.n_lon, self.cfg.splits)
+        # The multi-mesh numbers its nodes level by level; the engine works on a spatially coherent numbering (Morton order of the node
+        # positions) so that the sender rows gathered for neighbouring receivers -- neighbouring tiles of the receiver-sorted edge list -- are
+        # neighbours in memory too.  Mesh nodes never leave the engine: invisible outside (SKGC_MESH_ORDER=level keeps the caller's numbering).
+        if os.environ.get("SKGC_MESH_ORDER", "spatial") != "level":
+            full = renumber_mesh(full, spatial_order(full.mesh_pos))
         self.lat0, self.lat1 = latitude_band(self.cfg.n_lat, self.rank, self.world)
         self.graph = full if self.world == 1 else shard_graph(full, self.cfg.n_lat, self.cfg.n_lon, self.rank, self.world)
         self.prepared = False

@@ -192,6 +192,44 @@ def build_graph(n_lat: int, n_lon: int, splits: int) -> GraphStructure:
         mesh_node_feat=node_features(v), grid_node_feat=node_features(grid_pos, (np.deg2rad(glat), np.deg2rad(glon))), faces=f)
 
 
+def spatial_order(pos: np.ndarray, bits: int = 10) -> np.ndarray:
+    """Node indices in a locality-preserving order: sorted by the Morton (Z-order) code of the unit vectors quantised to ``bits`` bits per
+    axis -- neighbours on the sphere get neighbouring positions most of the time, at every scale of the multi-mesh."""
+    q = np.clip(((pos + 1.0) * 0.5 * ((1 << bits) - 1) + 0.5).astype(np.int64), 0, (1 << bits) - 1)
+    code = np.zeros(len(pos), dtype=np.int64)
+    for b in range(bits):
+        for axis in range(3):
+            code |= ((q[:, axis] >> b) & 1) << (3 * b + axis)
+    return np.argsort(code, kind="stable")
+
+
+def renumber_mesh(g: GraphStructure, order: np.ndarray) -> GraphStructure:
+    """The same graph with its MESH nodes renumbered: new node k is old node ``order[k]``.  Mesh nodes carry latents only (the network's
+    inputs and outputs live on the grid), so this changes nothing a caller can see except the order in which a receiver's messages are
+    summed; edges are re-sorted by (receiver, sender) in the new numbering and their features travel with them."""
+    order = np.asarray(order, dtype=np.int64)
+    if sorted(order.tolist()) != list(range(g.n_mesh)):
+        raise ValueError("renumber_mesh: `order` must be a permutation of the mesh nodes")
+    new = np.empty(g.n_mesh, dtype=np.int64)
+    new[order] = np.arange(g.n_mesh)
+
+    def resort(edges, feat, send_is_mesh, recv_is_mesh):
+        e = edges.copy()
+        if send_is_mesh:
+            e[:, 0] = new[e[:, 0]]
+        if recv_is_mesh:
+            e[:, 1] = new[e[:, 1]]
+        k = np.lexsort((e[:, 0], e[:, 1])) if recv_is_mesh else np.arange(len(e))    # grid receivers keep their order (3 edges per grid node)
+        return e[k], feat[k]
+
+    me, mef = resort(g.mesh_edges, g.mesh_edge_feat, True, True)
+    g2m, g2mf = resort(g.g2m_edges, g.g2m_edge_feat, False, True)
+    m2g, m2gf = resort(g.m2g_edges, g.m2g_edge_feat, True, False)
+    return GraphStructure(n_grid=g.n_grid, n_mesh=g.n_mesh, mesh_pos=g.mesh_pos[order], grid_pos=g.grid_pos, mesh_edges=me, g2m_edges=g2m, m2g_edges=m2g,
+                          mesh_edge_feat=mef, g2m_edge_feat=g2mf, m2g_edge_feat=m2gf, mesh_node_feat=g.mesh_node_feat[order],
+                          grid_node_feat=g.grid_node_feat, faces=new[g.faces])
+
+
 def latitude_band(n_lat: int, rank: int, world: int) -> tuple[int, int]:
     """Rows [lat0, lat1) of the grid owned by ``rank`` (contiguous bands, sizes differ by at most one row)."""
     return rank * n_lat // world, (rank + 1) * n_lat // world

@@ -239,3 +239,29 @@ def test_edge_mlp_by_distributivity_and_grouped_receiver_sum_cpu():
     node = 16 * (v // 48) + v % 16
     got = torch.zeros(n_recv, L, dtype=torch.float64).index_add_(0, node[node < n_recv], out[node < n_recv])      # what the epilogue sums in registers
     assert (got - want).abs().max().item() < 1e-12
+
+
+def test_mesh_renumbering_is_an_isomorphism_and_spatially_coherent():
+    """skyrim_amd/graphcast/mesh.py: renumber_mesh(g, spatial_order(...)) -- what the engine works on since round 5 -- is the same graph (edge sets
+    with their features map back one to one, edges stay sorted by receiver, the mesh->grid triples keep their grid order), and a sender's
+    index is close to its receiver's (the level-by-level numbering of the multi-mesh puts them hundreds of rows apart)."""
+    from skyrim_amd.graphcast.mesh import build_graph, renumber_mesh, spatial_order
+    g = build_graph(61, 120, 4)
+    order = spatial_order(g.mesh_pos)
+    h = renumber_mesh(g, order)
+    assert sorted(order.tolist()) == list(range(g.n_mesh)) and np.array_equal(h.mesh_pos, g.mesh_pos[order]) and np.array_equal(h.mesh_node_feat, g.mesh_node_feat[order])
+
+    def rows(e, f):
+        return sorted(map(tuple, np.concatenate([e, np.round(f.astype(np.float64) * 1e6).astype(np.int64)], 1).tolist()))
+    me = h.mesh_edges.copy(); me[:, 0] = order[me[:, 0]]; me[:, 1] = order[me[:, 1]]
+    assert rows(me, h.mesh_edge_feat) == rows(g.mesh_edges, g.mesh_edge_feat)
+    g2m = h.g2m_edges.copy(); g2m[:, 1] = order[g2m[:, 1]]
+    assert rows(g2m, h.g2m_edge_feat) == rows(g.g2m_edges, g.g2m_edge_feat)
+    m2g = h.m2g_edges.copy(); m2g[:, 0] = order[m2g[:, 0]]
+    assert np.array_equal(m2g, g.m2g_edges) and np.array_equal(h.m2g_edge_feat, g.m2g_edge_feat)
+    assert (np.diff(h.mesh_edges[:, 1]) >= 0).all() and (np.diff(h.g2m_edges[:, 1]) >= 0).all()
+    assert np.array_equal(np.sort(order[h.faces], axis=1), np.sort(g.faces, axis=1))
+    dist = lambda e: np.median(np.abs(e[:, 0] - e[:, 1]))  # noqa: E731
+    assert dist(h.mesh_edges) * 10 < dist(g.mesh_edges)
+    with pytest.raises(ValueError):
+        renumber_mesh(g, np.zeros(g.n_mesh, dtype=np.int64))

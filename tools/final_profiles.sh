@@ -6,7 +6,7 @@
 set -u
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
-R=${PROFILE_ROUND:-r04}
+R=${PROFILE_ROUND:-r05}
 O=gpurun_out/final
 mkdir -p $O profiles
 MODELS=${*:-pangu sfno graphcast}
@@ -25,7 +25,8 @@ for m in $MODELS; do
 done
 for m in $MODELS; do
   case $m in
-    pangu) python bench.py > $O/${R}_bench_pangu.json 2> $O/bench_pangu.err
+    pangu) python bench.py > $O/${R}_bench_pangu_line.json 2> $O/bench_pangu.err      # stdout: the compact line the driver records
+           cp bench_detail.json $O/${R}_bench_pangu.json                             # the full record of the same run
            python bench.py --graph --no-cpu-baseline --no-parity --no-alt-modes --no-models > $O/${R}_bench_pangu_graph.json 2> $O/bench_pangu_graph.err ;;
     sfno) python bench.py --model sfno > $O/${R}_bench_sfno.json 2> $O/bench_sfno.err ;;
     graphcast) python bench.py --model graphcast --steps 5 > $O/${R}_bench_graphcast.json 2> $O/bench_graphcast.err ;;
