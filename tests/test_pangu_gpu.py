@@ -4,7 +4,7 @@ Tolerances (floating point; stated per the north star): per-channel max|y - ref|
 Modes (skyrim_amd/pangu/engine.py PRECISIONS): hi/lo split GEMMs with fp16 single-term attention --
 "f16x1m" (DEFAULT since round 5: term plan 0x66F -- proj / fc1 / fc2 of every block with ONE fp16 weight plane; the coarse layers 2 / 3 read the
 activation operands' hi plane only, ONE MFMA term, and their QKV is one term; layers 1 / 4 keep two terms; weights rounded with error
-feedback (compensated) on the built-in calibration state; 2.5 .. 2.8e-4 measured over the full-size 24-h rollout -> asserted <= 3.2e-4),
+feedback (compensated) on the built-in calibration state; 2.0 .. 3.05e-4 measured over the full-size 24-h rollout -> asserted <= 3.5e-4),
 "f16x2m" (round 4's default, 0x6F: two terms everywhere; 1.4 .. 1.7e-4 -> <= 3e-4), "f16x2c" (0x66: layers 1 / 4 at three terms),
 "f16x3q" (3 terms; observed ~1e-4 -> asserted <= 3e-4), "f16x3", "bf16x3" (3 terms everywhere; ~8e-5 -> <= 3e-4), and "f16" (single-term
 speed probe, observed ~1.2e-3, does NOT meet the bar -> held to 5e-3).  Other plans: PanguEngine(g, "f16x3q", term_plan=...).
@@ -25,9 +25,11 @@ pytestmark = pytest.mark.gpu
 
 STAGE_TOL = {"f16x1m": 1.5e-3, "f16x2m": 1.5e-3, "f16x2c": 1.5e-3, "bf16x3": 5e-4, "f16x3": 5e-4, "f16x3q": 5e-4, "f16": 4e-3}
 # the default mode's asserted error per step (STEP_TOL[DEFAULT_PRECISION]).  Round 5: the one-term coarse layers, measured at 721x1440 over the 24-h
-# rollout at 2.50 / 2.78 / 2.75 / 2.84e-4 (2.0 .. 3.05e-4 across what the rounding is fitted on: tools/r5_x1m_full.py), toy grid 1.5e-4 -- three
-# times inside the bar; the two-term plan (round 4's default) sits at 1.4 .. 1.7e-4 and is held to 3e-4.
-DEF_TOL = 3.2e-4
+# rollout at 2.50 / 2.78 / 2.75 / 2.84e-4; the figure is deterministic for a given build but moves with anything that nudges the compensated rounding's
+# decisions -- 2.0 .. 3.05e-4 across three choices of what the rounding is fitted on (tools/r5_x1m_full.py), 1.95e-4 (step 1) after a kernel
+# clean-up that changed no arithmetic on paper -- hence 3.5e-4, three times inside the bar; toy grid 1.5 - 1.7e-4.  The two-term plan (round 4's
+# default) sits at 1.4 .. 1.7e-4 and is held to 3e-4.
+DEF_TOL = 3.5e-4
 STEP_TOL = {"f16x1m": DEF_TOL, "f16x2m": 3e-4, "f16x2c": 3e-4, "bf16x3": 3e-4, "f16x3": 3e-4, "f16x3q": 3e-4, "f16": 5e-3}   # 3-term modes: 3x inside the bar
 
 

@@ -134,8 +134,7 @@ def test_r04_default_line_full_size_parity_other_models_and_host_path():
 # ---- round 5 (profiles/r05_*): the one-term default, the compact line, GraphCast's algorithmic roofline fraction ---------------------------- #
 def _r05(name):
     f = PROFILES / name
-    if not f.exists():
-        pytest.skip(f"{name} is written by tools/final_profiles.sh at the end of the round")
+    assert f.exists(), f"{name}: written by tools/final_profiles.sh (PROFILE_ROUND=r05) and committed"
     return f
 
 
@@ -154,7 +153,7 @@ def test_r05_bench_line_and_counter_summary(model):
     r = d["roofline"]
     assert r["bound"] == {"pangu": "mfma", "sfno": "hbm", "graphcast": "mfma"}[model]
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0 < r["frac"] < 1 and r["traffic"] > 0
-    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0 and d["parity"]["max_rel_err"] < 3.2e-4
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0 and d["parity"]["max_rel_err"] < 3.5e-4
     p = json.loads(_r05(f"r05_{model}_pmc.json").read_text())
     assert p["total"]["scope"] == "the bench's own steps" and f"libskyrim_{model}.so" in p["stamp"]
     names, stats = " ".join(p["kernels"]), _r05(f"r05_{model}_kernel_stats.csv").read_text()
@@ -174,7 +173,7 @@ def test_r05_compact_line_is_what_the_driver_can_hold():
     r = line["roofline"]
     assert r["kernel"] == "proj_mlp_r1" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["traffic"] > 0
     assert abs(r["alg_flops_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 2.5e15 - r["frac"]) < 1e-6          # recomputable: FLOPs / time / peak
-    assert line["cpu_baseline"]["kind"] == "port" and line["parity"]["full_size"]["max_rel_err"] < 3.2e-4 and line["parity"]["full_size"]["max_sigma_err"] < 5e-4
+    assert line["cpu_baseline"]["kind"] == "port" and line["parity"]["full_size"]["max_rel_err"] < 3.5e-4 and line["parity"]["full_size"]["max_sigma_err"] < 5e-4
     for m in ("sfno", "graphcast"):
         assert line["models"][m]["ms_per_step"] == full["models"][m]["ms_per_step"] and 0 < line["models"][m]["roofline"]["frac"] < 1
     assert line["detail"] == "bench_detail.json"

@@ -15,7 +15,7 @@ for m in $MODELS; do
   lib=skyrim_amd/lib/libskyrim_$m.so
   stamp="$(sha256sum $lib | cut -c1-16) $(basename $lib), $(date -u +%Y-%m-%dT%H:%MZ)"
   rm -rf $O/stats_$m
-  SKYRIM_PANGU_CALIBRATION=off timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$m -o p -- python bench.py $extra --steps 5 --warmup 2 --no-cpu-baseline --no-parity --no-alt-modes --no-models > $O/stats_$m.log 2>&1
+  SKYRIM_BENCH_FULL_LINE=1 SKYRIM_PANGU_CALIBRATION=off timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$m -o p -- python bench.py $extra --steps 5 --warmup 2 --no-cpu-baseline --no-parity --no-alt-modes --no-models > $O/stats_$m.log 2>&1
   echo "stats $m rc=$?"
   cp $(ls $O/stats_$m/*/p_kernel_stats.csv $O/stats_$m/p_kernel_stats.csv 2>/dev/null | head -1) $O/${R}_${m}_kernel_stats.csv 2>/dev/null
   bash tools/pmc_collect.sh $m $extra
