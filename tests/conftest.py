@@ -71,6 +71,18 @@ def pytest_collection_finish(session):
     mod.stop([k for k, frags in mod.WANTED_BY.items() if not any(f in i for f in frags for i in ids)])
 
 
+@pytest.fixture(autouse=True)
+def _host_threads_beside_the_oracle_jobs():
+    """While full-size oracle jobs compute, the test process keeps to the host threads they leave (tests/_oracle_jobs.py: free_threads)."""
+    mod = sys.modules.get("_oracle_jobs")
+    if mod is not None and mod._shares:
+        import torch
+        n = mod.free_threads()
+        if torch.get_num_threads() != n:
+            torch.set_num_threads(n)
+    yield
+
+
 def pytest_sessionfinish(session, exitstatus):
     mod = sys.modules.get("_oracle_jobs")
     if mod is not None:
