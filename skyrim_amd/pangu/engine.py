@@ -31,7 +31,7 @@ PRECISIONS = {"bf16x3": PREC_BF16X3, "f16": PREC_F16, "f16x3": PREC_F16X3, "f16x
 #             is one term too; the full-resolution layers 1 / 4 keep two terms (A_hi W + A_lo W) and hi/lo QKV weights.  The one-plane
 #             weights are rounded with error feedback against the (rounded) operands' statistics (rounding="compensated", below), which is
 #             what pays for the activation rounding.  16.2 ms per step at 721x1440 against 18.4 for "f16x2m"; per-channel error over the
-#             full-size 24-h rollout 2.5 / 2.8 / 2.7 / 2.8e-4 (f16x2m: 1.4 / 1.7 / 1.6 / 1.7e-4), on states the calibration never saw
+#             full-size 24-h rollout 1.95 / 2.7 / 2.8 / 2.8e-4 (2.0 - 3.05e-4 across builds; f16x2m: 1.2 / 1.6 / 1.5 / 1.6e-4), on states the calibration never saw
 #             (power-law spectrum, other smoothing scales, meridional structure) 1.6 - 2.0e-4, on a gain-1 network over 20 steps <= 4.2e-4
 #             (tests/test_pangu_numerics_gpu.py) -- three times inside the 1e-3 bar everywhere it was looked at.
 #   "f16x2m"  round 3 / 4's default (0x6F): two terms in every block, one-term QKV in layers 2 / 3.
