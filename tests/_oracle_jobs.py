@@ -15,7 +15,6 @@ from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
 _started = {}          # key -> (Popen, path)
-_shares = {}           # key -> host threads given to that job
 _dir = None
 
 
@@ -83,18 +82,8 @@ def start(keys):
             continue
         path = os.path.join(_dir, key + ".pt")
         log = open(os.path.join(_dir, key + ".log"), "w")
-        _shares[key] = share[key]
         env = dict(os.environ, OMP_NUM_THREADS=str(share[key]), MKL_NUM_THREADS=str(share[key]), HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
         _started[key] = (subprocess.Popen([sys.executable, str(Path(__file__).resolve()), key, path], cwd=str(ROOT), env=env, stdout=log, stderr=log), path)
-
-
-def free_threads() -> int:
-    """Host threads the test process itself should use right now: what the running oracle jobs leave (at least 8), all of them once the jobs
-    are done.  The small-grid oracles the tests call in-process spin on every core by default; beside three 128-thread-class jobs that
-    oversubscription made a 20 s rollout test take 200 s (round 5)."""
-    cores = os.cpu_count() or 8
-    busy = sum(_shares.get(k, 0) for k, (proc, _) in _started.items() if proc.poll() is None)
-    return max(8, cores - busy)
 
 
 def _failed(key, rc, path):

@@ -27,30 +27,23 @@ def pytest_configure(config):
             _oracle_jobs.start(list(_oracle_jobs.WANTED_BY))
 
 
-# Collection order of the GPU suite (the driver runs `pytest -x`: whatever fails first hides the rest, so the parity evidence goes first, and
-# the GPU keeps working while the host computes the full-size oracle results -- 4-5 minutes for Pangu's 24-h rollout):
+# Collection order of the GPU suite (the driver runs `pytest -x`: whatever fails first hides the rest, so the parity evidence goes first):
 #   0  small-grid oracle parity of the three default modes (the native library test first)
-#   1  Pangu's full-size step against the oracle (its oracle step is ready ~1.5 min into the run)
-#   2  every other kernel / numerics comparison on small grids (mode matrix, other geometries, conventions, rollouts, building blocks)
-#   3  the remaining full-size comparisons (SFNO, GraphCast, Pangu's 24-h rollout and term plans: their oracle results are ready by now)
-#   4  the reference-shaped API, file I/O, weight ingestion, CLI and multi-process tests
+#   1  the full-size comparisons with the oracles (BASELINE.json's sizes; each waits for its host job -- SFNO's is ready first)
+#   2  everything else, in file order
 _TIER0 = ("test_pangu_gpu.py::test_native_library_is_the_path_that_runs[{d}]", "test_pangu_gpu.py::test_full_step_per_channel[{d}]",
           "test_pangu_gpu.py::test_step_matches_golden_fixture[{d}]", "test_pangu_gpu.py::test_earth_specific_block[{d}-",
           "test_sfno_gpu.py::test_step_vs_oracle_per_channel[", "test_sfno_gpu.py::test_step_matches_golden_fixture",
           "test_graphcast_gpu.py::test_step_vs_oracle[", "test_graphcast_gpu.py::test_matches_golden_fixture")
-_TIER1 = ("test_pangu_gpu.py::test_full_size_step_vs_oracle",)
-_TIER3 = ("test_sfno_gpu.py::test_full_size", "test_graphcast_gpu.py::test_full_size", "test_pangu_gpu.py::test_full_size_24h_rollout",
-          "test_pangu_gpu.py::test_full_size_term_plans", "test_pangu_gpu.py::test_full_size")
-_TIER4 = ("test_ingest_gpu.py::", "test_rccl_gpu.py::", "test_pinned_reference.py::", "reference_api", "two_process", "through_reference_api",
-          "keeps_the_state_in_hbm", "forecast_interleaves", "member_parallel", "skyrim_facade", "custom_op_boundary", "errors_are_loud",
-          "step_before_prepare", "profile_hooks", "time_loop_calibrates", "captured_hip_graph")
+_TIER1 = ("test_pangu_gpu.py::test_full_size_step_vs_oracle", "test_sfno_gpu.py::test_full_size", "test_graphcast_gpu.py::test_full_size",
+          "test_pangu_gpu.py::test_full_size_24h_rollout", "test_pangu_gpu.py::test_full_size_term_plans", "test_pangu_gpu.py::test_full_size")
 
 
 def _tier(nodeid, default_mode):
-    for t, frags in ((0, _TIER0), (1, _TIER1), (3, _TIER3), (4, _TIER4)):
+    for t, frags in enumerate((_TIER0, _TIER1)):
         for rank, f in enumerate(frags):
             if f.format(d=default_mode) in nodeid:
-                return t, rank if t in (0, 1, 3) else 0
+                return t, rank
     return 2, 0
 
 
@@ -69,18 +62,6 @@ def pytest_collection_finish(session):
         return
     ids = [item.nodeid for item in session.items]
     mod.stop([k for k, frags in mod.WANTED_BY.items() if not any(f in i for f in frags for i in ids)])
-
-
-@pytest.fixture(autouse=True)
-def _host_threads_beside_the_oracle_jobs():
-    """While full-size oracle jobs compute, the test process keeps to the host threads they leave (tests/_oracle_jobs.py: free_threads)."""
-    mod = sys.modules.get("_oracle_jobs")
-    if mod is not None and mod._shares:
-        import torch
-        n = mod.free_threads()
-        if torch.get_num_threads() != n:
-            torch.set_num_threads(n)
-    yield
 
 
 def pytest_sessionfinish(session, exitstatus):

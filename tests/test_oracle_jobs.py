@@ -45,10 +45,9 @@ def test_every_job_is_wanted_by_a_collected_gpu_test():
 
 
 def test_parity_evidence_is_collected_first_and_the_longest_job_starts_first():
-    """conftest.pytest_collection_modifyitems: small-grid oracle parity of the default modes, Pangu's full-size step, the other small-grid
-    kernel / numerics comparisons (the GPU works while the host computes the remaining oracle results), the other full-size comparisons,
-    and only then the API / file / multi-process tests -- under `pytest -x` a failing host-API test must not hide the parity evidence.
-    The job list starts the longest (Pangu's 4-step rollout) first."""
+    """conftest.pytest_collection_modifyitems: small-grid oracle parity of the default modes, then the full-size comparisons (Pangu's single step
+    first: its oracle step is ready a minute into the run), then everything else in its collected order -- under `pytest -x` a failing
+    host-API test must not hide the headline comparisons.  The job list starts the longest (Pangu's 4-step rollout) first."""
     import importlib.util
     from skyrim_amd.pangu.engine import DEFAULT_PRECISION as D
     spec = importlib.util.spec_from_file_location("_conftest_under_test", Path(__file__).resolve().parent / "conftest.py")
@@ -62,14 +61,7 @@ def test_parity_evidence_is_collected_first_and_the_longest_job_starts_first():
     items = [type("Item", (), {"nodeid": i})() for i in ids]
     conf.pytest_collection_modifyitems(None, items)
     got = [i.nodeid for i in items]
-    ids += ["tests/test_ingest_gpu.py::test_x", "tests/test_sfno_gpu.py::test_reference_api_forecast_on_the_sfno_engine"]
-    items = [type("Item", (), {"nodeid": i})() for i in ids]
-    conf.pytest_collection_modifyitems(None, items)
-    got = [i.nodeid for i in items]
-    #       tier 0: native, default toy step, sfno tiny | 1: pangu full step | 2: the rest of the small-grid comparisons, in collected order
-    assert got[:9] == [ids[10], ids[5], ids[8], ids[4], ids[0], ids[2], ids[6], ids[9], ids[7]][:4] + [ids[0], ids[2], ids[6], ids[9]] + [ids[7]]
-    #       tier 3: sfno full, graphcast full, pangu rollout | 4: ingest, reference API
-    assert got[9:] == [ids[1], ids[3], ids[11], ids[12]]
+    assert got == [ids[10], ids[5], ids[8], ids[4], ids[7], ids[1], ids[3], ids[0], ids[2], ids[6], ids[9]]
     only_cpu = [type("Item", (), {"nodeid": i})() for i in ("tests/test_host_api.py::b", "tests/test_abi.py::a")]
     conf.pytest_collection_modifyitems(None, only_cpu)
     assert [i.nodeid for i in only_cpu] == ["tests/test_host_api.py::b", "tests/test_abi.py::a"]          # a CPU run keeps its order
