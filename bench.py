@@ -99,16 +99,35 @@ def lib_sha16(model: str) -> str | None:
         return None
 
 
+def src_sha16() -> str:
+    """First 16 hex digits of sha256 over the kernel sources (skyrim_amd/csrc/*, include/*.h, names + contents).  hipcc does not reproduce a
+    shared object bit for bit (a from-scratch rebuild of identical sources hashes differently), so a counter summary is also accepted when
+    it names THESE sources: same kernels, another link."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted((ROOT / "skyrim_amd" / "csrc").glob("*")) + sorted((ROOT / "include").glob("*.h"))
+    for f in files:
+        if f.is_file():
+            h.update(f.name.encode())
+            h.update(f.read_bytes())
+    return h.hexdigest()[:16]
+
+
+def _stamp_is_current(stamp: str, model: str) -> bool:
+    have = lib_sha16(model)
+    return bool(have and stamp.startswith(have)) or f"src {src_sha16()}" in stamp
+
+
 def pmc_summary(model: str):
     """profiles/<round>_<model>_pmc.json (tools/pmc_collect.sh + tools/pmc_summary.py: rocprofv3 --pmc passes, FETCH_SIZE doubled per
     MI355X_MICROARCH.md 'HBM'), or None.  A COMMITTED profile, not a measurement of this run: it is only used when its stamp names the
-    library this process loads -- counters of another binary are dropped (``pmc_stale`` says so), never paired with fresh timings."""
+    library this process loads (or the kernel sources it was built from: ``src_sha16``) -- counters of another build are dropped (``pmc_stale`` says so), never paired with fresh timings."""
     f = ROOT / "profiles" / f"{PROFILE_ROUND}_{model}_pmc.json"
     try:
         d = json.loads(f.read_text())
     except Exception:
         return None
-    if not str(d.get("stamp", "")).startswith(lib_sha16(model) or "?"):
+    if not _stamp_is_current(str(d.get("stamp", "")), model):
         return None
     return d
 
@@ -121,7 +140,7 @@ def pmc_stale(model: str):
     except Exception:
         return None
     have = lib_sha16(model)
-    if have and stamp.startswith(have):
+    if _stamp_is_current(stamp, model):
         return None
     return {"stale": True, "profiled_at": stamp, "library_sha16": have, "note": "counter summary dropped: it describes another build of the library"}
 

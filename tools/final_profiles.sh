@@ -13,7 +13,7 @@ MODELS=${*:-pangu sfno graphcast}
 for m in $MODELS; do
   extra=""; [ $m != pangu ] && extra="--model $m"
   lib=skyrim_amd/lib/libskyrim_$m.so
-  stamp="$(sha256sum $lib | cut -c1-16) $(basename $lib), $(date -u +%Y-%m-%dT%H:%MZ)"
+  stamp="$(sha256sum $lib | cut -c1-16) $(basename $lib), $(date -u +%Y-%m-%dT%H:%MZ), src $(python -c 'import bench; print(bench.src_sha16())')"
   rm -rf $O/stats_$m
   SKYRIM_BENCH_FULL_LINE=1 SKYRIM_PANGU_CALIBRATION=off timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$m -o p -- python bench.py $extra --steps 5 --warmup 2 --no-cpu-baseline --no-parity --no-alt-modes --no-models > $O/stats_$m.log 2>&1
   echo "stats $m rc=$?"
