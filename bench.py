@@ -114,8 +114,20 @@ def src_sha16() -> str:
 
 
 def _stamp_is_current(stamp: str, model: str) -> bool:
+    """A counter summary belongs to this run when it names the library that is loaded -- or the kernel sources, and then only if the loaded
+    library is provably a build OF those sources: the default in-tree path (no SKYRIM_<MODEL>_LIB override) and not older than any source
+    file.  Otherwise counters of one binary could be paired with timings of another (a stale or variant build)."""
     have = lib_sha16(model)
-    return bool(have and stamp.startswith(have)) or f"src {src_sha16()}" in stamp
+    if have and stamp.startswith(have):
+        return True
+    if f"src {src_sha16()}" not in stamp or os.environ.get(f"SKYRIM_{model.upper()}_LIB"):
+        return False
+    lib = ROOT / "skyrim_amd" / "lib" / f"libskyrim_{model}.so"
+    srcs = [f for f in list((ROOT / "skyrim_amd" / "csrc").glob("*")) + list((ROOT / "include").glob("*.h")) if f.is_file()]
+    try:
+        return lib.stat().st_mtime >= max(f.stat().st_mtime for f in srcs)
+    except OSError:
+        return False
 
 
 def pmc_summary(model: str):
@@ -179,7 +191,7 @@ def quick_mode(precision, geom, params, x_host, dev, steps=3, mlp="fused", round
     weights' last bits and biases, never the kernels or their time; 13 s per engine at full size with compensated rounding) is off."""
     from skyrim_amd.pangu.engine import PanguEngine
     eng = PanguEngine(geom, precision, dev, mlp=mlp)
-    eng.load_params(params, calibration="off", rounding=rounding)
+    eng.load_params(params, calibration="off", rounding=rounding, guard=False)
     x = x_host.to(dev)
     eng.step(x, x)
     torch.cuda.synchronize()
@@ -199,7 +211,7 @@ def api_rollout_rate(precision, geom, params, x_host, dev, n=6):
     from skyrim_amd.core.models.utils import run_basic_inference
     from skyrim_amd.labeled import DataArray
     from skyrim_amd.pangu.timeloop import PanguTimeLoop
-    loop = PanguTimeLoop(params, geom, precision, dev, calibration="off")      # a rate, not a forecast: no load-time calibration
+    loop = PanguTimeLoop(params, geom, precision, dev, calibration="off", guard=False)      # a rate, not a forecast: no load-time calibration / guard
     t0 = datetime.datetime(2024, 1, 1)
     x = DataArray(x_host.numpy()[None], dims=["time", "channel", "lat", "lon"],
                   coords=dict(time=[t0], channel=loop.in_channel_names, lat=loop.grid.lat, lon=loop.grid.lon))
@@ -223,7 +235,7 @@ def members_on_streams(precision, geom, params, x_host, dev, n_members=2, steps=
     engs, xs = [], []
     for m in range(n_members):
         e = PanguEngine(geom, precision, dev)
-        e.load_params(params, calibration="off")           # throughput only
+        e.load_params(params, calibration="off", guard=False)           # throughput only
         engs.append(e)
         xs.append(x_host.to(dev) + 1e-3 * m)
     streams = [torch.cuda.Stream(dev) for _ in range(n_members)]
@@ -260,15 +272,17 @@ def predict_inclusive(precision, geom, params, dev, n_steps=8):
     import shutil
     import tempfile
     from skyrim_amd.core.models.pangu import PanguModel
-    keep = os.environ.get("SKYRIM_PANGU_CALIBRATION")
+    keep = {k: os.environ.get(k) for k in ("SKYRIM_PANGU_CALIBRATION", "SKYRIM_PANGU_GUARD")}
     os.environ["SKYRIM_PANGU_CALIBRATION"] = "off"         # a cost figure, not a forecast: skip the 13 s of load-time calibration
+    os.environ["SKYRIM_PANGU_GUARD"] = "off"               # ... and the guard that would judge the uncalibrated plan
     try:
         m = PanguModel(ic_source="synthetic", geom=geom, params=params, precision=precision, device=dev)
     finally:
-        if keep is None:
-            del os.environ["SKYRIM_PANGU_CALIBRATION"]
-        else:
-            os.environ["SKYRIM_PANGU_CALIBRATION"] = keep
+        for k, v in keep.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
     t0 = datetime.datetime(2024, 1, 1)
     base = "/dev/shm" if os.path.isdir("/dev/shm") else None
     out = {}
@@ -726,6 +740,10 @@ def main():
                 "members": n_members, "finite": finite,
                 "calibration": eng.calibrated_on,       # the term plan's biases: "synthetic" = fitted on the engine's built-in state, not on this run's
                 "rounding": eng.rounding,               # of the one-plane weights: "nearest" | "compensated" (pangu/calibration.py)
+                # the MFMA term plan the timed steps ran with, and what the load-time guard measured for it (sigma-unit error of one step
+                # against the three-term engine on the calibration state; PanguEngine._guard)
+                "term_plan": f"{eng.term_plan_in_effect:#05x}",
+                "guard": None if not eng.guard_report else [[f"{pl:#05x}", float(f"{e:.3e}")] for pl, e in eng.guard_report],
             },
             "roofline": {
                 "bound": "mfma", "kernel": dom["name"], "achieved": achieved / 1e12, "peak": PEAK_MFMA_BF16 / 1e12,
@@ -809,7 +827,7 @@ def compact_line(out: dict) -> dict:
     keep = lambda d, keys: {k: d[k] for k in keys if d is not None and k in d}  # noqa: E731
     line = keep(out, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"))
     cfg = out.get("config", {})
-    line["config"] = {"workload": cfg.get("workload", "")[:160], "precision": cfg.get("precision", "")[:120], **keep(cfg, ("parallelism", "members", "finite", "calibration", "rounding"))}
+    line["config"] = {"workload": cfg.get("workload", "")[:160], "precision": cfg.get("precision", "")[:120], **keep(cfg, ("parallelism", "members", "finite", "calibration", "rounding", "term_plan", "guard"))}
     line["config"]["parallelism"] = str(line["config"].get("parallelism", ""))[:120]
     roof = out.get("roofline", {})
     line["roofline"] = keep(roof, ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "alg_bytes_per_launch", "alg_flops_per_launch", "avg_launch_ms",

@@ -18,7 +18,7 @@
 extern "C" {
 #endif
 
-#define SKGC_ABI_VERSION 4
+#define SKGC_ABI_VERSION 5
 #define SKGC_E_ARG (-1)
 #define SKGC_E_HIP (-2)
 
@@ -130,7 +130,12 @@ int skgc_segment_fixup(float* agg, const float* heads, const int* nodes, const i
 
 /* Node update on fp32 rows, latent 512, three MFMA terms (fp32 operands split into fp16 hi/lo on the fly):
  *     out[r] = (res ? res[r] : 0) + LayerNorm( swish( concat_s src[s][r] W1^T + b1 ) W2^T + b2 ) * gamma + beta,   r < rows
- * src[s]: fp32 rows of 512 columns (n_src = 1 or 2: W1 is [512][512 n_src]); out may alias res or a source. */
+ * src[s]: fp32 rows of 512 columns (n_src = 1 or 2: W1 is [512][512 n_src]); out may alias res or a source.
+ * w1f (ABI 5: the layout changed from chunk order to K-OUTER with round 5's kernel, so a library of either generation refuses the other's
+ * blobs through the version): per source s, 1 KiB fragments in the order [ks = 0..15][n = 0..31][plane hi, lo] -- fragment (ks, n) holds,
+ * lane-linear (lane l, element e), W1[32 (n >> 1) + hidden unit of (n & 1, l & 15)][512 s + 32 ks + 8 (l >> 4) + e]: ONE k-step of all 512
+ * hidden units is one 64 KiB LDS stage (skyrim_amd/graphcast/fused.py: prep_w1_fragments_kouter is the reference packer).
+ * w2f: [j = 0..15][c = 0..31][plane] fragments of the second Linear, perm8 rows (fused.py: prep_w2_fragments). */
 typedef struct skgc_node_desc {
     const float* src[2];
     long long ld[2];

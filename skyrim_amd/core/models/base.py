@@ -48,7 +48,22 @@ class GlobalModel:
                                geom=getattr(self.model, "geom", None), state_fn=getattr(self.model, "synthetic_state", None))
 
     def release_model(self):
-        raise NotImplementedError
+        """Give the model's device memory back, deterministically (the reference's TODO, base.py:50-55; what its ensemble does between
+        members, ensemble.py:39-48): the TimeLoop destroys its engine contexts (``sk*_destroy``) and drops every arena / prepared tensor,
+        then the caching allocator is emptied.  The wrapper is unusable afterwards (``build_model()`` again for a new one)."""
+        m, self.model = getattr(self, "model", None), None
+        if getattr(self, "stepper", None) is not None:
+            self.stepper = None
+        if m is not None and hasattr(m, "__dict__"):
+            m._resident_state = None                            # the device copy of the last delivered states (utils.ResidentState)
+        if m is not None and hasattr(m, "release"):
+            m.release()
+        del m
+        import gc
+        import torch
+        gc.collect()
+        if torch.cuda.is_available():
+            torch.cuda.empty_cache()
 
     @property
     def time_step(self):

@@ -119,6 +119,14 @@ def _drain(model, loop, n: int, time):
     return DataArray(stacked, dims=["time", "channel", "lat", "lon"], coords=coords, ready=ready)
 
 
+def estimate_pressure_hpa(elevation_m):
+    """Standard-atmosphere pressure in hPa at ``elevation_m`` metres (reference utils.py:52-67): the barometric formula of the troposphere,
+    p = p0 (1 - L h / T0)^(g M / (R L)) with the ISA constants."""
+    p0, lapse, t0 = 101325.0, 0.0065, 288.15          # Pa, K / m, K
+    g, molar, gas = 9.80665, 0.0289644, 8.31447       # m / s^2, kg / mol, J / (mol K)
+    return p0 * (1.0 - lapse * elevation_m / t0) ** (g * molar / (gas * lapse)) / 100.0
+
+
 def perturb_initial_conditions(initial_conditions: DataArray, channel, lat, lon, value):
     """Set one (channel, nearest lat/lon) cell (reference utils.py:70-92); lon < 0 wraps by +360."""
     if lon < 0:

@@ -59,6 +59,7 @@ class NodeDesc(ctypes.Structure):
 
 
 _lib = None
+ABI_VERSION = 5            # include/skyrim_graphcast.h SKGC_ABI_VERSION: 5 = K-outer w1f of skgc_node_mlp
 
 
 def load_library():
@@ -81,6 +82,10 @@ def load_library():
     lib.skgc_node_mlp.argtypes = [ctypes.POINTER(NodeDesc), ctypes.c_void_p]
     for name in EXPORTS:
         getattr(lib, name).restype = ctypes.c_int
+    # the fragment orders this module packs (fused.py) belong to ONE generation of kernels: a stale build, or a SKYRIM_GRAPHCAST_LIB variant
+    # from other sources, would read them as something else and produce silently wrong node updates
+    if lib.skgc_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"{path}: skgc ABI {lib.skgc_abi_version()}, this package packs for ABI {ABI_VERSION} (include/skyrim_graphcast.h); rebuild the library")
     _lib = lib
     return lib
 
@@ -144,6 +149,16 @@ class GraphcastEngine:
         if self.w1_planes not in (1, 2):
             raise ValueError("SKGC_W1_PLANES is 1 or 2")
         self.state_shape = (self.cfg.n_vars, self.lat1 - self.lat0, self.cfg.n_lon)
+
+    def release(self):
+        """Drop the packed graph, every prepared weight and all latent / work buffers (~47 GB at 721x1440; GlobalModel.release_model).  The C ABI
+        holds no state of its own: all device memory is torch tensors owned here.  The engine is unusable afterwards."""
+        keep = ("cfg", "rank", "world", "reduce_fn", "gather_fn", "lib", "sf", "device", "state_shape")
+        kept = {k: v for k, v in vars(self).items() if k in keep}
+        self.__dict__.clear()
+        self.__dict__.update(kept)
+        self.prepared = False
+        self._events = []
 
     def _stream(self):
         return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
@@ -273,8 +288,11 @@ class GraphcastEngine:
             send = np.where(ok, edges[re, 0], -1)
             d = dict(rows=len(row_edge), n_edges=len(edges), row_edge=row_edge, recv=i32(recv), send=i32(send))
             nodes, first, tiles = _fz.continuation_list(recv)
+            # the heads buffer ALWAYS (2 KB per 128-row tile): continuation_list has just proven on the host whether a run crosses a tile
+            # boundary, and an op called without the buffer has to find that out on the device -- one blocking .item() per edge update,
+            # 17 per step on graphs without continuations (small meshes), which also made the step uncapturable as a HIP graph
+            d["heads"] = torch.zeros(len(row_edge) // _fz.TILE, L, dtype=torch.float32, device=dev)
             if len(nodes):
-                d["heads"] = torch.zeros(len(row_edge) // _fz.TILE, L, dtype=torch.float32, device=dev)
                 d["fix"] = (i32(nodes), i32(first), i32(tiles))
             return d
 

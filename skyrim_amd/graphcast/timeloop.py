@@ -133,6 +133,12 @@ class GraphcastTimeLoop:
         """Initial-condition hook of the synthetic DataSource (no network for GFS / ERA5 here)."""
         return synthetic_states(self.cfg, seed)[1]
 
+    def release(self):
+        """Drop the engine's graph, weights and latents and the cached forcing planes (GlobalModel.release_model)."""
+        self.engine.release()
+        self.stepper = None
+        self._sin_lat = self._cos_lat = self._lon = None
+
     def forcing(self, time: datetime.datetime) -> torch.Tensor:
         """(15, n_lat, n_lon) forcings of the step from ``time`` -- the same closed forms as ``spec.forcings``, on the device."""
         hours = (time - _EPOCH).total_seconds() / 3600.0

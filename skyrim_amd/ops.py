@@ -259,8 +259,9 @@ def _gc_edge_update(e_in, e_out, term, term_off, ld, idx, recv, w1f, w2f, b2, ga
     if heads is not None:
         if heads.numel() < rows // 128 * 512:
             raise ValueError("gc_edge_update: heads holds one 512-wide row per 128-row tile")
-    elif rows > 128 and bool((recv[127:rows - 1:128] == recv[128:rows:128]).any().item()):
-        # (one device sync, on this path only: the engine's packed orders always come with their heads buffer)
+    elif rows > 128 and bool(((recv[127:rows - 1:128] == recv[128:rows:128]) & (recv[128:rows:128] >= 0)).any().item()):
+        # ad-hoc callers only (one blocking device read): GraphcastEngine.pack() proves the same thing on the host (fused.continuation_list,
+        # padding rows -1 excluded there as here) and always hands over a heads buffer, so the engine's step never comes this way
         raise ValueError("gc_edge_update: a receiver's run continues across a tile boundary -- pass a heads buffer (and run gc_segment_fixup)")
     if agg.numel() < 512 or any(t.numel() - off < l for t, off, l in zip(term, term_off, ld)):
         raise ValueError("gc_edge_update: agg / term buffers are smaller than one row")

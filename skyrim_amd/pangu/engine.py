@@ -46,6 +46,12 @@ DEFAULT_PRECISION = "f16x1m"
 # are the same.  With 1 % of the weight rows scaled x5 the two-term plan holds 9e-5 (nearest: 2.8e-4); x30 on every Linear class at once
 # breaks EVERY mode, three-term and bf16x3 included, at ~1e-2 (tools/pangu_outlier_scan.py: the attention's one-plane fp16 operands).
 DEFAULT_ROUNDING = "compensated"
+# Load-time precision guard (PanguEngine._guard): a term plan is never applied blind to weights it was not tested on.  After the plan is prepared,
+# ONE step of it and ONE step of the three-term engine on the calibration state are compared, per channel, in units of the channel's sigma
+# (norm.std); at or above GUARD_TOL -- half the 1e-3 bar -- the engine falls back  plan -> plan without one-term block GEMMs -> three terms
+# everywhere (0x66F -> 0x6F -> 0x00), re-fitting each time, and says so.  SKYRIM_PANGU_GUARD=off skips it (timing-only sections of bench.py).
+# When even three terms everywhere disagree with the tiled three-term reference by GUARD_TOL the weights themselves are the problem: FloatingPointError.
+GUARD_TOL = float(os.environ.get("SKYRIM_PANGU_GUARD_TOL", "5e-4"))
 
 _LIB_PATH = Path(__file__).resolve().parent.parent / "lib" / "libskyrim_pangu.so"
 
@@ -194,27 +200,48 @@ class PanguEngine:
         self.device = torch.device(device)
         if mlp != "fused" and precision in TERM_PLANS and term_plan is None:
             term_plan = 0                                   # the tiled-GEMM path has no two-term kernels: a plan name + split = f16x3q + split
-        self.cfg = make_config(self.geom, precision, roll_sign, mask_value, mlp, term_plan, surface, qkv_order, bias_index)
         self._conventions = dict(roll_sign=roll_sign, mask_value=mask_value, surface=surface, qkv_order=qkv_order, bias_index=bias_index)
         self.mlp = mlp
-        self.term_plan = self.cfg.term_plan
-        self.sizes = query_sizes(self.geom, precision, self.cfg)
-        with torch.cuda.device(self.device):
-            self._prepared = torch.empty(self.sizes.prepared_bytes, dtype=torch.uint8, device=self.device)
-            self._workspace = torch.empty(self.sizes.workspace_bytes, dtype=torch.uint8, device=self.device)
-        self._ctx = ctypes.c_void_p()
-        _check(self.lib.skpangu_create(ctypes.byref(self.cfg), self._prepared.data_ptr(), self.sizes.prepared_bytes,
-                                       self._workspace.data_ptr(), self.sizes.workspace_bytes, ctypes.byref(self._ctx)),
-               "skpangu_create")
+        self._ctx = None
+        self._create(term_plan)
+        self.term_plan_requested = self.term_plan
+        self.guard_report = None                            # [(plan, sigma-unit error against the three-term engine), ...] of the last load / calibrate
         self.state_shape = (self.geom.n_channels, self.geom.n_lat, self.geom.n_lon)
         # compensated rounding pools the operand statistics of the calibration state and of this many of its successive 6-h forecasts
         self.calibration_forecasts = int(os.environ.get("SKYRIM_PANGU_CALIBRATION_FORECASTS", "1"))
 
-    def __del__(self):
+    def _create(self, term_plan: "int | None"):
+        """(Re)build the C context and its two arenas for ``term_plan`` (None: the precision name's own).  The guard's fall-back path."""
+        self.release()
+        c = self._conventions
+        self.cfg = make_config(self.geom, self.precision, c["roll_sign"], c["mask_value"], self.mlp, term_plan, c["surface"], c["qkv_order"], c["bias_index"])
+        self.term_plan = self.cfg.term_plan
+        self.sizes = query_sizes(self.geom, self.precision, self.cfg)
+        with torch.cuda.device(self.device):
+            self._prepared = torch.empty(self.sizes.prepared_bytes, dtype=torch.uint8, device=self.device)
+            self._workspace = torch.empty(self.sizes.workspace_bytes, dtype=torch.uint8, device=self.device)
+        ctx = ctypes.c_void_p()
+        _check(self.lib.skpangu_create(ctypes.byref(self.cfg), self._prepared.data_ptr(), self.sizes.prepared_bytes,
+                                       self._workspace.data_ptr(), self.sizes.workspace_bytes, ctypes.byref(ctx)),
+               "skpangu_create")
+        self._ctx = ctx
+
+    @property
+    def term_plan_in_effect(self) -> int:
+        """The plan the engine runs with (the requested one unless the load-time guard fell back)."""
+        return self.term_plan
+
+    def release(self):
+        """Destroy the C context and drop the arenas (``skpangu_destroy``; GlobalModel.release_model).  The engine is unusable afterwards."""
         ctx = getattr(self, "_ctx", None)
         if ctx:
             self.lib.skpangu_destroy(ctx)
-            self._ctx = None
+        self._ctx = None
+        self._prepared = self._workspace = self._master = None
+
+    def __del__(self):
+        if getattr(self, "lib", None) is not None:
+            self.release()
 
     # ------------------------------------------------------------------ #
     def _stream(self):
@@ -227,7 +254,8 @@ class PanguEngine:
             raise ValueError(f"expected shape {tuple(shape)}, got {tuple(t.shape)}")
         return ctypes.c_void_p(t.data_ptr())
 
-    def load_params(self, params: dict[str, torch.Tensor], calibration: "torch.Tensor | str | None" = "default", rounding: str = "default"):
+    def load_params(self, params: dict[str, torch.Tensor], calibration: "torch.Tensor | str | None" = "default", rounding: str = "default",
+                    guard: "bool | None" = None):
         """Pack fp32 master parameters into the library's blob layout, upload and prepare.
 
         Engines with a term plan only (one-plane Linears; both are load-time choices that cost nothing per step):
@@ -238,7 +266,10 @@ class PanguEngine:
         per-step totals; it changes weights' last bits and biases, not timings).
         ``rounding``: how their weights reach the fp16 grid -- "nearest" (the C ABI's own; the bias fold is ``skpangu_calibrate``) or
         "compensated" (pangu/calibration.py: column-by-column error feedback against the operand covariance of the calibration state,
-        computed here and handed to the library as the master weights); "default": SKYRIM_PANGU_ROUNDING or DEFAULT_ROUNDING."""
+        computed here and handed to the library as the master weights); "default": SKYRIM_PANGU_ROUNDING or DEFAULT_ROUNDING.
+        ``guard``: the load-time precision guard (``_guard``: one step of the plan against one of the three-term engine, fall back
+        0x66F -> 0x6F -> 0x00 until inside GUARD_TOL); None: on unless SKYRIM_PANGU_GUARD=off; False: measurements of a plan as given."""
+        self._guard_on = guard
         if isinstance(calibration, str) and calibration == "default":
             calibration = os.environ.get("SKYRIM_PANGU_CALIBRATION", "synthetic")
             if calibration == "first":                          # the time loop's mode: it calls calibrate() itself
@@ -252,9 +283,16 @@ class PanguEngine:
         off = calibration is None or (isinstance(calibration, str) and calibration == "off")
         self._params, self.rounding = params, rounding          # calibrate() starts over from these
         self.calibrated_on = None
+        self._guard_pair = None
+        if self.term_plan != self.term_plan_requested:          # an earlier load fell back: every load starts from the plan asked for
+            self._create(self.term_plan_requested)
         self._prepare(params)
+        fit = None
         if self.term_plan and not off:
-            self.calibrate(calibration_state(self.geom, params["norm.mean"], params["norm.std"]) if isinstance(calibration, str) else calibration)
+            fit = calibration_state(self.geom, params["norm.mean"], params["norm.std"]) if isinstance(calibration, str) else calibration
+            self._fit(fit)
+        self._guard(fit)
+        if fit is not None:
             self.calibrated_on = "synthetic" if isinstance(calibration, str) else "state"
 
     def _prepare(self, params: dict[str, torch.Tensor]):
@@ -271,17 +309,27 @@ class PanguEngine:
         self._master = master if self.term_plan else None       # skpangu_calibrate re-reads weights and biases from it
 
     def calibrate(self, state: "torch.Tensor | None"):
-        """Fit the one-plane Linears of the term plan to ``state`` (None: back to nearest rounding and the master biases); a no-op for
-        engines without a plan.  Calling again starts over from the parameters handed to ``load_params``.
-        rounding "nearest": fold the mean of the dropped term, A x (W - fp16(W)), into each bias -- one step on ``state`` through the
+        """Fit the one-plane Linears of the term plan to ``state`` (None: back to nearest rounding and the master biases), then run the
+        load-time guard on it; a no-op for engines without a plan.  Calling again starts over from the parameters handed to ``load_params``."""
+        if not self.term_plan_requested:
+            return
+        if getattr(self, "_params", None) is None:
+            raise RuntimeError("load_params() first")
+        if self.term_plan != self.term_plan_requested:          # an earlier guard fell back: every fit starts from the plan asked for
+            self._create(self.term_plan_requested)
+            self._prepare(self._params)
+        self._guard_pair = None
+        self._fit(state)
+        self._guard(state)
+
+    def _fit(self, state: "torch.Tensor | None"):
+        """rounding "nearest": fold the mean of the dropped term, A x (W - fp16(W)), into each bias -- one step on ``state`` through the
         three-term kernels, column means of every short Linear's operand (include/skyrim_pangu.h: skpangu_calibrate).
         rounding "compensated": the operands of one three-term step on ``state`` and of one on its forecast (a second, tiled-form
         engine that lives for the duration of this call), their pooled second moments, error-compensated fp16 weights + folded biases
         (pangu/calibration.py), prepared again."""
         if not self.term_plan:
             return
-        if getattr(self, "_params", None) is None:
-            raise RuntimeError("load_params() first")
         if self.rounding == "compensated":
             params = self._params
             if state is not None:
@@ -293,6 +341,9 @@ class PanguEngine:
                     for _ in range(self.calibration_forecasts):  # the state and its own forecast(s): a rollout's later inputs are model outputs
                         states.append(tap.step(states[-1]))
                     params = calibrated_params(self._params, self.term_plan, engine_taps(tap, self._params, states))
+                if len(states) > 1:
+                    self._guard_pair = (states[0], states[1])   # the guard's reference: the three-term forecast of the calibration state
+                tap.release()
                 del tap
             self._prepare(params)                               # fp16-grid weights: the library's own rounding leaves them as they are
             torch.cuda.empty_cache()
@@ -303,6 +354,67 @@ class PanguEngine:
                                                   self._stream()), "skpangu_calibrate")
                 torch.cuda.current_stream(self.device).synchronize()
         self.calibrated_on = None if state is None else "state"
+
+    def _guard(self, state: "torch.Tensor | None"):
+        """The load-time precision guard (GUARD_TOL above).  ``state``: what the plan was fitted on (None: the built-in calibration state).
+        Leaves ``guard_report`` = [(plan, error), ...] in the order tried and the engine on the first plan below the tolerance; plan 0 is the
+        three-term engine itself and always ends the chain."""
+        self.guard_report = None
+        on = getattr(self, "_guard_on", None)
+        if on is None:
+            on = os.environ.get("SKYRIM_PANGU_GUARD", "on").lower() not in ("off", "0", "no")
+        if not self.term_plan or not on:
+            return
+        import time
+        import warnings
+        t0 = time.perf_counter()
+        p = self._params
+        fit = state
+        with torch.no_grad(), torch.cuda.device(self.device):
+            if self._guard_pair is not None:
+                x, ref = self._guard_pair
+            else:
+                x = (calibration_state(self.geom, p["norm.mean"], p["norm.std"]) if state is None else state).to(self.device, torch.float32).contiguous()
+                three = PanguEngine(self.geom, "f16x3q", self.device, mlp="split", **self._conventions)    # the tiled three-term form, like the fit's tap engine
+                three.load_params(p, calibration="off")
+                ref = three.step(x)
+                three.release()
+                del three
+            sigma = p["norm.std"].to(self.device, torch.float32).reshape(-1)
+            chain = []
+            for plan in (self.term_plan, self.term_plan & 0xFF, 0):
+                if plan not in chain:
+                    chain.append(plan)
+            report = []
+            for plan in chain:
+                if plan != self.term_plan:
+                    self._create(plan)
+                    self._prepare(p)
+                    if fit is not None:
+                        pair = self._guard_pair
+                        self._fit(fit)
+                        self._guard_pair = pair
+                err = ((self.step(x) - ref).abs().amax(dim=(1, 2)) / sigma).max().item()
+                report.append((plan, err))
+                if err < GUARD_TOL:
+                    break
+        self._guard_pair = None
+        self.guard_report = report
+        self.guard_seconds = time.perf_counter() - t0
+        torch.cuda.empty_cache()
+        tried = ", ".join(f"{pl:#05x}: {e:.2e}" for pl, e in report)
+        if report[-1][1] >= GUARD_TOL:
+            # plan 0 IS three terms everywhere (the fused kernels); the reference is the tiled three-term form of the same arithmetic.  Two fp32-class
+            # evaluations that far apart mean the WEIGHTS amplify rounding beyond the bar (measured: 1 % of every Linear's rows x30 -> 1e-2 in every
+            # mode, the CPU oracle included): refused like a non-finite forecast, unless SKYRIM_PANGU_GUARD=warn.
+            msg = (f"Pangu weights amplify fp32-class rounding differences beyond {GUARD_TOL:g} sigma on the calibration state in every term plan ({tried}): "
+                   "no mode of this engine can promise the 1e-3 bar on them")
+            if os.environ.get("SKYRIM_PANGU_GUARD", "on").lower() != "warn":
+                raise FloatingPointError(msg + " (SKYRIM_PANGU_GUARD=warn to run anyway)")
+            warnings.warn(msg, RuntimeWarning, stacklevel=3)
+        elif len(report) > 1:
+            warnings.warn(f"Pangu term plan {self.term_plan_requested:#05x} is outside {GUARD_TOL:g} sigma of the three-term engine on these weights "
+                          f"({tried}); running plan {self.term_plan:#05x}", RuntimeWarning, stacklevel=3)
 
     def step(self, x: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
         if out is None:

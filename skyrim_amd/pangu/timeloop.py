@@ -80,7 +80,7 @@ class PanguTimeLoop:
 
     def __init__(self, params: dict | None = None, geom: PanguGeometry | None = None, precision: str = DEFAULT_PRECISION,
                  device: str | torch.device = "cuda:0", seed: int = 0, params24: dict | None = None, conventions: dict | None = None,
-                 calibration: "torch.Tensor | str | None" = None, rounding: str = "default"):
+                 calibration: "torch.Tensor | str | None" = None, rounding: str = "default", guard: "bool | None" = None):
         """``params``: 6-h network (default: ``SKYRIM_PANGU_WEIGHTS`` state dict or seeded random init).
         ``params24`` (optional, or ``SKYRIM_PANGU_WEIGHTS_24``): the 24-h network; when present a multi-step
         generator interleaves the two like earth2mip's Pangu loop does (every 4th step is a 24-h step from the state
@@ -106,13 +106,14 @@ class PanguTimeLoop:
         self.engine = PanguEngine(self.geom, precision, device, **conventions)
         if params is None:
             params = weights.resolve("SKYRIM_PANGU_WEIGHTS", lambda p: _load_weights(p, self.geom), lambda: init_synthetic(self.geom, seed), "pangu")
-        self.engine.load_params(params, calibration=calibration, rounding=rounding)
+        # ``guard``: the engine's load-time precision guard (PanguEngine.load_params): on by default -- the plan in effect is ``self.term_plan``
+        self.engine.load_params(params, calibration=calibration, rounding=rounding, guard=guard)
         if params24 is None and os.environ.get("SKYRIM_PANGU_WEIGHTS_24"):
             params24 = _load_weights(os.environ["SKYRIM_PANGU_WEIGHTS_24"], self.geom)
         self.engine24 = None
         if params24 is not None:
             self.engine24 = PanguEngine(self.geom, precision, device, **conventions)
-            self.engine24.load_params(params24, calibration=calibration, rounding=rounding)
+            self.engine24.load_params(params24, calibration=calibration, rounding=rounding, guard=guard)
         self.grid = Grid(self.geom.lat, self.geom.lon)
         self._mean = params["norm.mean"].to(self.engine.device, torch.float32).reshape(-1, 1, 1)
         self._std = params["norm.std"].to(self.engine.device, torch.float32).reshape(-1, 1, 1)
@@ -121,10 +122,22 @@ class PanguTimeLoop:
     def device(self):
         return self.engine.device
 
+    @property
+    def term_plan(self) -> int:
+        """The MFMA term plan the 6-h engine runs with (the default unless its load-time guard fell back; engine.guard_report has the figures)."""
+        return self.engine.term_plan_in_effect
+
     def to(self, device):
         if torch.device(device) != self.engine.device:
             raise NotImplementedError("the engine's arenas are bound to one GPU; build a new PanguTimeLoop for another device")
         return self
+
+    def release(self):
+        """``skpangu_destroy`` + arenas dropped, for both networks (GlobalModel.release_model)."""
+        for e in (self.engine, self.engine24):
+            if e is not None:
+                e.release()
+        self._mean = self._std = None
 
     def __call__(self, time: datetime.datetime, x: torch.Tensor, restart=None):
         if x.dim() != 5 or x.shape[0] != 1 or x.shape[1] != self.n_history_levels or tuple(x.shape[2:]) != self.engine.state_shape:

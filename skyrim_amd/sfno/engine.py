@@ -181,6 +181,17 @@ class SfnoEngine:
     def _stream(self):
         return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
+    def release(self):
+        """Drop every prepared matrix, table and work buffer (GlobalModel.release_model).  The C ABI holds no state of its own -- all device
+        memory is torch tensors owned here -- so this IS the teardown; the engine is unusable until ``load_params`` runs again."""
+        keep = ("cfg", "terms", "fused", "skip_in_spectrum", "f_ana", "f_syn", "lib", "device", "state_shape", "_label", "profiling")
+        kept = {k: v for k, v in vars(self).items() if k in keep}
+        self.__dict__.clear()
+        self.__dict__.update(kept)
+        self.chain = None
+        self.prepared = False
+        self._events = []
+
     # ---- prepare ---------------------------------------------------------------------------------- #
     def load_params(self, params: dict):
         c = self.cfg

@@ -65,6 +65,10 @@ class SfnoTimeLoop:
         """Initial-condition hook of the synthetic DataSource (no network for GFS / ERA5 here)."""
         return synthetic_state(self.cfg, seed)
 
+    def release(self):
+        """Drop every prepared matrix and work buffer of the engine (GlobalModel.release_model; the SFNO C ABI is stateless)."""
+        self.engine.release()
+
     def __call__(self, time: datetime.datetime, x: torch.Tensor, restart=None):
         if x.dim() != 5 or x.shape[0] != 1 or x.shape[1] != 1 or tuple(x.shape[2:]) != self.engine.state_shape:
             raise ValueError(f"expected x of shape (1, 1, {', '.join(map(str, self.engine.state_shape))}), got {tuple(x.shape)}")

@@ -192,7 +192,7 @@ def test_graphcast_library_exports_declared_symbols_and_rejects_bad_arguments():
     syms = sorted(set(re.findall(r"\b(skgc_[a-z0-9_]+)\s*\(", header)))
     lib = E.load_library()
     assert set(syms) == set(E.EXPORTS) and all(hasattr(lib, s) for s in syms)
-    assert lib.skgc_abi_version() == 4
+    assert lib.skgc_abi_version() == 5
     assert lib.skgc_gather_gemm(None, None) == -1
     assert lib.skgc_gather_gemm(ctypes.byref(E.GatherDesc()), None) == -1
     assert lib.skgc_layer_norm(None, None, None, None, None, 4, 32, None) == -1

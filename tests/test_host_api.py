@@ -194,6 +194,62 @@ def test_multi_model_ensemble_mean_over_common_channels(boring_registry):
         GlobalEnsemble(["boring", "missing"])
 
 
+def test_ensemble_rollout_saves_the_per_step_mean_files_and_releases_each_member(boring_registry, tmp_path, monkeypatch):
+    """The reference's contract (ensemble.py:86-128): members one at a time, each released in a ``finally``; with save=True the per-step
+    ENSEMBLE-MEAN files ``{a_b}/{a_b}__{src}__{t0}__{t1}.nc`` (names sorted) are written and returned; ``GlobalEnsemblePrediction`` opens them."""
+    from skyrim_amd.core.models.ensemble import GlobalEnsemblePrediction
+    released = []
+    monkeypatch.setattr(BoringGlobalModel, "release_model", lambda self: released.append(self.model_name))
+    ens = GlobalEnsemble(["other", "boring"], ic_source="cds")
+    mean, paths = ens.rollout(T0, n_steps=2, save=True, save_config={"output_dir": str(tmp_path)})
+    assert released == ["other", "boring"] and ens._model is None
+    assert [p.name for p in paths] == ["boring_other__synthetic__20240513_18:00__20240514_00:00.nc", "boring_other__file__20240514_00:00__20240514_06:00.nc"]
+    assert all(p.parent == tmp_path / "boring_other" and p.exists() for p in paths)
+    assert len(ens.member_paths) == 4 and all(Path(p).exists() for p in ens.member_paths)
+    for s, p in enumerate(paths):
+        got = open_dataarray(p)
+        members = [open_dataarray(q) for q in ens.member_paths[s::2]]
+        want = 0.5 * (members[0].sel(channel=["t2m", "u1000"]).values + members[1].sel(channel=["t2m", "u1000"]).values)
+        assert got.channel.values.tolist() == ["t2m", "u1000"] and np.allclose(got.values, want)
+    assert np.allclose(open_dataarray(paths[-1]).values, mean.values)
+    gp = GlobalEnsemblePrediction(paths[-1])
+    assert gp.point(90.0, 0.0, "t2m", n_step=1) == pytest.approx(mean.values[1, 0, 0, 0])
+    # a member that fails is still released, and nothing is swallowed
+    monkeypatch.setattr(OtherBoringModel, "rollout", lambda self, **kw: (_ for _ in ()).throw(RuntimeError("boom")))
+    released.clear()
+    with pytest.raises(RuntimeError, match="boom"):
+        GlobalEnsemble(["boring", "other"], ic_source="cds").rollout(T0, n_steps=1, save=False)
+    assert released == ["boring", "other"]
+    with pytest.raises(ValueError, match="netcdf"):
+        ens.rollout(T0, n_steps=1, save=True, save_config={"output_dir": str(tmp_path), "file_type": "zarr"})
+
+
+def test_ensemble_mean_aligns_reversed_latitudes():
+    """xr.concat aligns by label (reference ensemble.py:64); a member delivered south-to-north (GraphCast) is turned round, another grid refused."""
+    lat = np.linspace(90, -90, 5)
+    a = DataArray(np.arange(10, dtype=np.float32).reshape(1, 1, 5, 2), ["time", "channel", "lat", "lon"], dict(time=[T0], channel=["t2m"], lat=lat, lon=[0.0, 180.0]))
+    b = DataArray(a.values[:, :, ::-1].copy(), ["time", "channel", "lat", "lon"], dict(time=[T0], channel=["t2m"], lat=lat[::-1].copy(), lon=[0.0, 180.0]))
+    m = GlobalEnsemble(["pangu"])._ensemble_predictions([a, b])
+    assert np.array_equal(m.values, a.values) and np.array_equal(m.lat.values, lat)
+    c = DataArray(a.values, ["time", "channel", "lat", "lon"], dict(time=[T0], channel=["t2m"], lat=lat * 0.5, lon=[0.0, 180.0]))
+    with pytest.raises(ValueError, match="different lat"):
+        GlobalEnsemble(["pangu"])._ensemble_predictions([a, c])
+
+
+def test_estimate_pressure_hpa():
+    from skyrim_amd.core.models.utils import estimate_pressure_hpa
+    assert estimate_pressure_hpa(0.0) == pytest.approx(1013.25)
+    assert estimate_pressure_hpa(1500.0) == pytest.approx(845.6, abs=0.2) and estimate_pressure_hpa(5500.0) == pytest.approx(505.4, abs=0.5)
+
+
+def test_release_model_calls_the_time_loops_release():
+    m = BoringGlobalModel(ic_source="cds")
+    seen = []
+    m.model.release = lambda: seen.append("released")
+    m.release_model()
+    assert seen == ["released"] and m.model is None
+
+
 def test_perturb_initial_conditions():
     da = DataArray(np.zeros((1, 2, 9, 96), np.float32), ["time", "channel", "lat", "lon"],
                    dict(time=[T0], channel=["t2m", "msl"], lat=GEOM.lat, lon=GEOM.lon))

@@ -42,6 +42,8 @@ def test_pangu_onnx_file_through_the_reference_api(tmp_path, monkeypatch):
     ic = torch.from_numpy(np.array(pred.values[0]))
     err = O.per_channel_rel_err(torch.from_numpy(np.array(pred.values[1])), O.forward(params, ic)).max().item()
     assert err < 7e-4, err
+    # the load-time guard judged the default plan on THESE weights and the loop records what it runs with (PanguEngine._guard)
+    assert m.model.term_plan == 0x66F and m.model.engine.guard_report and m.model.engine.guard_report[-1][1] < 5e-4, m.model.engine.guard_report
     # without the reviewed mapping the loader refuses (the automatic shape-and-order mapping is never applied silently)
     Path(str(path) + ".map.json").unlink()
     with pytest.raises(ValueError, match="no slot mapping given"):
@@ -189,3 +191,42 @@ def test_multi_model_mean_on_real_engines_and_device_wind_speed():
     host = gp.wind_speed_field(1000, n_step=1)
     dev = gp.wind_speed_field(1000, n_step=1, device="cuda:0")
     assert dev.is_cuda and np.allclose(np.asarray(host), dev.cpu().numpy(), rtol=1e-6)
+
+
+def test_ensemble_rollout_on_real_engines_writes_the_mean_files_and_frees_each_member(tmp_path, monkeypatch):
+    """``GlobalEnsemble.rollout`` to the reference's contract (ensemble.py:86-128) on the HIP engines: one member on the GPU at a time, released
+    in a ``finally`` (``GlobalModel.release_model``: ``skpangu_destroy`` / arenas dropped / allocator emptied -- ``torch.cuda.memory_allocated()``
+    is back at its baseline after EACH member), the per-step ensemble-mean files named ``{a_b}__{src}__{t0}__{t1}.nc`` and holding the mean of
+    the members' files of that step."""
+    from skyrim_amd.core.models.ensemble import GlobalEnsemble, GlobalEnsemblePrediction
+    from skyrim_amd.labeled import open_dataarray
+    from skyrim_amd.pangu.spec import PanguGeometry
+    from skyrim_amd.sfno.spec import SfnoConfig
+    g = PanguGeometry(49, 192)
+    cfg = SfnoConfig(n_lat=49, n_lon=192, embed_dim=32, num_layers=3, scale_factor=2)
+    ens = GlobalEnsemble(["pangu", "fourcastnet_v2"], ic_source="synthetic", model_kwargs={"pangu": dict(geom=g), "fourcastnet_v2": dict(cfg=cfg)})
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    base, seen, peak = torch.cuda.memory_allocated(), [], []
+    release = GlobalEnsemble._release_model
+
+    def spy(self):
+        peak.append(torch.cuda.memory_allocated())
+        release(self)
+        seen.append(torch.cuda.memory_allocated())
+
+    monkeypatch.setattr(GlobalEnsemble, "_release_model", spy)
+    mean, paths = ens.rollout(T0, n_steps=2, save=True, save_config={"output_dir": str(tmp_path)})
+    assert len(seen) == 2 and all(p > base + (1 << 20) for p in peak), (base, peak)          # a member holds device memory while it runs ...
+    assert all(s <= base for s in seen), (base, seen)                                            # ... and none once it is released
+    assert [p.name for p in paths] == ["fourcastnet_v2_pangu__synthetic__20240513_18:00__20240514_00:00.nc",
+                                       "fourcastnet_v2_pangu__file__20240514_00:00__20240514_06:00.nc"]
+    assert all(p.parent == tmp_path / "fourcastnet_v2_pangu" and p.exists() for p in paths)
+    for s, p in enumerate(paths):
+        got, members = open_dataarray(p), [open_dataarray(q) for q in ens.member_paths[s::2]]
+        common = got.channel.values.tolist()
+        assert len(common) > 40 and common == ens.common_channels
+        want = 0.5 * (members[0].sel(channel=common).values + members[1].sel(channel=common).values)
+        assert np.allclose(got.values, want, rtol=1e-6, atol=1e-6)
+    assert np.allclose(open_dataarray(paths[-1]).values, mean.values, rtol=1e-6, atol=1e-6)
+    assert GlobalEnsemblePrediction(paths[-1]).prediction.shape == mean.shape

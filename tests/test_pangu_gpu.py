@@ -251,7 +251,7 @@ def test_full_size_term_plans_vs_oracle(full, full_ref):
                   (0x66, "synthetic", "nearest", 1e-3), (0x66, "off", "nearest", 1e-3), (0xFF, "synthetic", "compensated", 1e-3), (0x66F, "synthetic", "nearest", 1e-3)]
     for plan, cal, rounding, bound in plans:
         e = PanguEngine(g, "f16x3q", "cuda:0", term_plan=plan)
-        e.load_params(params, calibration=cal, rounding=rounding)
+        e.load_params(params, calibration=cal, rounding=rounding, guard=False)          # the plan AS GIVEN is what is measured
         state = x.cuda().clone()
         errs = []
         for k in range(4):
@@ -531,7 +531,7 @@ def test_calibration_folds_the_dropped_weight_term_into_the_biases(toy, ref):
     errs, outs = {}, {}
     for cal in ("off", "synthetic"):
         eng = PanguEngine(g, "f16x3q", "cuda:0", term_plan=0xFF)
-        eng.load_params(params, calibration=cal)
+        eng.load_params(params, calibration=cal, guard=False)           # the plan as given: the load-time guard would leave an uncalibrated 0xFF
         assert eng.calibrated_on == (None if cal == "off" else "synthetic")
         outs[cal] = eng.step(x.cuda()).cpu()
         errs[cal] = O.per_channel_rel_err(outs[cal], y_ref).max().item()
@@ -605,7 +605,7 @@ def test_compensated_rounding_of_the_one_plane_weights(toy, ref):
     errs = {}
     for rounding in ("nearest", "compensated"):
         eng = PanguEngine(g, "f16x3q", "cuda:0", term_plan=0xFF)
-        eng.load_params(params, rounding=rounding)
+        eng.load_params(params, rounding=rounding, guard=False)
         assert eng.rounding == rounding and eng.calibrated_on == "synthetic"
         state = x.cuda().clone()
         e = []
@@ -620,7 +620,7 @@ def test_compensated_rounding_of_the_one_plane_weights(toy, ref):
     assert errs["compensated"] < 0.6 * errs["nearest"] and errs["compensated"] < 3 * errs["three terms"], errs
     eng.calibrate(None)                                             # back to nearest rounding, master biases
     off = PanguEngine(g, "f16x3q", "cuda:0", term_plan=0xFF)
-    off.load_params(params, calibration="off")
+    off.load_params(params, calibration="off", guard=False)
     assert torch.equal(eng.step(x.cuda()), off.step(x.cuda()))
     # the operands the statistics are taken from are the oracle's (attention output, mid-block stream, hidden activation of block 0)
     tap = PanguEngine(g, "f16x3q", "cuda:0", mlp="split")
@@ -651,7 +651,7 @@ def test_one_term_block_gemms_in_the_coarse_layers(toy, ref):
     errs, outs = {}, {}
     for rounding in ("nearest", "compensated"):
         eng = PanguEngine(g, "f16x1m", "cuda:0")
-        eng.load_params(params, rounding=rounding)
+        eng.load_params(params, rounding=rounding, guard=False)
         assert eng.term_plan == 0x66F
         outs[rounding] = eng.step(x.cuda()).cpu()
         errs[rounding] = O.per_channel_rel_err(outs[rounding], y_ref).max().item()
@@ -694,7 +694,7 @@ def test_time_loop_calibrates_on_the_first_initial_condition(toy, ref):
     _, y2, _ = next(it)
     it.close()
     assert torch.equal(y2, y)
-    off = PanguTimeLoop(params, g, calibration="off")
+    off = PanguTimeLoop(params, g, calibration="off", guard=False)
     assert off.engine.calibrated_on is None and PanguTimeLoop(params, g).engine.calibrated_on == "synthetic"
 
 
@@ -753,9 +753,9 @@ def test_outlier_weights_and_states_stay_inside_the_bar_or_trip_the_guard(toy):
     from skyrim_amd.pangu.timeloop import PanguTimeLoop
     g, params, x = toy
 
-    def run(p, state, **kw):
+    def run(p, state, guard=None, **kw):
         e = PanguEngine(g, device="cuda:0", **kw)
-        e.load_params(p)
+        e.load_params(p, guard=guard)
         return e.step(state.cuda()).cpu()
 
     mild = _outlier_params(params, scale=5.0)
@@ -764,9 +764,9 @@ def test_outlier_weights_and_states_stay_inside_the_bar_or_trip_the_guard(toy):
     assert err < DEF_TOL, err
     heavy = _outlier_params(params, scale=30.0)
     ref = O.forward(heavy, x)
-    e_def = O.per_channel_rel_err(run(heavy, x), ref).max().item()
+    e_def = O.per_channel_rel_err(run(heavy, x, guard=False), ref).max().item()
     e_3t = O.per_channel_rel_err(run(heavy, x, precision="f16x3q", term_plan=0), ref).max().item()
-    print(f"outlier stress (1 % of the weight rows x30): default {e_def:.3e}, three terms everywhere {e_3t:.3e}")
+    print(f"outlier stress (1 % of the weight rows x30): default plan as given {e_def:.3e}, three terms everywhere {e_3t:.3e}")
     assert e_def < 2.0 * e_3t + 1e-3, (e_def, e_3t)
     mean, std = params["norm.mean"], params["norm.std"]
     wild = x.clone()
@@ -785,6 +785,47 @@ def test_outlier_weights_and_states_stay_inside_the_bar_or_trip_the_guard(toy):
     _, y1, _ = next(it)
     it.close()
     assert torch.isfinite(y1).all()
+
+
+def test_load_time_guard_never_applies_the_default_plan_blind(toy, ref):
+    """PanguEngine._guard: after the plan is prepared, ONE step of it against ONE step of the three-term engine on the
+    calibration state, per channel in sigma units; at GUARD_TOL (5e-4, half the bar) or more the engine falls back 0x66F -> 0x6F -> 0x00, refits,
+    says so and reports the plan in effect.  (i) the synthetic weights keep the default plan; (ii) a plan loaded without calibration / with
+    nearest rounding does not survive (that combination used to run blind); (iii) QKV rows x30: the one-term block GEMMs go, the
+    result meets the bar against the oracle; (iv) 1 % of every Linear's rows x30: even two three-term evaluations disagree by 1e-2 -- the
+    weights amplify rounding in every mode, the oracle's fp32 included -- and the load is REFUSED (FloatingPointError), or, run anyway
+    (SKYRIM_PANGU_GUARD=warn), warned about."""
+    import warnings
+    from skyrim_amd.pangu.engine import GUARD_TOL, PanguEngine
+    from tools.pangu_outlier_scan import outliers
+    g, params, x = toy
+    _, y_ref = ref
+    e = PanguEngine(g, device="cuda:0")
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")                              # (i) no fall-back, no warning
+        e.load_params(params)
+    assert e.term_plan_in_effect == e.term_plan_requested == 0x66F
+    (plan, err), = e.guard_report
+    assert plan == 0x66F and 0 < err < GUARD_TOL, e.guard_report
+    print(f"guard, synthetic weights: plan {plan:#05x} at {err:.2e} sigma of the three-term engine (tolerance {GUARD_TOL:g}), {e.guard_seconds * 1e3:.0f} ms")
+    for kw in (dict(calibration="off"), dict(rounding="nearest")):  # (ii)
+        with pytest.warns(RuntimeWarning, match="term plan 0x66f"):
+            e.load_params(params, **kw)
+        assert e.term_plan_in_effect != 0x66F and e.guard_report[-1][1] < GUARD_TOL and e.term_plan_requested == 0x66F
+        assert O.per_channel_rel_err(e.step(x.cuda()).cpu(), y_ref).max().item() < DEF_TOL
+    e.load_params(params)                                           # a later load starts from the plan asked for again
+    assert e.term_plan_in_effect == 0x66F
+    qkv = outliers(params, scale=30.0, only="qkv")                  # (iii)
+    with pytest.warns(RuntimeWarning, match="running plan 0x06f"):
+        e.load_params(qkv)
+    assert e.term_plan_in_effect == 0x6F and [p_ for p_, _ in e.guard_report] == [0x66F, 0x6F]
+    err = O.per_channel_rel_err(e.step(x.cuda()).cpu(), O.forward(qkv, x)).max().item()
+    print(f"guard, QKV rows x30: {[(hex(a), float(f'{b:.2e}')) for a, b in e.guard_report]} -> vs oracle {err:.2e}")
+    assert err < 1e-3, err
+    heavy = outliers(params, scale=30.0)                            # (iv)
+    with pytest.raises(FloatingPointError, match="amplify"):
+        e.load_params(heavy)
+    e.release()
 
 
 def test_step_as_a_captured_hip_graph(toy):
