@@ -50,7 +50,6 @@ MODE_NOTES = {
     "f16x3": ("fp16 MFMA on hi/lo fp16 planes, 3 terms per GEMM" + _ATT, "meets the bar (~8e-5)"),
     "bf16x3": ("bf16 MFMA on hi/lo bf16 planes (16-bit operands, fp32 range), 3 terms per GEMM" + _ATT,
                "wide-range alternative; meets the bar (~8e-5)"),
-    "f16": ("fp16 MFMA, single term everywhere, fp32 accumulate", "does NOT meet the bar (~1.2e-3)"),
 }
 
 
@@ -182,7 +181,7 @@ def pmc_kernels(model: str, *needles: str):
 PANGU_STAGE_KERNEL = {"mlp_r0": ("fused_mlp_kernel", "MlpShape<192"), "mlp_r1": ("fused_mlp_kernel", "MlpShape<384"),
                       "proj_mlp_r0": ("proj_mlp", "Shape<192"), "proj_mlp_r1": ("proj_mlp", "Shape<384"),
                       "qkv_r0": ("rt_qkv_kernel", "QkvShape<192"), "qkv_r1": ("rt_qkv_kernel", "QkvShape<384"),
-                      "attn_r0": ("earth_attention",), "attn_r1": ("earth_attention",),
+                      "attn_r0": ("attention", "QaShape<192"), "attn_r1": ("attention", "QaShape<384"),      # qkv_attention_kernel: QKV + attention in one launch
                       "proj_r0": ("gemm_dma_kernel", "256x192", "EpLayerNorm", "RowMapIndexed"), "proj_r1": ("gemm_dma_kernel", "128x384", "EpLayerNorm")}
 
 
@@ -785,7 +784,7 @@ def main():
             out["members_per_gpu"] = members_on_streams(args.precision, geom, params, x_host, dev, args.members_per_gpu)
             torch.cuda.empty_cache()
             out["modes"] = {m: dict(quick_mode(m, geom, params, x_host, dev), note=MODE_NOTES[m][1])
-                            for m in ("f16x2m", "f16x3q", "bf16x3", "f16") if m != args.precision}
+                            for m in ("f16x2m", "f16x3q", "bf16x3") if m != args.precision}
             if not args.no_parity:
                 # the load-time rounding of the one-plane weights (pangu/calibration.py): same kernels, same speed -- what the default gives away without it
                 for m, rounding in ((args.precision, "nearest"),):

@@ -18,11 +18,11 @@
 extern "C" {
 #endif
 
-#define SKPANGU_ABI_VERSION 5
+#define SKPANGU_ABI_VERSION 6
 
 /* precision modes: how each matrix product is formed on the MFMA pipe (values 2 and 5 of ABI v4, the fp16-hidden variants, are gone) */
 #define SKPANGU_PREC_BF16X3 0 /* bf16 hi/lo split, 3 MFMA terms, fp32 range (wide-range mode) */
-#define SKPANGU_PREC_F16    1 /* single fp16 term everywhere (speed probe; outside the 1e-3 bar) */
+/* (value 1, a single fp16 term everywhere, was a speed probe outside the 1e-3 bar and slower than the default plan: removed in ABI v6) */
 #define SKPANGU_PREC_F16X3  3 /* fp16 hi/lo split, 3 MFMA terms (22-bit operands; activations must stay < 65504) */
 #define SKPANGU_PREC_F16X3_Q 4 /* f16x3 with the QKV linear reading only the hi plane of the stream; with a term_plan: the host's modes */
 

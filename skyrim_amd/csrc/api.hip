@@ -132,10 +132,13 @@ struct Engine : IEngine {
     bool rt_proj = false, rt_qkv = false;   // row-tile proj / QKV kernels (rowtile.hip)
     bool fused_block = false;               // proj + LayerNorm + residual + MLP as one kernel (fused_block.hip)
     bool attn2 = true;                      // attention with the bias gathered from the compact table in LDS (SKP_ATTN_V1=1: the expanded table)
+    bool fused_qa = true;                   // QKV + attention as ONE kernel, q / k / v in registers (attention.hip; SKP_SPLIT_ATTN=1: the two launches)
     int plan2 = 0;                          // bit l: layer l + 1 runs proj / fc1 / fc2 with TWO terms (weights as one fp16 plane, fused_block2.hip)
     bool two_term(int layer) const { return (plan2 >> layer) & 1; }
     bool qkv_one(int layer) const { return rt_qkv && ((plan2 >> (4 + layer)) & 1); }   // QKV with ONE term (stream hi plane x weight hi plane)
     bool block_one(int layer) const { return (plan2 >> (8 + layer)) & 1; }             // proj / fc1 / fc2 with ONE term (activation hi plane x weight hi plane)
+    // the fused QKV + attention kernel takes the row-tile QKV weights of a block: one plane at either width, hi / lo planes at C = 192 only (LDS)
+    bool qa_fused(const BlockW<T>& bw, int res) const { return fused_qa && rt_qkv && attn2 && bw.bias_cmp && (bw.qkvh || (bw.qkvf && res == 0)); }
     T* zrow = nullptr;
     float *qkv_w_tmp = nullptr, *qkv_b_tmp = nullptr;
     float* cal_sum = nullptr;               // column sums of one GEMM operand (calibrate)
@@ -191,6 +194,10 @@ struct Engine : IEngine {
             fl[C_PROJ0 + o] = 2 * mw * C * C;          by[C_PROJ0 + o] = mw * C * sa + 2 * nt * C * 4 + C * C * wb;   // stream: 4 B/elem read + 4 B/elem written
             fl[C_FC1_0 + o] = 2 * nt * C * 4 * C;      by[C_FC1_0 + o] = nt * C * 2 * NA_ + nt * 4 * C * sa + 4 * C * C * wb;
             fl[C_FC2_0 + o] = 2 * nt * C * 4 * C;      by[C_FC2_0 + o] = nt * 4 * C * sa + 2 * nt * C * 4 + 4 * C * C * wb;
+            if (fused_qa && rt_qkv && attn2 && (r == 0 || (plan2 >> (4 + 1)) & 1)) {   // QKV inside the attention launch: its FLOPs, the stream's hi plane in, the output out
+                fl[C_ATTN0 + o] += fl[C_QKV0 + o];
+                by[C_ATTN0 + o] = nt * C * 2 + mw * C * sa + 3 * C * C * wb + (double)g.types[r] * heads * 3456 * 2;
+            }
             if (fused_mlp) {   // one kernel: both GEMMs, stream read once + written once, both weight matrices
                 fl[C_FC1_0 + o] = 4 * nt * C * 4 * C;  by[C_FC1_0 + o] = 2 * nt * C * 4 + 8 * C * C * wb;
             }
@@ -291,6 +298,7 @@ struct Engine : IEngine {
 
     explicit Engine(const Geom& geom, int qkv_a1 = 0, int mlp_mode = 0, int term_plan = 0) : g(geom) {
         attn2 = getenv("SKP_ATTN_V1") == nullptr;
+        fused_qa = getenv("SKP_SPLIT_ATTN") == nullptr;
         fused_mlp = (P::NA == 2 && P::NW == 2 && mlp_mode == 0);
         // proj in row-tile form measures the same as the tiled GEMM (0.199 vs 0.197 ms at C = 384, 0.264 vs 0.264 at C = 192: with 16 rows
         // per wave its LDS reads run at 2/3 of the LDS rate): kept behind SKP_RT_PROJ=1, the tiled LayerNorm GEMM stays the default
@@ -405,17 +413,28 @@ struct Engine : IEngine {
         const BlockW<T>& bw = w.blk[block_index(layer0, i)];
         const int* widx = w.widx[res][i & 1];
         const int o = res == 0 ? 0 : 5;
-        mark(C_QKV0 + o, s);
+        bool fused = false;
         if constexpr (std::is_same<P, PrecF16x3>::value) {
-            if (rt_qkv) CK(op_qkv_rowtile(g, bw, widx, res, xs, wk, s));
-            else CK((op_qkv<P>(g, bw, widx, res, xs, wk, s)));
-        } else {
-            CK((op_qkv<P>(g, bw, widx, res, xs, wk, s)));
+            // QKV + attention in one launch: the row-tile QKV forms (stream hi plane; one weight plane, or hi / lo at C = 192) with the compact bias
+            if (qa_fused(bw, res)) {
+                mark(C_ATTN0 + o, s);
+                CK(op_qkv_attention(g, bw, widx, res, xs, wk, s, block_one(layer0) ? 1 : 2));
+                fused = true;
+            }
         }
-        mark(C_ATTN0 + o, s);
-        AttnArgs<P> a{wk.q, wk.k, wk.vt, wk.qkv_plane, bw.bias_exp, bw.bias_cmp, wk.ao, wk.ao_plane, C, g.nwin[res], g.nW[res], heads};
-        a.out_planes = block_one(layer0) ? 1 : 0;           // a one-term block kernel reads the hi plane only
-        CK(launch_attention<P>(a, s));
+        if (!fused) {
+            mark(C_QKV0 + o, s);
+            if constexpr (std::is_same<P, PrecF16x3>::value) {
+                if (rt_qkv) CK(op_qkv_rowtile(g, bw, widx, res, xs, wk, s));
+                else CK((op_qkv<P>(g, bw, widx, res, xs, wk, s)));
+            } else {
+                CK((op_qkv<P>(g, bw, widx, res, xs, wk, s)));
+            }
+            mark(C_ATTN0 + o, s);
+            AttnArgs<P> a{wk.q, wk.k, wk.vt, wk.qkv_plane, bw.bias_exp, bw.bias_cmp, wk.ao, wk.ao_plane, C, g.nwin[res], g.nW[res], heads};
+            a.out_planes = block_one(layer0) ? 1 : 0;           // a one-term block kernel reads the hi plane only
+            CK(launch_attention<P>(a, s));
+        }
         if constexpr (std::is_same<P, PrecF16x3>::value) {
             if (two_term(layer0)) {               // ... with the weights as one fp16 plane: two MFMA terms, or one
                 mark(C_FC1_0 + o, s);
@@ -608,7 +627,6 @@ struct Engine : IEngine {
 IEngine* make_engine(const skpangu_config& cfg, const Geom& g) {
     switch (cfg.precision) {
         case SKPANGU_PREC_BF16X3: return new Engine<PrecBF16x3>(g, 0, cfg.mlp_mode);
-        case SKPANGU_PREC_F16: return new Engine<PrecF16>(g);
         case SKPANGU_PREC_F16X3: return new Engine<PrecF16x3>(g, 0, cfg.mlp_mode, cfg.term_plan);
         case SKPANGU_PREC_F16X3_Q: return new Engine<PrecF16x3>(g, 1, cfg.mlp_mode, cfg.term_plan);
         default: return nullptr;

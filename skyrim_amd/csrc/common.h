@@ -38,7 +38,6 @@ __device__ __forceinline__ typename OpT<T>::v8 as_v8(const uint4& u) {
 // A GEMM computes sum over "terms": (A_hi,W_hi) [+ (A_lo,W_hi) if NA==2] [+ (A_hi,W_lo) if NW==2].
 // bf16x3 carries 16 significand bits per operand: fp32-class results on the bf16 MFMA pipe.
 struct PrecBF16x3 { typedef bf16 T; static constexpr int NA = 2, NW = 2; };
-struct PrecF16    { typedef f16 T;  static constexpr int NA = 1, NW = 1; };
 // fp16 hi/lo planes, 3 terms: 22 significand bits per operand (bf16x3: 16); needs |x| < 65504 (activations are O(1..10))
 struct PrecF16x3  { typedef f16 T;  static constexpr int NA = 2, NW = 2; };
 // fc2 of the "fp16 hidden" mode: A = single fp16 plane (the GELU output), W = fp16 hi/lo planes, 2 MFMA terms

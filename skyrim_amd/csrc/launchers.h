@@ -98,6 +98,8 @@ template <class T> hipError_t prep_mlp_weights(const float* w1, const float* w2,
 template <class P> hipError_t op_proj_rowtile(const Geom&, const BlockW<typename P::T>&, const int* widx, int res, typename P::T* Xs, const Work<P>&, hipStream_t);
 hipError_t op_qkv_rowtile(const Geom&, const BlockW<f16>&, const int* widx, int res, const f16* Xs, const Work<PrecF16x3>&, hipStream_t);
 template <class T> hipError_t prep_rowtile_weights(const float* w, T* wf, int N, int K, hipStream_t, int planes = 2);
+// the 2-term / 1-term QKV linear and the window attention as ONE kernel: q / k / v stay in registers (attention.hip); out_planes as AttnArgs'
+hipError_t op_qkv_attention(const Geom&, const BlockW<f16>&, const int* widx, int res, const f16* Xs, const Work<PrecF16x3>&, hipStream_t, int out_planes);
 // proj + LayerNorm + residual + MLP + LayerNorm + residual in one kernel (fused_block.hip): weights from prep_rowtile_weights / prep_mlp_weights
 template <class P> hipError_t op_proj_mlp_fused(const Geom&, const BlockW<typename P::T>&, const int* winv, int res, typename P::T* Xs, const Work<P>&, hipStream_t);
 // the same with the weights as ONE fp16 plane: two MFMA terms, or -- `one` -- a single term (activation operands as one fp16 plane too) (fused_block2.hip)

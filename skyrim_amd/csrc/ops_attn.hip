@@ -44,10 +44,8 @@ hipError_t op_proj(const Geom& g, const BlockW<typename P::T>& b, const int* wid
 }
 
 template hipError_t op_qkv<PrecBF16x3>(const Geom&, const BlockW<bf16>&, const int*, int, const bf16*, const Work<PrecBF16x3>&, hipStream_t);
-template hipError_t op_qkv<PrecF16>(const Geom&, const BlockW<f16>&, const int*, int, const f16*, const Work<PrecF16>&, hipStream_t);
 template hipError_t op_qkv<PrecF16x3>(const Geom&, const BlockW<f16>&, const int*, int, const f16*, const Work<PrecF16x3>&, hipStream_t);
 template hipError_t op_proj<PrecBF16x3>(const Geom&, const BlockW<bf16>&, const int*, int, bf16*, const Work<PrecBF16x3>&, hipStream_t);
-template hipError_t op_proj<PrecF16>(const Geom&, const BlockW<f16>&, const int*, int, f16*, const Work<PrecF16>&, hipStream_t);
 template hipError_t op_proj<PrecF16x3>(const Geom&, const BlockW<f16>&, const int*, int, f16*, const Work<PrecF16x3>&, hipStream_t);
 
 }  // namespace skp

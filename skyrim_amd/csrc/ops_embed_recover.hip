@@ -55,10 +55,8 @@ hipError_t op_recover(const Geom& g, const ModelW<typename P::T>& w, const typen
 }
 
 template hipError_t op_embed<PrecBF16x3>(const Geom&, const ModelW<bf16>&, const float*, bf16*, const Work<PrecBF16x3>&, hipStream_t);
-template hipError_t op_embed<PrecF16>(const Geom&, const ModelW<f16>&, const float*, f16*, const Work<PrecF16>&, hipStream_t);
 template hipError_t op_embed<PrecF16x3>(const Geom&, const ModelW<f16>&, const float*, f16*, const Work<PrecF16x3>&, hipStream_t);
 template hipError_t op_recover<PrecBF16x3>(const Geom&, const ModelW<bf16>&, const bf16*, const bf16*, float*, const Work<PrecBF16x3>&, hipStream_t);
-template hipError_t op_recover<PrecF16>(const Geom&, const ModelW<f16>&, const f16*, const f16*, float*, const Work<PrecF16>&, hipStream_t);
 template hipError_t op_recover<PrecF16x3>(const Geom&, const ModelW<f16>&, const f16*, const f16*, float*, const Work<PrecF16x3>&, hipStream_t);
 
 }  // namespace skp

@@ -32,10 +32,8 @@ hipError_t op_fc2(const Geom& g, const BlockW<typename P::T>& b, int res, typena
 }
 
 template hipError_t op_fc1<PrecBF16x3>(const Geom&, const BlockW<bf16>&, int, const bf16*, const Work<PrecBF16x3>&, hipStream_t);
-template hipError_t op_fc1<PrecF16>(const Geom&, const BlockW<f16>&, int, const f16*, const Work<PrecF16>&, hipStream_t);
 template hipError_t op_fc1<PrecF16x3>(const Geom&, const BlockW<f16>&, int, const f16*, const Work<PrecF16x3>&, hipStream_t);
 template hipError_t op_fc2<PrecBF16x3>(const Geom&, const BlockW<bf16>&, int, bf16*, const Work<PrecBF16x3>&, hipStream_t);
-template hipError_t op_fc2<PrecF16>(const Geom&, const BlockW<f16>&, int, f16*, const Work<PrecF16>&, hipStream_t);
 template hipError_t op_fc2<PrecF16x3>(const Geom&, const BlockW<f16>&, int, f16*, const Work<PrecF16x3>&, hipStream_t);
 
 }  // namespace skp

@@ -43,10 +43,8 @@ hipError_t op_up(const Geom& g, const ModelW<typename P::T>& w, const typename P
 }
 
 template hipError_t op_down<PrecBF16x3>(const Geom&, const ModelW<bf16>&, const bf16*, bf16*, const Work<PrecBF16x3>&, hipStream_t);
-template hipError_t op_down<PrecF16>(const Geom&, const ModelW<f16>&, const f16*, f16*, const Work<PrecF16>&, hipStream_t);
 template hipError_t op_down<PrecF16x3>(const Geom&, const ModelW<f16>&, const f16*, f16*, const Work<PrecF16x3>&, hipStream_t);
 template hipError_t op_up<PrecBF16x3>(const Geom&, const ModelW<bf16>&, const bf16*, bf16*, const Work<PrecBF16x3>&, hipStream_t);
-template hipError_t op_up<PrecF16>(const Geom&, const ModelW<f16>&, const f16*, f16*, const Work<PrecF16>&, hipStream_t);
 template hipError_t op_up<PrecF16x3>(const Geom&, const ModelW<f16>&, const f16*, f16*, const Work<PrecF16x3>&, hipStream_t);
 
 }  // namespace skp

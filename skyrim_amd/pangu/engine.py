@@ -17,14 +17,13 @@ from .. import ops
 from .spec import PanguGeometry
 
 PREC_BF16X3 = 0
-PREC_F16 = 1
 PREC_F16X3 = 3
 PREC_F16X3_Q = 4
 # per-layer MFMA term plan (skpangu_config.term_plan): bit l = layer l + 1 runs proj / fc1 / fc2 with two terms (weights as ONE fp16 plane);
 # bits 4-7: the layer's QKV with ONE term (stream hi plane x weight hi plane); bits 8-11: the layer's proj / fc1 / fc2 with ONE term (the
 # activation operands as their fp16 hi plane too).  Any other plan: PanguEngine(geom, "f16x3q", term_plan=...).
 TERM_PLANS = {"f16x1m": 0x66F, "f16x2m": 0x6F, "f16x2c": 0x66}
-PRECISIONS = {"bf16x3": PREC_BF16X3, "f16": PREC_F16, "f16x3": PREC_F16X3, "f16x3q": PREC_F16X3_Q, **{m: PREC_F16X3_Q for m in TERM_PLANS}}
+PRECISIONS = {"bf16x3": PREC_BF16X3, "f16x3": PREC_F16X3, "f16x3q": PREC_F16X3_Q, **{m: PREC_F16X3_Q for m in TERM_PLANS}}
 # Modes (all: fp16 hi/lo ACTIVATION planes in the residual stream, fp32 accumulation / LayerNorm / softmax / GELU, fp16 attention core):
 #   "f16x1m"  DEFAULT since round 5 (plan 0x66F).  Every block's proj / fc1 / fc2 weights are ONE fp16 plane; in the coarse layers 2 / 3 (C = 384:
 #             12 of the 16 blocks, 72 % of the FLOPs) those GEMMs read the activations' hi plane only -- ONE MFMA term, A_hi W -- and the QKV
@@ -37,7 +36,6 @@ PRECISIONS = {"bf16x3": PREC_BF16X3, "f16": PREC_F16, "f16x3": PREC_F16X3, "f16x
 #   "f16x2m"  round 3 / 4's default (0x6F): two terms in every block, one-term QKV in layers 2 / 3.
 #   "f16x2c"  0x66: layers 1 / 4 at three terms.   "f16x3q": three terms everywhere (~1e-4), QKV from the stream's hi plane.
 #   "f16x3"   three terms, hi/lo QKV operand.      "bf16x3": the wide-range alternative (activations beyond fp16's 65504).
-#   "f16"     single fp16 plane everywhere: a speed probe, NOT inside the bar (~1.2e-3).
 # The term a one-plane Linear drops, A x (W - fp16(W)), has its mean over a calibration state folded into the bias at load time
 # (``PanguEngine.calibrate``).
 DEFAULT_PRECISION = "f16x1m"
@@ -81,6 +79,7 @@ EXPORTS = [
 ]
 
 _lib = None
+ABI_VERSION = 6            # include/skyrim_pangu.h SKPANGU_ABI_VERSION
 
 
 def load_library() -> ctypes.CDLL:
@@ -117,6 +116,8 @@ def load_library() -> ctypes.CDLL:
     lib.skpangu_profile_read.argtypes = [vp, ctypes.POINTER(SkStageStat), ci, ctypes.POINTER(ci)]
     for name in EXPORTS:
         getattr(lib, name)
+    if lib.skpangu_abi_version() != ABI_VERSION:              # a stale build or a SKYRIM_PANGU_LIB variant from other sources
+        raise RuntimeError(f"{path}: skpangu ABI {lib.skpangu_abi_version()}, this package binds ABI {ABI_VERSION} (include/skyrim_pangu.h); rebuild the library")
     _lib = lib
     return lib
 

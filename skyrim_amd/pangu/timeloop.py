@@ -107,13 +107,16 @@ class PanguTimeLoop:
         if params is None:
             params = weights.resolve("SKYRIM_PANGU_WEIGHTS", lambda p: _load_weights(p, self.geom), lambda: init_synthetic(self.geom, seed), "pangu")
         # ``guard``: the engine's load-time precision guard (PanguEngine.load_params): on by default -- the plan in effect is ``self.term_plan``
-        self.engine.load_params(params, calibration=calibration, rounding=rounding, guard=guard)
+        # (calibration "first": the plan is fitted -- and judged -- on the first initial condition, not at load time)
+        load_guard = False if self._calibrate_on_first else guard
+        self.engine.load_params(params, calibration=calibration, rounding=rounding, guard=load_guard)
         if params24 is None and os.environ.get("SKYRIM_PANGU_WEIGHTS_24"):
             params24 = _load_weights(os.environ["SKYRIM_PANGU_WEIGHTS_24"], self.geom)
+        self._guard = guard
         self.engine24 = None
         if params24 is not None:
             self.engine24 = PanguEngine(self.geom, precision, device, **conventions)
-            self.engine24.load_params(params24, calibration=calibration, rounding=rounding, guard=guard)
+            self.engine24.load_params(params24, calibration=calibration, rounding=rounding, guard=load_guard)
         self.grid = Grid(self.geom.lat, self.geom.lon)
         self._mean = params["norm.mean"].to(self.engine.device, torch.float32).reshape(-1, 1, 1)
         self._std = params["norm.std"].to(self.engine.device, torch.float32).reshape(-1, 1, 1)
@@ -155,6 +158,7 @@ class PanguTimeLoop:
             self._calibrate_on_first = False
             for e in (self.engine, self.engine24):
                 if e is not None:
+                    e._guard_on = self._guard
                     e.calibrate(state)
                     e.calibrated_on = "first"
         yield time, state.unsqueeze(0).clone(), restart

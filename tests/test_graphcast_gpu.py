@@ -281,15 +281,37 @@ def test_full_size_step_vs_oracle_per_channel():
     f = forcings(cfg, 1000.0)
     y = eng.step(x0.cuda(), x1.cuda(), f.cuda())
     assert torch.isfinite(y).all()
-    y = y.cpu()
-    del eng
+    import os
+    if os.environ.get("SKYRIM_TEST_LIVE_ORACLE") == "1":             # every grid point, against the live host job (~2 min of 128 threads)
+        y = y.cpu()
+        eng.release()
+        torch.cuda.empty_cache()
+        import _oracle_jobs
+        ref = _oracle_jobs.fetch("graphcast_full_step")["ref"]       # = O.forward(p, OG.build(...), x0, x1, f), started when collection finished
+        e_ch, e_inc = O.per_channel_rel_err(y, ref).max().item(), O.increment_rel_err(y, ref, x1).max().item()
+        print(f"graphcast full-size step: max per-channel rel err {e_ch:.3e}, relative to the predicted increment {e_inc:.3e}")
+        assert e_ch < 1e-5
+        assert e_inc < 1e-3
+        return
+    # the committed golden vectors of the oracle's rollout on the ORACLE's own graph (tests/golden/full_graphcast.npz), 4 autoregressive
+    # steps (multi-step parity at the real size, and a bound on the fused path's increment drift there -- 7e-3 after 40 toy steps)
+    from _golden_full import FullSizeGolden
+    gold = FullSizeGolden("graphcast")
+    a, b, errs = x0.cuda(), x1.cuda(), []
+    for k in range(gold.steps):
+        if k:
+            y = eng.step(a, b, forcings(cfg, 1000.0 + 6.0 * k).cuda())
+        e = gold.errors(k, y)
+        errs.append((float(e["rel"].max()), float(e["cell"].max()), float(e["inc"].max())))
+        a, b = b, y
+    eng.release()
     torch.cuda.empty_cache()
-    import _oracle_jobs
-    ref = _oracle_jobs.fetch("graphcast_full_step")["ref"]           # = O.forward(p, OG.build(...), x0, x1, f), started when collection finished
-    e_ch, e_inc = O.per_channel_rel_err(y, ref).max().item(), O.increment_rel_err(y, ref, x1).max().item()
-    print(f"graphcast full-size step: max per-channel rel err {e_ch:.3e}, relative to the predicted increment {e_inc:.3e}")
-    assert e_ch < 1e-5
-    assert e_inc < 1e-3
+    print("graphcast full-size rollout, per step: max per-channel rel err " + " ".join(f"{r:.3e}" for r, _, _ in errs) + "; cell means " +
+          " ".join(f"{c:.3e}" for _, c, _ in errs) + "; relative to the step's predicted increment " + " ".join(f"{i:.3e}" for _, _, i in errs))
+    assert torch.isfinite(y).all() and gold.steps >= 4
+    assert errs[0][0] < 1e-5 and errs[0][1] < 1e-5 and errs[0][2] < 1e-3, errs[0]            # one step: as asserted since round 3
+    for k, (r, c, i) in enumerate(errs):
+        assert r < 1e-4 and c < 1e-4 and i < 1e-3, (k, errs)                                  # every step of the rollout: inside the bar, increment too
 
 
 @pytest.mark.timeout(1500)

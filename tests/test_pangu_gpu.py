@@ -6,8 +6,8 @@ Modes (skyrim_amd/pangu/engine.py PRECISIONS): hi/lo split GEMMs with fp16 singl
 activation operands' hi plane only, ONE MFMA term, and their QKV is one term; layers 1 / 4 keep two terms; weights rounded with error
 feedback (compensated) on the built-in calibration state; 2.0 .. 3.05e-4 measured over the full-size 24-h rollout -> asserted <= 3.5e-4),
 "f16x2m" (round 4's default, 0x6F: two terms everywhere; 1.4 .. 1.7e-4 -> <= 3e-4), "f16x2c" (0x66: layers 1 / 4 at three terms),
-"f16x3q" (3 terms; observed ~1e-4 -> asserted <= 3e-4), "f16x3", "bf16x3" (3 terms everywhere; ~8e-5 -> <= 3e-4), and "f16" (single-term
-speed probe, observed ~1.2e-3, does NOT meet the bar -> held to 5e-3).  Other plans: PanguEngine(g, "f16x3q", term_plan=...).
+"f16x3q" (3 terms; observed ~1e-4 -> asserted <= 3e-4), "f16x3", "bf16x3" (3 terms everywhere; ~8e-5 -> <= 3e-4).  (The single-plane
+"f16" probe -- slower than the default since round 5 and outside the bar -- was deleted in round 6.)  Other plans: PanguEngine(g, "f16x3q", term_plan=...).
 Stage-level tests use max-abs / max-abs-ref.
 """
 import os
@@ -23,14 +23,14 @@ from skyrim_amd.pangu.spec import PanguGeometry, init_synthetic, synthetic_state
 
 pytestmark = pytest.mark.gpu
 
-STAGE_TOL = {"f16x1m": 1.5e-3, "f16x2m": 1.5e-3, "f16x2c": 1.5e-3, "bf16x3": 5e-4, "f16x3": 5e-4, "f16x3q": 5e-4, "f16": 4e-3}
+STAGE_TOL = {"f16x1m": 1.5e-3, "f16x2m": 1.5e-3, "f16x2c": 1.5e-3, "bf16x3": 5e-4, "f16x3": 5e-4, "f16x3q": 5e-4}
 # the default mode's asserted error per step (STEP_TOL[DEFAULT_PRECISION]).  Round 5: the one-term coarse layers, measured at 721x1440 over the 24-h
 # rollout at 2.50 / 2.78 / 2.75 / 2.84e-4; the figure is deterministic for a given build but moves with anything that nudges the compensated rounding's
 # decisions -- 2.0 .. 3.05e-4 across three choices of what the rounding is fitted on (tools/r5_x1m_full.py), 1.95e-4 (step 1) after a kernel
 # clean-up that changed no arithmetic on paper -- hence 3.5e-4, three times inside the bar; toy grid 1.5 - 1.7e-4.  The two-term plan (round 4's
 # default) sits at 1.4 .. 1.7e-4 and is held to 3e-4.
 DEF_TOL = 3.5e-4
-STEP_TOL = {"f16x1m": DEF_TOL, "f16x2m": 3e-4, "f16x2c": 3e-4, "bf16x3": 3e-4, "f16x3": 3e-4, "f16x3q": 3e-4, "f16": 5e-3}   # 3-term modes: 3x inside the bar
+STEP_TOL = {"f16x1m": DEF_TOL, "f16x2m": 3e-4, "f16x2c": 3e-4, "bf16x3": 3e-4, "f16x3": 3e-4, "f16x3q": 3e-4}   # 3-term modes: 3x inside the bar
 
 
 def rel(a, b):
@@ -46,8 +46,8 @@ def ref(toy):
     return taps, y
 
 
-# the default run: the default mode, three terms on fp16 planes, the wide-range bf16 planes; SKYRIM_TEST_ALL_MODES=1 adds the other names
-MODES = [DEFAULT_PRECISION, "f16x3q", "bf16x3"] + ([m for m in STEP_TOL if m not in (DEFAULT_PRECISION, "f16x3q", "bf16x3")] if os.environ.get("SKYRIM_TEST_ALL_MODES") else [])
+# the default run: the default mode and three terms on fp16 planes; SKYRIM_TEST_ALL_MODES=1 adds the other names (bf16x3: one step below)
+MODES = [DEFAULT_PRECISION, "f16x3q"] + ([m for m in STEP_TOL if m not in (DEFAULT_PRECISION, "f16x3q")] if os.environ.get("SKYRIM_TEST_ALL_MODES") else [])
 
 
 @pytest.fixture(scope="module", params=MODES)
@@ -125,7 +125,7 @@ def test_rollout_4_steps_in_place(eng, toy):
         eng.step(xs, xs)
         xr = O.forward(params, xr)
     e = O.per_channel_rel_err(xs.cpu(), xr)
-    assert e.max().item() < (1e-3 if eng.precision != "f16" else 1e-2)
+    assert e.max().item() < 1e-3
 
 
 def test_deterministic(eng, toy):
@@ -182,7 +182,7 @@ def test_profile_hooks_cover_the_step(eng, toy):
     eng.profile(False)
     by = {s["name"]: s for s in stats}
     # 3-term modes: projection + MLP as one kernel per block (fused_block.hip); the others: proj, fc1, fc2 as separate launches
-    mlp = "proj_mlp_r1" if eng.precision != "f16" else "fc1_r1"
+    mlp = "proj_mlp_r1"
     assert by[mlp]["launches"] == 12 and by["qkv_r0"]["launches"] == 4 and by["embed"]["launches"] == 1
     assert by["fc2_r1"]["launches"] == by["proj_r1"]["launches"] == (0 if mlp == "proj_mlp_r1" else 12)
     assert all(s["total_ms"] > 0 for s in stats if s["launches"])
@@ -204,9 +204,23 @@ def full():
 
 @pytest.fixture(scope="module")
 def full_ref(full):
-    """BASELINE configs[1]: the oracle's 24-h rollout (4 steps) at 721x1440 -- ~1 min of host time per step."""
+    """BASELINE configs[1]: the oracle's 24-h rollout (4 steps) at 721x1440 -- the committed golden vectors of it (tests/golden/full_pangu.npz:
+    lattice samples, whole-field maxima, cell means; tests/_golden_full.py), or, with SKYRIM_TEST_LIVE_ORACLE=1, the live host job (~1 min
+    of 128 threads per step, every grid point)."""
     import _oracle_jobs
-    return _oracle_jobs.PanguRollout()          # [k] = step k of O.rollout(params, x, 4); the job started in pytest_configure
+    if os.environ.get("SKYRIM_TEST_LIVE_ORACLE") == "1":
+        return _oracle_jobs.PanguRollout()      # [k] = step k of O.rollout(params, x, 4); the job started in pytest_configure
+    from _golden_full import FullSizeGolden
+    return FullSizeGolden("pangu")
+
+
+def full_err(ref, k, y):
+    """max over channels of SURVEY 8(d)'s per-channel error of engine state ``y`` against step k of the oracle's rollout.  Golden vectors: the
+    lattice points' figure, with the cell means of the WHOLE field held to the same tolerance by the caller (second value)."""
+    if hasattr(ref, "errors"):
+        e = ref.errors(k, y)
+        return float(e["rel"].max()), float(e["cell"].max())
+    return O.per_channel_rel_err(y.cpu(), ref[k]).max().item(), 0.0
 
 
 @pytest.mark.timeout(1500)
@@ -214,11 +228,12 @@ def test_full_size_step_vs_oracle(full, full_ref):
     """The headline configuration against the CPU oracle, per channel (the north star's 1e-3 bar)."""
     g, params, x, e = full
     y = e.step(x.cuda())
-    err = O.per_channel_rel_err(y.cpu(), full_ref[0])
+    err, cell = full_err(full_ref, 0, y)
     assert torch.isfinite(y).all()
-    print(f"full-size step: max per-channel rel err {err.max().item():.3e} ({DEFAULT_PRECISION})")
-    assert err.max().item() < 1e-3, err
-    assert err.max().item() < DEF_TOL, err       # what the default mode is asserted to deliver (two-term plan: ~5e-4)
+    print(f"full-size step: max per-channel rel err {err:.3e}, cell means {cell:.3e} ({DEFAULT_PRECISION}; plan {e.term_plan_in_effect:#05x}, guard {e.guard_report})")
+    assert e.term_plan_in_effect == 0x66F and e.guard_report[0][1] < 5e-4, e.guard_report      # the load-time guard kept the default plan at full size
+    assert err < 1e-3 and cell < 1e-3, (err, cell)
+    assert err < DEF_TOL and cell < DEF_TOL, (err, cell)       # what the default mode is asserted to deliver
 
 
 @pytest.mark.timeout(1500)
@@ -230,10 +245,11 @@ def test_full_size_24h_rollout_vs_oracle(full, full_ref):
     errs = []
     for k in range(4):
         e.step(state, out=state)                # in place, as bench.py times it
-        errs.append(O.per_channel_rel_err(state.cpu(), full_ref[k]).max().item())
+        errs.append(full_err(full_ref, k, state))
     assert torch.isfinite(state).all()
-    print("full-size 24-h rollout: max per-channel rel err per step " + " ".join(f"{e:.3e}" for e in errs) + f" ({DEFAULT_PRECISION})")
-    assert max(errs) < DEF_TOL, errs
+    print("full-size 24-h rollout: max per-channel rel err per step " + " ".join(f"{a:.3e}" for a, _ in errs) + "; cell means " +
+          " ".join(f"{c:.3e}" for _, c in errs) + f" ({DEFAULT_PRECISION})")
+    assert max(max(a, c) for a, c in errs) < DEF_TOL, errs
 
 
 @pytest.mark.timeout(1500)
@@ -256,7 +272,7 @@ def test_full_size_term_plans_vs_oracle(full, full_ref):
         errs = []
         for k in range(4):
             e.step(state, out=state)
-            errs.append(O.per_channel_rel_err(state.cpu(), full_ref[k]).max().item())
+            errs.append(max(full_err(full_ref, k, state)))
         print(f"full-size term plan {plan:#04x} calibration {cal} rounding {rounding}: max per-channel rel err per step " + " ".join(f"{v:.3e}" for v in errs))
         assert max(errs) < bound, (hex(plan), cal, rounding, errs)
         del e
@@ -276,10 +292,6 @@ def test_full_size_longitude_shift_equivariance_and_fp16_mode(full):
     y2 = e2.step(torch.roll(x, 480, dims=-1).cuda())
     assert O.per_channel_rel_err(torch.roll(y2, -480, dims=-1).cpu(), y.cpu()).max().item() < 2 * DEF_TOL
     del e2
-    e3 = PanguEngine(g, "f16", "cuda:0")
-    e3.load_params(params)
-    y3 = e3.step(x.cuda())
-    assert O.per_channel_rel_err(y3.cpu(), y.cpu()).max().item() < 5e-3
 
 
 # --------------------------------------------------------------------------------------------- #

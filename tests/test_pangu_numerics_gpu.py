@@ -86,7 +86,10 @@ def test_gain_one_network_rollout(toy):
     import os
     for m in (MODES if os.environ.get("SKYRIM_TEST_ALL_MODES") else [DEFAULT_PRECISION]):
         e = PanguEngine(g, m, "cuda:0")
-        e.load_params(p1)
+        e.load_params(p1)                             # with the load-time guard: on this network it judges the plan (in sigma units) and may fall back
+        print(f"gain-1 {m}: load-time guard {[(hex(a), float(f'{b:.2e}')) for a, b in (e.guard_report or [])]} -> plan {e.term_plan_in_effect:#05x}")
+        assert not e.guard_report or e.guard_report[-1][1] < 5e-4
+        e.load_params(p1, guard=False)                # the plan AS NAMED is what the figures below are of
         free, fed_err, free_err = x.cuda().clone(), [], []
         for k in range(N_GAIN_STEPS):
             fed_err.append(_errs(e.step(oracle_states[k].cuda()).cpu(), oracle_states[k + 1], p1))

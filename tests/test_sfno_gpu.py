@@ -264,11 +264,42 @@ def test_full_size_step_vs_oracle_per_channel():
     eng.load_params(params)
     y = eng.step(x.cuda())
     y2 = eng.step(y)
-    import _oracle_jobs
-    ref = _oracle_jobs.fetch("sfno_full_step")["ref"]                # = O.forward(params, x, cfg), started when collection finished
-    err = O.per_channel_rel_err(y.cpu(), ref)
     assert torch.isfinite(y).all() and torch.isfinite(y2).all()
-    assert err.max().item() < 1e-4, err           # bar 1e-3; the 3-term GEMMs deliver ~1e-6 .. 1e-5
+    import os
+    if os.environ.get("SKYRIM_TEST_LIVE_ORACLE") == "1":             # every grid point, against the live host job (~2 min of 128 threads)
+        import _oracle_jobs
+        ref = _oracle_jobs.fetch("sfno_full_step")["ref"]            # = O.forward(params, x, cfg), started when collection finished
+        err = O.per_channel_rel_err(y.cpu(), ref)
+        assert err.max().item() < 1e-4, err       # bar 1e-3; the 3-term GEMMs deliver ~1e-6 .. 1e-5
+        return
+    from _golden_full import FullSizeGolden
+    e = FullSizeGolden("sfno").errors(0, y)
+    print(f"sfno full-size step: max per-channel rel err {e['rel'].max():.3e} (lattice points), cell means {e['cell'].max():.3e}")
+    assert e["rel"].max() < 1e-4 and e["cell"].max() < 1e-4, e
+
+
+@pytest.mark.timeout(1500)
+def test_full_size_24h_rollout_vs_oracle():
+    """configs[2] at its REAL size over several steps (multi-step parity existed for Pangu only): 4 autoregressive 6-h steps at
+    721x1440x73, engine and oracle each feeding their own output back, against the committed golden vectors of the oracle's rollout
+    (tests/golden/full_sfno.npz) -- per channel on the lattice points and on the cell means of the whole field, at every step.  A random-weight
+    SFNO amplifies perturbations (~1.6x per step, measured on the small grid below), so the bound loosens with the step: 1e-4 x 2^k, inside 1e-3."""
+    from skyrim_amd.sfno.engine import SfnoEngine
+    from _golden_full import FullSizeGolden
+    gold = FullSizeGolden("sfno")
+    cfg = SfnoConfig()
+    params, x = init_synthetic(cfg, 0), synthetic_state(cfg, 0)
+    eng = SfnoEngine(cfg, "cuda:0")
+    eng.load_params(params)
+    state, errs = x.cuda().clone(), []
+    for k in range(gold.steps):
+        state = eng.step(state)
+        e = gold.errors(k, state)
+        errs.append((float(e["rel"].max()), float(e["cell"].max())))
+    print("sfno full-size rollout: max per-channel rel err per step " + " ".join(f"{a:.3e}" for a, _ in errs) + "; cell means " + " ".join(f"{c:.3e}" for _, c in errs))
+    assert torch.isfinite(state).all() and gold.steps >= 4
+    for k, (a, c) in enumerate(errs):
+        assert max(a, c) < min(1e-3, 1e-4 * 2 ** k), (k, errs)
 
 
 @pytest.mark.timeout(1500)

@@ -87,7 +87,7 @@ def run(prec, g, params, x):
     eng = PanguEngine(g, prec)
     eng.load_params(params)
     dev = eng.device
-    npl = 1 if prec == "f16" else 2
+    npl = 2
     t16 = torch.bfloat16 if prec.startswith("bf16x3") else torch.float16
     hnpl, ht16 = (1, torch.float16) if prec.endswith("h") else (npl, t16)
 
@@ -168,7 +168,7 @@ if __name__ == "__main__":
     g = PanguGeometry(nlat, nlon)
     params = init_synthetic(g, 0)
     x = synthetic_state(g, 0)
-    for prec in (sys.argv[3:] or ["bf16x3", "f16x3q", "f16"]):
+    for prec in (sys.argv[3:] or ["bf16x3", "f16x3q"]):
         try:
             run(prec, g, params, x)
         except Exception:
