@@ -85,7 +85,7 @@ def toy_parity(precision, rounding="default"):
             "max_sigma_err": O.per_channel_sigma_err(y, ref, p["norm.std"]).max().item()}     # the same difference in units of the channel's sigma
 
 
-PROFILE_ROUND = "r05"
+PROFILE_ROUND = "r06"
 
 
 def lib_sha16(model: str) -> str | None:

@@ -332,13 +332,20 @@ qkv_attention_kernel(const QkvAttnArgs a) {
             const f16* src = a.wf + ((long long)(which * a.heads + head) * S::BLK_KIB << 9) + lane * 8;
             for (int p = wave; p < S::BLK_KIB; p += S::NWAVES) glds16(src + (p << 9), lds_base + (unsigned)((which * S::BLK_KIB + p) << 10));
         }
+        // the compact bias table -> its four shifted LDS copies: all of a thread's entries are requested first, then written (the loop form
+        // of earth_attention2_kernel pays one L2 round trip per entry: seven in a row here, per workgroup, with nothing else resident on the CU)
         const f16* src = a.bias_cmp + (long long)th * 3456;
-        for (int i = tid; i < 3456; i += S::THREADS) {
-            const int r = i / 24, e = i - 24 * r;
-            const f16 v = src[i];
-            if (e < 23) {
+        constexpr int NT = (3456 + S::THREADS - 1) / S::THREADS;
+        f16 tv[NT];
 #pragma unroll
-                for (int c = 0; c < 4; ++c) tabs[c * BT_COPY + r * BT_ROW + e + c] = v;
+        for (int j = 0; j < NT; ++j) { const int i = tid + j * S::THREADS; tv[j] = src[i < 3456 ? i : 0]; }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int i = tid + j * S::THREADS;
+            const int r = i / 24, e = i - 24 * r;
+            if (i < 3456 && e < 23) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) tabs[c * BT_COPY + r * BT_ROW + e + c] = tv[j];
             }
         }
         if (tid < 96) qb[tid] = a.bias[(tid >> 5) * C + head * HEAD_DIM + (tid & 31)];
@@ -350,6 +357,16 @@ qkv_attention_kernel(const QkvAttnArgs a) {
         const int zk = k0 / 72, hk = (k0 / 12) % 6, wk0 = k0 % 12;
         koff[f] = 2 * ((2 * zk * 36 + 6 * hk) * BT_ROW + wk0);
     }
+    // the window table entries of a window's nine token fragments (9 dependent 4-byte gathers) are fetched ONE WINDOW AHEAD, under the attention
+    // loop (the first window's: under the weight fetch); a token-group triple's first two ring fetches are issued before the previous triple's
+    // conversions: what a triple waits for at its top is then one L2 round trip that has been in flight for a while, not three in a row
+    int srcn[9];
+    auto load_src = [&](int wi_) {
+        const int w_ = type * a.nW + wi_;
+#pragma unroll
+        for (int f = 0; f < 9; ++f) srcn[f] = a.widx[w_ * WIN_TOKENS + attn_key(f, l15)];
+    };
+    load_src(wave < a.nW ? wave : 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     const char* tb = reinterpret_cast<const char*>(tabs);
@@ -359,16 +376,6 @@ qkv_attention_kernel(const QkvAttnArgs a) {
     // (a lane's share of the biases -- q / k dims 8g + [0..7]; v: the dim of column l15 in fragment df -- is read from LDS where it is used:
     // 18 registers held across the loops were 18 registers spilled)
 
-    // the window table entries of a window's nine token fragments (9 dependent 4-byte gathers) are fetched ONE WINDOW AHEAD, under the attention
-    // loop; a token-group triple's first two ring fetches are issued before the previous triple's conversions: what a triple waits for at its
-    // top is then one L2 round trip that has been in flight for a while, not three in a row
-    int srcn[9];
-    auto load_src = [&](int wi_) {
-        const int w_ = type * a.nW + wi_;
-#pragma unroll
-        for (int f = 0; f < 9; ++f) srcn[f] = a.widx[w_ * WIN_TOKENS + attn_key(f, l15)];
-    };
-    load_src(wave < a.nW ? wave : 0);
     for (int wi = wave; wi < a.nW; wi += S::NWAVES) {
         const int win = type * a.nW + wi;
         int src[9];

@@ -183,7 +183,11 @@ def test_profile_hooks_cover_the_step(eng, toy):
     by = {s["name"]: s for s in stats}
     # 3-term modes: projection + MLP as one kernel per block (fused_block.hip); the others: proj, fc1, fc2 as separate launches
     mlp = "proj_mlp_r1"
-    assert by[mlp]["launches"] == 12 and by["qkv_r0"]["launches"] == 4 and by["embed"]["launches"] == 1
+    assert by[mlp]["launches"] == 12 and by["attn_r0"]["launches"] == 4 and by["attn_r1"]["launches"] == 12 and by["embed"]["launches"] == 1
+    # round 6: QKV runs inside the attention launch wherever the head's weights fit LDS beside the bias copies -- every layer of the default plan
+    # (one weight plane at C = 384), the C = 192 layers of the hi / lo plans
+    want_qkv = (0, 0) if eng.precision == DEFAULT_PRECISION else (0, 12)
+    assert (by["qkv_r0"]["launches"], by["qkv_r1"]["launches"]) == want_qkv, (eng.precision, by["qkv_r0"], by["qkv_r1"])
     assert by["fc2_r1"]["launches"] == by["proj_r1"]["launches"] == (0 if mlp == "proj_mlp_r1" else 12)
     assert all(s["total_ms"] > 0 for s in stats if s["launches"])
 

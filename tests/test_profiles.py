@@ -193,3 +193,57 @@ def test_r05_default_mode_dominant_kernel_and_graphcast_fraction():
     # frac = the published network's FLOPs of the dominant stage / its time / 2.5 PF; the term-weighted figure has its own name
     assert abs(gr["alg_flops_per_step_of_stage"] / (gr["stage_ms_per_step"] * 1e-3) / 2.5e15 - gr["frac"]) < 1e-6
     assert gr["frac_executed"] < gr["frac"] < gr["mfma_busy_equiv"] and g["ms_per_step"] < 56.0
+
+
+# ---- round 6 (profiles/r06_*): QKV + attention as one kernel, the term plan and its guard in the line -------------------------------------- #
+def _r06(name):
+    f = PROFILES / name
+    if not f.exists():
+        pytest.skip(f"{name}: written by tools/final_profiles.sh (PROFILE_ROUND=r06) as the round's last GPU call")
+    return f
+
+
+R6_KERNELS = {"pangu": ["proj_mlp2_kernel", "qkv_attention_kernel"], "sfno": ["sfno_chain_kernel", "gemm_strided_kernel"],
+              "graphcast": ["edge_update_kernel<true, 2, 1>", "node_mlp_kernel<2>", "gemm_strided_kernel_s"]}
+
+
+@pytest.mark.parametrize("model", ["pangu", "sfno", "graphcast"])
+def test_r06_bench_line_and_counter_summary(model):
+    d = json.loads(_r06(f"r06_bench_{model}.json").read_text())
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+                "roofline", "cpu_baseline", "parity"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["vs_baseline"] is None and d["data"] == "synthetic" and "721x1440" in d["config"]["workload"]
+    assert abs(d["value"] * d["ms_per_step"] / 1e3 - 1.0) < 1e-6
+    r = d["roofline"]
+    assert r["bound"] == {"pangu": "mfma", "sfno": "hbm", "graphcast": "mfma"}[model]
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0 < r["frac"] < 1 and r["traffic"] > 0
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0 and d["parity"]["max_rel_err"] < 3.5e-4
+    p = json.loads(_r06(f"r06_{model}_pmc.json").read_text())
+    assert p["total"]["scope"] == "the bench's own steps" and f"libskyrim_{model}.so" in p["stamp"]
+    names, stats = " ".join(p["kernels"]), _r06(f"r06_{model}_kernel_stats.csv").read_text()
+    for k in R6_KERNELS[model]:
+        assert k in names and k in stats, k
+
+
+def test_r06_pangu_line_names_its_plan_and_the_attention_is_one_launch():
+    """The line says which MFMA term plan the timed steps ran with and what the load-time guard measured for it; q / k / v no longer exist in
+    HBM: no QKV kernel and no separate attention kernel in the trace of the default mode, 57 launches per step instead of 73."""
+    text = _r06("r06_bench_pangu_line.json").read_text().strip().splitlines()[-1]
+    assert len(text) <= 3000
+    line, full = json.loads(text), json.loads(_r06("r06_bench_pangu.json").read_text())
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"):
+        assert line[key] == full[key], key
+    cfg = line["config"]
+    assert cfg["term_plan"] == "0x66f" and cfg["guard"] and cfg["guard"][-1][0] == "0x66f" and cfg["guard"][-1][1] < 5e-4, cfg
+    assert line["ms_per_step"] < 15.8                                                         # round 5: 16.0 - 16.3
+    assert line["parity"]["full_size"]["max_rel_err"] < 3.5e-4
+    r = line["roofline"]
+    assert r["kernel"] == "proj_mlp_r1" and abs(r["alg_flops_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 2.5e15 - r["frac"]) < 1e-6
+    st = full["roofline"]["stages"]
+    assert "qkv_r0" not in st and "qkv_r1" not in st and st["attn_r1"]["launches_per_step"] == 12 and st["attn_r0"]["launches_per_step"] == 4
+    assert st["attn_r1"]["ms_per_launch"] < 0.25 and st["attn_r0"]["ms_per_launch"] < 0.44       # two launches, round 5: 0.165 + 0.108, 0.271 + 0.236
+    stats = _r06("r06_pangu_kernel_stats.csv").read_text()
+    assert "rt_qkv_kernel" not in stats and "earth_attention2_kernel" not in stats
+    for m in ("sfno", "graphcast"):
+        assert 0 < line["models"][m]["roofline"]["frac"] < 1

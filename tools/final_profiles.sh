@@ -6,7 +6,7 @@
 set -u
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
-R=${PROFILE_ROUND:-r05}
+R=${PROFILE_ROUND:-r06}
 O=gpurun_out/final
 mkdir -p $O profiles
 MODELS=${*:-pangu sfno graphcast}
@@ -15,7 +15,8 @@ for m in $MODELS; do
   lib=skyrim_amd/lib/libskyrim_$m.so
   stamp="$(sha256sum $lib | cut -c1-16) $(basename $lib), $(date -u +%Y-%m-%dT%H:%MZ), src $(python -c 'import bench; print(bench.src_sha16())')"
   rm -rf $O/stats_$m
-  SKYRIM_BENCH_FULL_LINE=1 SKYRIM_PANGU_CALIBRATION=off timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$m -o p -- python bench.py $extra --steps 5 --warmup 2 --no-cpu-baseline --no-parity --no-alt-modes --no-models > $O/stats_$m.log 2>&1
+  # (calibration off: its one-time launches stay out of the trace; guard off: it would judge -- and replace -- the uncalibrated plan)
+  SKYRIM_BENCH_FULL_LINE=1 SKYRIM_PANGU_CALIBRATION=off SKYRIM_PANGU_GUARD=off timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$m -o p -- python bench.py $extra --steps 5 --warmup 2 --no-cpu-baseline --no-parity --no-alt-modes --no-models > $O/stats_$m.log 2>&1
   echo "stats $m rc=$?"
   cp $(ls $O/stats_$m/*/p_kernel_stats.csv $O/stats_$m/p_kernel_stats.csv 2>/dev/null | head -1) $O/${R}_${m}_kernel_stats.csv 2>/dev/null
   bash tools/pmc_collect.sh $m $extra

@@ -8,6 +8,7 @@ tag=$1; shift
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 export SKYRIM_PANGU_CALIBRATION=off   # the one-time calibration launches (PanguEngine.load_params) stay out of the per-step totals; timings do not depend on it
+export SKYRIM_PANGU_GUARD=off         # ... and so do the load-time guard's (it would also replace the uncalibrated plan by three terms)
 run() {   # <pass name> <counters...> --
   local name=$1; shift
   local ctrs=()
