@@ -308,7 +308,7 @@ struct QkvAttnArgs {
     const f16* bias_cmp;           // compact earth-specific bias tables (+ mask), [type][head][144][24]
     const f16* zrow;               // zeros: the row of a padding token
     f16* out; long long out_plane; // attention output, window-ordered rows, blocked layout
-    int nW, heads;
+    int nW, heads, types;
     float scale;
 };
 
@@ -323,8 +323,15 @@ qkv_attention_kernel(const QkvAttnArgs a) {
     float* qb = reinterpret_cast<float*>(smem + S::W_BYTES + S::TAB_BYTES);
     const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int th = blockIdx.x;
-    const int head = th % a.heads, type = th / a.heads;
+    // Workgroup -> (window type, head), XCD-aware.  The `heads` workgroups of a type read the SAME stream rows (the type's nW windows); workgroups
+    // go to the 8 XCDs round-robin in launch order, each XCD with its own L2.  With the plain map (type major, head minor) the heads of a type
+    // landed on different XCDs and every L2 fetched the rows for itself: 0.94 GB fetched per launch at C = 384 for a 0.1 GB operand, the kernel
+    // running at 5.4 TB/s of fabric traffic (profiles/r06_pangu_pmc.json, first take).  Here XCD x owns the types x, x + 8, ...: block b -> XCD
+    // b & 7, slot b >> 3 = (type index on that XCD) * heads + head, so a type's heads run side by side on ONE L2.
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int head = slot % a.heads, type = xcd + 8 * (slot / a.heads);
+    if (type >= a.types) return;                                 // (the XCDs with one type fewer: whole workgroups, before any barrier)
+    const int th = type * a.heads + head;
     {   // the head's three weight blocks -> LDS, piece p of a block by wave p % 8
         const unsigned lds_base = (unsigned)(size_t)smem;
 #pragma unroll
@@ -510,12 +517,12 @@ static hipError_t launch_qa(const QkvAttnArgs& a, int types, int out_planes, hip
         auto kern = qkv_attention_kernel<S, 1>;
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, S::SMEM);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(kern, dim3((unsigned)(types * a.heads)), dim3(S::THREADS), S::SMEM, stream, a);
+        hipLaunchKernelGGL(kern, dim3((unsigned)(8 * ((types + 7) / 8) * a.heads)), dim3(S::THREADS), S::SMEM, stream, a);
     } else {
         auto kern = qkv_attention_kernel<S, 2>;
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, S::SMEM);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(kern, dim3((unsigned)(types * a.heads)), dim3(S::THREADS), S::SMEM, stream, a);
+        hipLaunchKernelGGL(kern, dim3((unsigned)(8 * ((types + 7) / 8) * a.heads)), dim3(S::THREADS), S::SMEM, stream, a);
     }
     return hipGetLastError();
 }
@@ -524,7 +531,7 @@ static hipError_t launch_qa(const QkvAttnArgs& a, int types, int out_planes, hip
 hipError_t op_qkv_attention(const Geom& g, const BlockW<f16>& b, const int* widx, int res, const f16* Xs, const Work<PrecF16x3>& wk, hipStream_t s, int out_planes) {
     if (!b.bias_cmp || !(b.qkvh || b.qkvf)) return hipErrorInvalidValue;
     const int heads = res == 0 ? 6 : 12;
-    QkvAttnArgs a{Xs, widx, b.qkvh ? b.qkvh : b.qkvf, b.qkv_b, b.bias_cmp, wk.zrow, wk.ao, wk.ao_plane, g.nW[res], heads, 0.17677669529663687f};
+    QkvAttnArgs a{Xs, widx, b.qkvh ? b.qkvh : b.qkvf, b.qkv_b, b.bias_cmp, wk.zrow, wk.ao, wk.ao_plane, g.nW[res], heads, g.types[res], 0.17677669529663687f};
     if (b.qkvh) return res == 0 ? launch_qa<QaShape<192, 1>>(a, g.types[res], out_planes, s) : launch_qa<QaShape<384, 1>>(a, g.types[res], out_planes, s);
     if (res != 0) return hipErrorNotSupported;             // C = 384 with hi / lo weights: 144 KiB of weights + the bias copies do not fit one CU's LDS
     return launch_qa<QaShape<192, 2>>(a, g.types[res], out_planes, s);

@@ -48,6 +48,13 @@ struct GemmArgs {
 template <class AL, class = void> struct al_uniform_k_t { static constexpr bool value = false; };
 template <class AL> struct al_uniform_k_t<AL, decltype((void)AL::kUniformK)> { static constexpr bool value = AL::kUniformK; };
 template <class AL> constexpr bool al_uniform_k_v = al_uniform_k_t<AL>::value;
+// loaders whose ROWS are the contiguous index in memory (k strided) declare  static constexpr bool kRowsFirst = true : the staging threads
+// are then laid out rows-first (a wave = 64 consecutive rows of ONE 8-wide k chunk), so that each of a thread's 8 scalar loads is, across the
+// wave, one contiguous 256-byte segment; with the default k-first layout (4 k chunks x 16 rows per wave) the same load touches four
+// 64-byte segments of four different k rows -- half cache lines, four times the requests
+template <class AL, class = void> struct al_rows_first_t { static constexpr bool value = false; };
+template <class AL> struct al_rows_first_t<AL, decltype((void)AL::kRowsFirst)> { static constexpr bool value = AL::kRowsFirst; };
+template <class AL> constexpr bool al_rows_first_v = al_rows_first_t<AL>::value;
 
 template <class P, class TC>
 constexpr int gemm_smem_bytes() { return (P::NA * TC::BM + P::NW * TC::BN) * TC::BK * 2; }
@@ -69,11 +76,15 @@ __device__ __forceinline__ void gemm_body(const GemmArgs<P, AL, EP>& g, char* sm
 
     const int st_slot = tid % CPR;          // this thread's 16-byte slot within a tile row
     const int st_row = tid / CPR;           // first tile row it stages
+    // the A operand's own thread layout (rows-first loaders, one chunk per thread: see al_rows_first_t); W keeps the k-first one
+    constexpr bool A_ROWS_FIRST = al_rows_first_v<AL> && TC::A_CHUNKS == 1 && THREADS == BM * CPR;
+    const int a_slot = A_ROWS_FIRST ? tid / BM : st_slot;
+    const int a_row = A_ROWS_FIRST ? tid % BM : st_row;
 
     typename AL::Row arow[TC::A_CHUNKS];
 #pragma unroll
     for (int i = 0; i < TC::A_CHUNKS; ++i) {
-        const int r = st_row + i * ROWS_PER_PASS;
+        const int r = a_row + i * ROWS_PER_PASS;
         arow[i] = g.al.row(m0 + (r < BM ? r : 0));
     }
     const T* wrow[TC::W_CHUNKS];
@@ -97,9 +108,9 @@ __device__ __forceinline__ void gemm_body(const GemmArgs<P, AL, EP>& g, char* sm
         const int k = kt * BK + st_slot * 8;
 #pragma unroll
         for (int i = 0; i < TC::A_CHUNKS; ++i) {
-            if (TC::A_CHUNKS * ROWS_PER_PASS == BM || st_row + i * ROWS_PER_PASS < BM) {
-                if constexpr (al_uniform_k_v<AL>) g.al.issue2(arow[i], kt * BK, st_slot * 8, BK, araw[i]);     // uniform base + per-thread offset
-                else g.al.issue(arow[i], k, araw[i]);
+            if (TC::A_CHUNKS * ROWS_PER_PASS == BM || a_row + i * ROWS_PER_PASS < BM) {
+                if constexpr (al_uniform_k_v<AL>) g.al.issue2(arow[i], kt * BK, a_slot * 8, BK, araw[i]);     // uniform base + per-thread offset
+                else g.al.issue(arow[i], kt * BK + a_slot * 8, araw[i]);
             }
         }
 #pragma unroll
@@ -113,7 +124,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs<P, AL, EP>& g, char* sm
     auto stage_tile = [&]() {
 #pragma unroll
         for (int i = 0; i < TC::A_CHUNKS; ++i) {
-            const int r = st_row + i * ROWS_PER_PASS;
+            const int r = a_row + i * ROWS_PER_PASS;
             if (TC::A_CHUNKS * ROWS_PER_PASS == BM || r < BM) {
                 uint4 o[NA];
                 if constexpr (AL::kDirect) {
@@ -124,7 +135,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs<P, AL, EP>& g, char* sm
                     split8<T, NA>(v, o);
                 }
 #pragma unroll
-                for (int p = 0; p < NA; ++p) *reinterpret_cast<uint4*>(As + p * A_PLANE + lds_off<BK>(r, st_slot)) = o[p];
+                for (int p = 0; p < NA; ++p) *reinterpret_cast<uint4*>(As + p * A_PLANE + lds_off<BK>(r, a_slot)) = o[p];
             }
         }
 #pragma unroll

@@ -67,6 +67,9 @@ struct ALStrided {
 template <bool VEC>
 struct ALFast {
     static constexpr bool kDirect = false, kUniformK = true;
+    // k strided (VEC = false): in every use of this loader the ROWS are the contiguous index (pixels of an NCHW activation, latitudes of a
+    // spectrum: a_sm == 1) -- stage rows-first (gemm.h: al_rows_first_t); harmless where they are not
+    static constexpr bool kRowsFirst = !VEC;
     const float* a;
     int M, K, m1;
     long long sm, sm2, sk;

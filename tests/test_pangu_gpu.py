@@ -844,6 +844,36 @@ def test_load_time_guard_never_applies_the_default_plan_blind(toy, ref):
     e.release()
 
 
+@pytest.mark.parametrize("precision", [DEFAULT_PRECISION, "f16x2m", "f16x3q"])
+def test_fused_qkv_attention_is_bit_identical_to_the_two_launches(toy, monkeypatch, precision):
+    """Round 6: QKV + window attention as ONE kernel (csrc/attention.hip: qkv_attention_kernel; q / k / v stay in registers) against the
+    QKV launch + attention launch it replaces (SKP_SPLIT_ATTN=1 at engine construction): the same products in the same order, so the same
+    BITS -- on the toy grid, whose windows carry padding rows and the shifted-window mask, in the default plan (one weight plane in the coarse
+    layers, hi / lo in layers 1 / 4), the two-term plan, and three terms (where only the C = 192 layers fuse: hi / lo planes at C = 384 do not fit
+    LDS beside the bias copies).  The per-stage profile shows which form ran."""
+    from skyrim_amd.pangu.engine import PanguEngine
+    g, params, x = toy
+    outs, launches = {}, {}
+    for split in (True, False):
+        if split:
+            monkeypatch.setenv("SKP_SPLIT_ATTN", "1")
+        else:
+            monkeypatch.delenv("SKP_SPLIT_ATTN", raising=False)
+        e = PanguEngine(g, precision, "cuda:0")
+        e.load_params(params, guard=False)
+        e.profile(True)
+        outs[split] = e.step(x.cuda())
+        launches[split] = {s_["name"]: s_["launches"] for s_ in e.profile_read()}
+        e.profile(False)
+        y2 = e.step(outs[split])                       # and a second step on its own output
+        outs[split] = (outs[split].cpu(), y2.cpu())
+        e.release()
+    assert launches[True]["qkv_r0"] == 4 and launches[True]["qkv_r1"] == 12
+    assert launches[False]["qkv_r0"] == 0 and launches[False]["qkv_r1"] == (12 if precision == "f16x3q" else 0)
+    assert launches[False]["attn_r0"] == 4 and launches[False]["attn_r1"] == 12
+    assert torch.equal(outs[True][0], outs[False][0]) and torch.equal(outs[True][1], outs[False][1])
+
+
 def test_step_as_a_captured_hip_graph(toy):
     """One in-place step captured as a HIP graph (72 launches -> one replay): same bits as the eager step, replayable."""
     from skyrim_amd.pangu.engine import PanguEngine
