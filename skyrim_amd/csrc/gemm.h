@@ -77,9 +77,10 @@ __device__ __forceinline__ void gemm_body(const GemmArgs<P, AL, EP>& g, char* sm
     const int st_slot = tid % CPR;          // this thread's 16-byte slot within a tile row
     const int st_row = tid / CPR;           // first tile row it stages
     // the A operand's own thread layout (rows-first loaders, one chunk per thread: see al_rows_first_t); W keeps the k-first one
-    constexpr bool A_ROWS_FIRST = al_rows_first_v<AL> && TC::A_CHUNKS == 1 && THREADS == BM * CPR;
-    const int a_slot = A_ROWS_FIRST ? tid / BM : st_slot;
-    const int a_row = A_ROWS_FIRST ? tid % BM : st_row;
+    bool rows_first = false;                  // (wave-uniform; the loader decides from its strides: ALFast<false> always, ALStrided when k is strided)
+    if constexpr (al_rows_first_v<AL> && TC::A_CHUNKS == 1 && THREADS == BM * CPR) rows_first = g.al.rows_first();
+    const int a_slot = rows_first ? tid / BM : st_slot;
+    const int a_row = rows_first ? tid % BM : st_row;
 
     typename AL::Row arow[TC::A_CHUNKS];
 #pragma unroll

@@ -14,6 +14,10 @@ namespace skp {
 // ---- A operand: fp32, strided ------------------------------------------------------------------ //
 struct ALStrided {
     static constexpr bool kDirect = false;
+    // rows contiguous and k strided (an NCHW activation read pixel-major: GraphCast's embedding, the un-fused SFNO encoder / decoder): stage
+    // rows-first, like ALFast<false> (gemm.h: al_rows_first_t); decided per launch from the strides
+    static constexpr bool kRowsFirst = true;
+    __device__ __forceinline__ bool rows_first() const { return sm == 1 && sk != 1 && (a2 == nullptr || sk2 != 1); }
     const float* a;
     int M, K, m1;                 // row m -> (m / m1) * sm2 + (m % m1) * sm
     long long sm, sm2, sk;
@@ -70,6 +74,7 @@ struct ALFast {
     // k strided (VEC = false): in every use of this loader the ROWS are the contiguous index (pixels of an NCHW activation, latitudes of a
     // spectrum: a_sm == 1) -- stage rows-first (gemm.h: al_rows_first_t); harmless where they are not
     static constexpr bool kRowsFirst = !VEC;
+    __device__ __forceinline__ bool rows_first() const { return true; }
     const float* a;
     int M, K, m1;
     long long sm, sm2, sk;
