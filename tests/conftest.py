@@ -17,6 +17,11 @@ os.environ.setdefault("SKYRIM_SYNTHETIC_WEIGHTS", "1")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # The oracles the tests call in-process work on SMALL grids (49x192, 97x192, 33x64 ...): on the GPU box's 128 host threads their PyTorch-CPU
+    # ops are slower than on 8 (measured: the SFNO 40-step rollout test 72 s with 128 threads, 9 s with 32, 4.5 s with 8 -- thread fan-out per tiny
+    # tensor op).  The full-size oracle runs are separate processes with their own thread counts (tests/_oracle_jobs.py, tests/golden/make_full_size.py).
+    import torch
+    torch.set_num_threads(min(8, os.cpu_count() or 8))
     # a GPU run: the full-size oracle jobs start NOW (tests/_oracle_jobs.py; Pangu's rollout, the longest, first) -- they compute in host
     # processes while pytest collects and the small-grid parity tests run
     expr = getattr(config.option, "markexpr", "") or ""
