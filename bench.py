@@ -57,16 +57,23 @@ def cpu_baseline(params, geom, x, keep=None):
     """CPU restatement (oracle/, kind 'port') timed on this box's host cores: ONE full step of the same workload, no scaling.
     ``keep`` (a dict): receives the step's output under "y" -- the full-size parity figure of the line is read against it."""
     from oracle import pangu_oracle as O
-    cores = torch.get_num_threads()
-    t0 = time.time()
-    with torch.no_grad():
-        y = O.forward(params, x)
-    dt = time.time() - t0
+    # the thread count the restatement is FASTEST with, not the largest available: measured on the 128-thread GPU box (tools/cpu_scale.py) one
+    # full-size step takes 62.5 s on 128 threads, 44.6 on 64, 42.8 on 32, 43.3 on 16 -- the baseline runs on 32 (SKYRIM_BENCH_CPU_THREADS overrides)
+    have = torch.get_num_threads()
+    cores = int(os.environ.get("SKYRIM_BENCH_CPU_THREADS", 0)) or min(32, have)
+    torch.set_num_threads(cores)
+    try:
+        t0 = time.time()
+        with torch.no_grad():
+            y = O.forward(params, x)
+        dt = time.time() - t0
+    finally:
+        torch.set_num_threads(have)
     if keep is not None:
         keep["y"] = y
     return {"value": 1.0 / dt, "unit": "steps/s", "cores": cores, "kind": "port",
             "sample": f"ONE full {geom.n_lat}x{geom.n_lon} 6-h step of the PyTorch-CPU fp32 restatement (oracle/pangu_oracle.py) in {dt:.1f} s on {cores} "
-                      f"threads; no scaling; not the reference's ONNX graph (onnxruntime and the weights are not obtainable here); finite={bool(torch.isfinite(y).all())}",
+                      f"threads (of {have}: more are slower); no scaling; not the reference's ONNX graph (onnxruntime and the weights are not obtainable here); finite={bool(torch.isfinite(y).all())}",
             "s_per_step": dt}
 
 
