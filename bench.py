@@ -306,10 +306,28 @@ def predict_inclusive(precision, geom, params, dev, n_steps=8):
     base = "/dev/shm" if os.path.isdir("/dev/shm") else None
     out = {}
     pred, _ = m.rollout(t0, n_steps=3, save=False)                                                   # warm: IC, pinned buffers
+    from skyrim_amd.core.models.base import SAVE_WORKERS
+    in_flight = int(os.environ.get("SKYRIM_SAVE_WORKERS", SAVE_WORKERS)) + 3
     for save in (False, True):
         d = tempfile.mkdtemp(prefix="skyrim_bench_", dir=base)
         try:
-            pred, _ = m.rollout(t0, n_steps=2, save=save, save_config={"output_dir": d}, initial_condition=pred)      # warm the file system path
+            # Warm-up = the timed rollout itself, run once before: the pinned delivery buffers (one 573 MB block per prediction in flight,
+            # up to SAVE_WORKERS + 2 of them) and the memory the page cache takes for the files have then been touched once.  On a fresh
+            # VM the FIRST touch of guest memory is what a save rollout measures otherwise (~3 - 7 GB/s however many threads write,
+            # docs/experiments.md A6.5); its figure is kept as ``save_first_rollout``.  The warm-up's files are deleted before the timed run.
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            pred, paths = m.rollout(t0, n_steps=n_steps if save else 2, save=save, save_config={"output_dir": d}, initial_condition=pred)
+            pred.values
+            if save:
+                out["save_first_rollout"] = {"ms_per_step": 1e3 * (time.perf_counter() - t) / n_steps, "files": len(paths)}
+                for p in paths:
+                    os.unlink(p)
+                # ... and torch's pinned-block cache holds one block per prediction that can be in flight (the first rollout stalls on its
+                # own allocations, so it never has that many at once: tools/save_timeline.py shows a 45 - 90 ms hipHostMalloc inside a
+                # later rollout's step otherwise)
+                blocks = [torch.empty(tuple(pred.shape), dtype=torch.float32, pin_memory=True) for _ in range(in_flight)]
+                del blocks
             torch.cuda.synchronize()
             t = time.perf_counter()
             pred, paths = m.rollout(t0, n_steps=n_steps, save=save, save_config={"output_dir": d}, initial_condition=pred)
@@ -320,11 +338,15 @@ def predict_inclusive(precision, geom, params, dev, n_steps=8):
         finally:
             shutil.rmtree(d, ignore_errors=True)
     out["io_counters"] = dict(m.model.io_counters)
+    from skyrim_amd import deliver
+    out["big_endian_image"] = deliver.enabled()
     out["note"] = (f"GlobalModel.rollout(n_steps={n_steps}, initial_condition=<the previous prediction>) through the reference-shaped API: the state stays in "
-                   "HBM (io_counters: one upload, the initial condition of the warm-up); every step's (t, t + 6 h) pair copied to pinned host memory on a "
-                   "copy stream, the copy of step k running under step k + 1 (the delivered array waits for it when its numbers are read); "
-                   f"save: one netCDF-3 file of 573 MB per step ({'tmpfs' if base else 'tmp dir'}) written by the save threads (each converts its piece to big-endian "
-                   "and pwrites it; SKYRIM_NC_MMAP=1: straight into a mapping of the file) while the next steps run")
+                   "HBM (io_counters: one upload, the initial condition of the warm-up); no_save: every step's (t, t + 6 h) pair copied to pinned host memory "
+                   "on a copy stream, the copy of step k running under step k + 1 (the delivered array waits for it when its numbers are read); "
+                   f"save: one netCDF-3 file of 573 MB per step ({'tmpfs' if base else 'tmp dir'}); the pair is byte-swapped in HBM (skio_bswap32) and it is that "
+                   "big-endian image that crosses to pinned memory (intermediate steps: instead of the native copy; last step: both), so the save threads only "
+                   "pwrite while the next steps run (SKYRIM_SAVE_BE=0: native copy, swapped by the save threads). save = the second saving rollout of the "
+                   "process with torch's pinned-block cache holding a block per prediction in flight; save_first_rollout = the first one (it allocates them)")
     return out
 
 
@@ -873,7 +895,7 @@ def compact_line(out: dict) -> dict:
             line["models"][name]["roofline"]["kernel"] = str(line["models"][name]["roofline"].get("kernel", ""))[:60]
     for k in ("pcie_inclusive", "predict_inclusive"):
         if k in out and isinstance(out[k], dict):
-            line[k] = {kk: vv for kk, vv in out[k].items() if isinstance(vv, (int, float)) or (isinstance(vv, dict) and kk in ("save", "no_save"))}
+            line[k] = {kk: vv for kk, vv in out[k].items() if isinstance(vv, (int, float)) or (isinstance(vv, dict) and kk in ("save", "no_save", "save_first_rollout"))}
             line[k] = {kk: (keep(vv, ("ms_per_step",)) if isinstance(vv, dict) else vv) for kk, vv in line[k].items()}
     line["detail"] = "bench_detail.json"
     return line

@@ -91,7 +91,10 @@ class GlobalModel:
 
     def predict_one_step(self, start_time: datetime.datetime, initial_condition=None) -> DataArray:
         # if initial_condition is None, it is fetched from the self.ic_source
-        return run_basic_inference(model=self.model, n=1, data_source=self.data_source, time=start_time, x=initial_condition)
+        return self._predict_one_step(start_time, initial_condition, None)
+
+    def _predict_one_step(self, start_time, initial_condition, deliver) -> DataArray:
+        return run_basic_inference(model=self.model, n=1, data_source=self.data_source, time=start_time, x=initial_condition, deliver=deliver)
 
     def forecast(self, start_time: datetime.datetime, n_steps: int = 3, channels: List[str] = []):
         da = run_basic_inference(model=self.model, n=n_steps, data_source=self.data_source, time=start_time, x=None)
@@ -120,12 +123,22 @@ class GlobalModel:
         # user-supplied ``save_config["mapping_func"]`` runs on the save threads, several at once (SKYRIM_SAVE_WORKERS=1 restores one file
         # at a time, in step order); once a step's write has failed no further step is submitted, but writes already running finish.
         workers = 1
-        if save and (cfg.get("file_type") or "netcdf") == "netcdf" and "://" not in str(cfg.get("output_dir", "")):
+        netcdf_local = save and (cfg.get("file_type") or "netcdf") == "netcdf" and "://" not in str(cfg.get("output_dir", ""))
+        if netcdf_local:
             workers = max(1, int(os.environ.get("SKYRIM_SAVE_WORKERS", SAVE_WORKERS)))
         pool = ThreadPoolExecutor(max_workers=workers, thread_name_prefix="skyrim-save") if save else None
+        # netCDF-3 holds big-endian floats.  When the file is the prediction as delivered (no mapping_func, no channel filter) its bytes
+        # are produced in HBM and copied to the host as they will lie in the file (skyrim_amd/deliver.py): the save threads only pwrite.
+        # Intermediate steps bring ONLY that image over PCIe -- the next step reads the state from HBM, nobody reads their ``values``
+        # (which would be filled from the image on demand); the last step, returned to the caller, brings both.
+        image = netcdf_local and cfg.get("mapping_func") is None and not cfg.get("filter_vars") \
+            and type(self).predict_one_step is GlobalModel.predict_one_step
         try:
             for n in range(n_steps):
-                pred = self.predict_one_step(start_time, initial_condition=pred)
+                if image:
+                    pred = self._predict_one_step(start_time, pred, "be" if n < n_steps - 1 else "both")
+                else:
+                    pred = self.predict_one_step(start_time, initial_condition=pred)
                 pred_time = start_time + self.time_step
                 if save:
                     failed = next((f for f in pending if f.done() and f.exception() is not None), None)

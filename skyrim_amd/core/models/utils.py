@@ -42,8 +42,10 @@ class ResidentState:
         return torch.stack([t[0] if t.dim() == 4 else t for t in self.states[-n_hist:]], dim=0).unsqueeze(0)
 
 
-def run_basic_inference(model, n: int, data_source: Any, time: datetime, x=None):
-    """Run a basic inference: returns DataArray(time = n + 1, channel, lat, lon); entry 0 is the state at ``time``."""
+def run_basic_inference(model, n: int, data_source: Any, time: datetime, x=None, deliver: str | None = None):
+    """Run a basic inference: returns DataArray(time = n + 1, channel, lat, lon); entry 0 is the state at ``time``.
+    ``deliver`` (skyrim_amd/deliver.py; ``rollout`` sets it for the steps of a saving rollout): "be" = bring only the big-endian image
+    of the states to the host (the file's bytes; native ``values`` are filled from it on first read), "both" = native and image."""
     counters = model.__dict__.setdefault("io_counters", {"state_uploads": 0, "resident_hits": 0}) if hasattr(model, "__dict__") else {}
     resident = getattr(model, "_resident_state", None)
     if hasattr(model, "__dict__"):
@@ -68,25 +70,43 @@ def run_basic_inference(model, n: int, data_source: Any, time: datetime, x=None)
     # through a copy stream, so the D2H of step k overlaps the forward of step k + 1; the result is the same array.
     loop = model(time, x)
     try:
-        return _drain(model, loop, n, time)
+        return _drain(model, loop, n, time, deliver)
     finally:
         if hasattr(loop, "close"):
             loop.close()        # lets the TimeLoop flush its deferred checks (FiniteGuard: the last yielded state) -- may raise; also runs
                                 # when the loop body itself raised, so that a generator is never left to the garbage collector
 
 
-def _drain(model, loop, n: int, time):
-    times, stacked, arrays, side, last = [], None, [], None, []
+def _drain(model, loop, n: int, time, deliver=None):
+    from ... import deliver as D
+    times, stacked, arrays, side, last, be = [], None, [], None, [], None
     for k, (time, output, _) in enumerate(loop):
         out = output.squeeze(0) if output.dim() == 4 and output.shape[0] == 1 else output
         if out.is_cuda:
             if stacked is None:
                 pin = (n + 1) * out.numel() * 4 <= _PINNED_LIMIT
-                stacked = torch.empty((n + 1,) + tuple(out.shape), dtype=torch.float32, pin_memory=pin)
+                shape = (n + 1,) + tuple(out.shape)
                 side = torch.cuda.Stream(out.device)
+                if deliver in ("be", "both") and pin and out.dtype == torch.float32 and D.enabled():
+                    D.load_library()                                   # (a missing library is an error here, not a silent host swap)
+                    be = torch.empty(shape, dtype=torch.float32, pin_memory=True)
+                else:
+                    deliver = None
+                # "be": no copy lands in the native array -- plain pageable memory that stays untouched (no page behind it) unless
+                # somebody reads ``values``; one pinned block per prediction in flight, as without the image
+                stacked = torch.from_numpy(np.empty(shape, dtype=np.float32)) if deliver == "be" else torch.empty(shape, dtype=torch.float32, pin_memory=pin)
             side.wait_stream(torch.cuda.current_stream(out.device))
             with torch.cuda.stream(side):
-                stacked[k].copy_(out, non_blocking=True)
+                if deliver != "be":
+                    stacked[k].copy_(out, non_blocking=True)
+                if be is not None:
+                    # the bytes of the file: swapped in HBM on the copy stream (0.1 ms beside the next step's kernels), then the same
+                    # device-to-host copy as the native one
+                    src = out.contiguous()
+                    swapped = torch.empty_like(src)
+                    D.bswap32(src, swapped, side)
+                    be[k].copy_(swapped, non_blocking=True)
+                    del src, swapped
             out.record_stream(side)
             last = (last + [output if output.dim() == 4 else output.unsqueeze(0)])[-model.n_history_levels:]
         else:
@@ -96,7 +116,7 @@ def _drain(model, loop, n: int, time):
             break
     if hasattr(loop, "close"):
         loop.close()            # flush BEFORE the result is built: a non-finite last state must not be delivered
-    ready = None
+    ready = image = None
     if stacked is not None:
         # The last state's copy is still in flight on the side stream.  The array is handed over now and the DataArray waits for the
         # copy's event the first time its numbers are read (labeled.DataArray.values): ``rollout`` feeds the prediction straight back
@@ -107,7 +127,13 @@ def _drain(model, loop, n: int, time):
         pinned = stacked.is_pinned()
         keep = stacked                              # the tensor owns the pinned block: it must outlive the numpy view
         stacked = stacked[:len(times)].numpy()
-        if pinned:
+        if be is not None:
+            image = D.BigEndianImage(be[:len(times)].numpy().view(">f4"), of=stacked, wait=done.synchronize, keep=be)
+        if deliver == "be":
+            # nothing was copied into ``stacked``: whoever reads ``values`` gets them from the image, swapped back on the host (a second,
+            # writable view of the block -- ``stacked`` itself goes read-only in ResidentState)
+            ready = lambda img=image, dst=keep[:len(times)].numpy(), _keep=keep: img.fill_native(dst)    # noqa: E731
+        elif pinned:
             ready = lambda ev=done, _keep=keep: ev.synchronize()    # noqa: E731
         else:
             done.synchronize()
@@ -116,7 +142,7 @@ def _drain(model, loop, n: int, time):
     else:
         stacked = np.stack(arrays)
     coords = dict(time=times, channel=model.out_channel_names, lat=np.asarray(model.grid.lat), lon=np.asarray(model.grid.lon))
-    return DataArray(stacked, dims=["time", "channel", "lat", "lon"], coords=coords, ready=ready)
+    return DataArray(stacked, dims=["time", "channel", "lat", "lon"], coords=coords, ready=ready, image=image)
 
 
 def estimate_pressure_hpa(elevation_m):

@@ -45,13 +45,16 @@ class Coordinate:
 
 
 class DataArray:
-    def __init__(self, data, dims: Iterable[str], coords: dict[str, Any] | None = None, name: str | None = None, ready=None):
+    def __init__(self, data, dims: Iterable[str], coords: dict[str, Any] | None = None, name: str | None = None, ready=None, image=None):
         """``ready``: a callable that returns once ``data`` holds its final contents (run_basic_inference hands over a pinned host
         buffer whose device-to-host copy may still be in flight, with the copy's event wait as ``ready``).  It is called the first
         time ``values`` is read -- shape, dims and coordinates never wait -- so a prediction fed straight back into the next step
-        (``rollout``) lets its copy overlap that step; whoever reads the numbers (the save thread, the caller) waits first."""
+        (``rollout``) lets its copy overlap that step; whoever reads the numbers (the save thread, the caller) waits first.
+        ``image``: the same numbers as a big-endian host image (deliver.BigEndianImage) for the netCDF writer, which then never reads
+        ``values``; it belongs to this object and this array only -- assigning ``values`` drops it, derived arrays do not inherit it."""
         self._values = np.asarray(data)
         self._ready = ready
+        self._image = image
         self.dims = tuple(dims)
         if len(self.dims) != self._values.ndim:
             raise ValueError(f"{len(self.dims)} dims for a {self._values.ndim}-d array")
@@ -73,7 +76,7 @@ class DataArray:
 
     @values.setter
     def values(self, v):
-        self._values, self._ready = np.asarray(v), None
+        self._values, self._ready, self._image = np.asarray(v), None, None
 
     # -- basic accessors --------------------------------------------------- #
     @property

@@ -110,3 +110,16 @@ def test_custom_ops_are_registered_and_have_no_cpu_kernel():
     schema = torch.ops.skyrim_hip.pangu_step.default._schema
     assert str(schema) == "skyrim_hip::pangu_step(int ctx, Tensor x, Tensor(a!) out) -> ()"
     ops.register()          # idempotent
+
+
+def test_io_library_exports_every_declared_symbol():
+    """include/skyrim_io.h (the delivery helpers of the save path): every declared entry point is exported, versions agree."""
+    from skyrim_amd import deliver as D
+    text = re.sub(r"/\*.*?\*/", "", (HEADER.parent / "skyrim_io.h").read_text(), flags=re.S)
+    syms = sorted(set(re.findall(r"\b(skio_[a-z0-9_]+)\s*\(", text)))
+    lib = D.load_library()
+    assert syms == sorted(D.EXPORTS) and len(syms) == 2
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in skyrim_io.h but not exported"
+    assert lib.skio_abi_version() == D.ABI_VERSION == int(re.search(r"SKIO_ABI_VERSION (\d+)", text).group(1))
+    assert lib.skio_bswap32(None, None, 0, None) == 0 and lib.skio_bswap32(None, None, 4, None) == -1      # argument checks run without a GPU

@@ -205,6 +205,8 @@ def test_ensemble_rollout_on_real_engines_writes_the_mean_files_and_frees_each_m
     g = PanguGeometry(49, 192)
     cfg = SfnoConfig(n_lat=49, n_lon=192, embed_dim=32, num_layers=3, scale_factor=2)
     ens = GlobalEnsemble(["pangu", "fourcastnet_v2"], ic_source="synthetic", model_kwargs={"pangu": dict(geom=g), "fourcastnet_v2": dict(cfg=cfg)})
+    import gc
+    gc.collect()                                  # engines of earlier tests still waiting for the collector would be freed mid-test by release_model's own gc
     torch.cuda.synchronize()
     torch.cuda.empty_cache()
     base, seen, peak = torch.cuda.memory_allocated(), [], []
@@ -230,3 +232,66 @@ def test_ensemble_rollout_on_real_engines_writes_the_mean_files_and_frees_each_m
         assert np.allclose(got.values, want, rtol=1e-6, atol=1e-6)
     assert np.allclose(open_dataarray(paths[-1]).values, mean.values, rtol=1e-6, atol=1e-6)
     assert GlobalEnsemblePrediction(paths[-1]).prediction.shape == mean.shape
+
+
+def test_bswap32_kernel_against_numpy():
+    """skio_bswap32 (include/skyrim_io.h): every word byte-reversed, vector body and scalar tail, unaligned starts, in place."""
+    from skyrim_amd import deliver as D
+    side = torch.cuda.Stream()
+    for n, off in ((1, 0), (3, 0), (4, 0), (1027, 0), (1027, 1), (1 << 20, 0), ((1 << 20) + 5, 3)):
+        src = torch.randn(n + off, device="cuda")[off:]
+        dst = torch.empty(n + off, device="cuda")[off:]
+        side.wait_stream(torch.cuda.current_stream())
+        D.bswap32(src, dst, side)
+        side.synchronize()
+        want = src.cpu().numpy().byteswap()
+        assert np.array_equal(dst.cpu().numpy().view(np.uint32), want.view(np.uint32)), (n, off)
+    x = torch.randn(4099, device="cuda")
+    want = x.cpu().numpy().byteswap()
+    D.bswap32(x, x, torch.cuda.current_stream())
+    torch.cuda.synchronize()
+    assert np.array_equal(x.cpu().numpy().view(np.uint32), want.view(np.uint32))
+    with pytest.raises(ValueError):
+        D.bswap32(x, x[:10], torch.cuda.current_stream())
+    with pytest.raises(ValueError):
+        D.bswap32(x.double(), x.double(), torch.cuda.current_stream())
+
+
+def test_saving_rollout_delivers_the_bytes_of_its_files(tmp_path, monkeypatch):
+    """``rollout(save=True)`` (reference base.py:134-143 -> common.py:144): the per-step netCDF files written from the big-endian image
+    produced in HBM are byte-identical to the files of the host-swapping path (SKYRIM_SAVE_BE=0); intermediate steps bring only the
+    image to the host, the state stays resident, and a reader of their ``values`` still gets the numbers."""
+    from skyrim_amd import ncio
+    from skyrim_amd.core.models.pangu import PanguModel
+    from skyrim_amd.core.models.utils import run_basic_inference
+    from skyrim_amd.pangu.spec import PanguGeometry, init_synthetic
+    g = PanguGeometry(49, 192)
+    m = PanguModel(ic_source="synthetic", geom=g, params=init_synthetic(g, 0))
+    monkeypatch.setattr(ncio, "FAST_PAYLOAD_BYTES", 0)               # toy payloads (5 MB) through the large-payload writers
+    calls = {"image": 0, "host": 0}
+    image_w, host_w = ncio._image_payload_write, ncio._parallel_payload_write
+    monkeypatch.setattr(ncio, "_image_payload_write", lambda *a, **k: (calls.__setitem__("image", calls["image"] + 1), image_w(*a, **k))[1])
+    monkeypatch.setattr(ncio, "_parallel_payload_write", lambda *a, **k: (calls.__setitem__("host", calls["host"] + 1), host_w(*a, **k))[1])
+    ic = m.predict_one_step(T0)
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("SKYRIM_SAVE_BE", mode)
+        before = dict(calls)
+        pred, paths = m.rollout(T0, n_steps=3, save=True, save_config={"output_dir": str(tmp_path / mode), "forecast_id": "x"}, initial_condition=ic)
+        out[mode] = (np.array(pred.values), [Path(p) for p in paths])
+        assert (calls["image"] - before["image"], calls["host"] - before["host"]) == ((3, 0) if mode == "1" else (0, 3))
+        assert (pred.__dict__["_image"] is not None) == (mode == "1")
+    assert np.array_equal(out["0"][0], out["1"][0])
+    for a, b in zip(out["0"][1], out["1"][1]):
+        assert a.name == b.name and a.read_bytes() == b.read_bytes()
+    # an intermediate step as the rollout asks for it: nothing but the image crosses to the host, the numbers appear on first read
+    both = run_basic_inference(m.model, 1, m.data_source, T0, ic, deliver="both")
+    only = run_basic_inference(m.model, 1, m.data_source, T0, ic, deliver="be")
+    uploads = m.model.io_counters["state_uploads"]
+    assert only.__dict__["_ready"] is not None and only.__dict__["_image"] is not None
+    nxt = run_basic_inference(m.model, 1, m.data_source, T0, only)                     # fed back without a read: resident, no upload
+    assert m.model.io_counters["state_uploads"] == uploads and only.__dict__["_ready"] is not None
+    assert np.array_equal(only.values, both.values) and only.__dict__["_ready"] is None
+    assert np.array_equal(np.asarray(both.__dict__["_image"].array, dtype=np.float32), both.values)
+    ref = run_basic_inference(m.model, 1, m.data_source, T0, both)
+    assert np.array_equal(nxt.values, ref.values)

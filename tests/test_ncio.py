@@ -86,3 +86,55 @@ def test_fast_path_failures_never_leave_a_half_written_file(tmp_path, monkeypatc
     with pytest.raises(OSError):
         ncio.write_dataarray_netcdf3(da, tmp_path / "enospc.nc", fast_threshold=0)
     assert not (tmp_path / "enospc.nc").exists() and not (tmp_path / "enospc.nc.part").exists()
+
+
+def _with_image(da):
+    """``da`` as a saving rollout delivers an intermediate step: the native array allocated but NOT filled, the numbers present only as
+    the big-endian image (skyrim_amd/deliver.py); ``values`` fills the native array from the image on first read."""
+    from skyrim_amd.deliver import BigEndianImage
+    truth = da.values.copy()
+    be = truth.astype(">f4")
+    native = np.full_like(truth, np.nan)
+    waited = []
+    image = BigEndianImage(be, of=native, wait=lambda: waited.append(1))
+    alias = native[...]                                             # the writable view the fill goes through
+    out = DataArray(native, da.dims, dict(da._coords), ready=lambda: image.fill_native(alias), image=image)
+    native.flags.writeable = False                                  # as ResidentState leaves a delivered array
+    return out, truth, waited
+
+
+def test_a_delivered_big_endian_image_is_written_as_it_is(tmp_path):
+    """The file of a prediction that carries its big-endian image: byte-identical to the plain writer's, written without reading (hence
+    without filling) the native array; the image is dropped when the array is replaced, and derived arrays do not inherit it."""
+    da = _da((2, 9, 181, 360), seed=3)
+    ncio.write_dataarray_netcdf3(da, tmp_path / "plain.nc", fast_threshold=1 << 60)
+    img, truth, waited = _with_image(da)
+    ncio.write_dataarray_netcdf3(img, tmp_path / "image.nc", fast_threshold=0)
+    assert filecmp.cmp(tmp_path / "plain.nc", tmp_path / "image.nc", shallow=False)
+    assert waited == [1] and img.__dict__["_ready"] is not None and np.isnan(img.__dict__["_values"]).all()      # nobody read ``values``
+    # a reader gets the numbers, filled from the image once
+    assert np.array_equal(img.values, truth) and img.__dict__["_ready"] is None
+    # below the fast-path threshold the plain writer runs: it reads ``values`` (filled from the image)
+    small, truth_s, _ = _with_image(_da())
+    ncio.write_dataarray_netcdf3(small, tmp_path / "small.nc")
+    assert np.array_equal(open_dataarray(str(tmp_path / "small.nc")).values, truth_s)
+    # derived arrays and assigned values never use a stale image
+    img2, truth2, _ = _with_image(da)
+    sel = img2.isel(channel=[0, 2])
+    assert sel.__dict__.get("_image") is None and np.array_equal(sel.values, truth2[:, [0, 2]])
+    img3, truth3, _ = _with_image(da)
+    img3.values = truth3 * 2
+    assert img3.__dict__["_image"] is None
+    ncio.write_dataarray_netcdf3(img3, tmp_path / "doubled.nc", fast_threshold=0)
+    assert np.array_equal(open_dataarray(str(tmp_path / "doubled.nc")).values, truth3 * 2)
+
+
+def test_an_image_of_another_array_is_refused():
+    from skyrim_amd.deliver import BigEndianImage
+    a = np.zeros((2, 3), np.float32)
+    with pytest.raises(ValueError):
+        BigEndianImage(a.astype(">f4")[:1], of=a)
+    with pytest.raises(ValueError):
+        BigEndianImage(a, of=a)                                     # native byte order is not an image
+    image = BigEndianImage(a.astype(">f4"), of=a)
+    assert image.mirrors(a) and not image.mirrors(a.copy())

@@ -35,7 +35,36 @@ def writers():
     print(json.dumps({"writer_ms_573MB": out, "round_trip": bool(ok), "cpus": os.cpu_count()}))
 
 
+def first_touch():
+    """573 MB per file into tmpfs with plain pwrite, N files at once, three rounds each (files deleted in between): round 0 of a fresh
+    box allocates guest memory nobody touched before, the later rounds reuse it."""
+    from concurrent.futures import ThreadPoolExecutor
+    n = 2 * 69 * 721 * 1440 * 4
+    mv = memoryview(np.random.default_rng(0).integers(0, 255, n, dtype=np.uint8))
+    base = "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp"
+
+    def wr(i):
+        fd = os.open(f"{base}/skyrim_touch_{i}.bin", os.O_RDWR | os.O_CREAT | os.O_TRUNC)
+        off = 0
+        while off < n:
+            off += os.pwrite(fd, mv[off:off + (64 << 20)], off)
+        os.close(fd)
+    out = {}
+    for files in (1, 2, 4, 8, 16):
+        for r in range(3):
+            t = time.perf_counter()
+            with ThreadPoolExecutor(files) as ex:
+                list(ex.map(wr, range(files)))
+            dt = time.perf_counter() - t
+            out[f"files{files}_round{r}"] = {"ms_per_file": round(1e3 * dt / files, 1), "GBps": round(files * n / dt / 1e9, 1)}
+            for i in range(files):
+                os.unlink(f"{base}/skyrim_touch_{i}.bin")
+    print(json.dumps({"first_touch_vs_reuse": out}))
+
+
 def main():
+    if "--touch" in sys.argv:
+        first_touch()
     if "--no-writers" not in sys.argv:
         writers()
     if "--writers-only" in sys.argv:
@@ -50,7 +79,7 @@ def main():
     for workers, threads in matrix:
         os.environ["SKYRIM_NC_THREADS"], os.environ["SKYRIM_SAVE_WORKERS"] = threads, workers
         r = bench.predict_inclusive(DEFAULT_PRECISION, g, params, torch.device("cuda", 0))
-        print(json.dumps({"SKYRIM_NC_THREADS": threads, "SKYRIM_SAVE_WORKERS": workers, "no_save_ms": round(r["no_save"]["ms_per_step"], 2), "save_ms": round(r["save"]["ms_per_step"], 2),
+        print(json.dumps({"SKYRIM_NC_THREADS": threads, "SKYRIM_SAVE_WORKERS": workers, "no_save_ms": round(r["no_save"]["ms_per_step"], 2), "save_ms": round(r["save"]["ms_per_step"], 2), "save_first_rollout_ms": round(r["save_first_rollout"]["ms_per_step"], 2),
                           "io_counters": r["io_counters"]}))
 
 
