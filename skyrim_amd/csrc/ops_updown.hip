@@ -14,7 +14,9 @@ hipError_t op_down(const Geom& g, const ModelW<typename P::T>& w, const typename
     a.ep = EP{nullptr, 384, 0, X2s, wk.xs_plane[1]};
     a.W = w.down.w; a.w_plane = w.down.plane; a.ldw = w.down.ldw;
     a.M = g.ntok[1]; a.N = 384; a.K = 768;
-    return launch_gemm<P, typename Tiles<P>::L384>(a, s);      // whole N per block: the merged + normalised A rows are produced once
+    // whole N per block: the merged + normalised A rows are produced once; 128 of them per block: a k-step's 48 KiB weight tile (hi + lo) comes
+    // from L2 once per 128 rows -- with 64-row blocks that traffic (2.3 GB per launch) was the bound: 0.45 -> 0.33 ms (docs/experiments.md A6.6)
+    return launch_gemm<P, typename Tiles<P>::D384>(a, s);
 }
 
 template <class P>
