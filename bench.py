@@ -326,8 +326,9 @@ def predict_inclusive(precision, geom, params, dev, n_steps=8):
                 # ... and torch's pinned-block cache holds one block per prediction that can be in flight (the first rollout stalls on its
                 # own allocations, so it never has that many at once: tools/save_timeline.py shows a 45 - 90 ms hipHostMalloc inside a
                 # later rollout's step otherwise)
-                blocks = [torch.empty(tuple(pred.shape), dtype=torch.float32, pin_memory=True) for _ in range(in_flight)]
-                del blocks
+                for entries in (1, pred.shape[0]):       # an intermediate step's image holds the new state only, the last step's arrays the pair
+                    blocks = [torch.empty((entries,) + tuple(pred.shape[1:]), dtype=torch.float32, pin_memory=True) for _ in range(in_flight)]
+                    del blocks
             torch.cuda.synchronize()
             t = time.perf_counter()
             pred, paths = m.rollout(t0, n_steps=n_steps, save=save, save_config={"output_dir": d}, initial_condition=pred)
@@ -341,8 +342,9 @@ def predict_inclusive(precision, geom, params, dev, n_steps=8):
     from skyrim_amd import deliver
     out["big_endian_image"] = deliver.enabled()
     out["note"] = (f"GlobalModel.rollout(n_steps={n_steps}, initial_condition=<the previous prediction>) through the reference-shaped API: the state stays in "
-                   "HBM (io_counters: one upload, the initial condition of the warm-up); no_save: every step's (t, t + 6 h) pair copied to pinned host memory "
-                   "on a copy stream, the copy of step k running under step k + 1 (the delivered array waits for it when its numbers are read); "
+                   "HBM (io_counters: one upload, the initial condition of the warm-up) and the host never waits for the GPU between two steps (a step's "
+                   "non-finite flag is read with its copy); no_save: only the last prediction's (t, t + 6 h) pair is copied to the host -- what the "
+                   "call returns; "
                    f"save: one netCDF-3 file of 573 MB per step ({'tmpfs' if base else 'tmp dir'}); the pair is byte-swapped in HBM (skio_bswap32) and it is that "
                    "big-endian image that crosses to pinned memory (intermediate steps: instead of the native copy; last step: both), so the save threads only "
                    "pwrite while the next steps run (SKYRIM_SAVE_BE=0: native copy, swapped by the save threads). save = the second saving rollout of the "

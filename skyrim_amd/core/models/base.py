@@ -21,7 +21,8 @@ from .utils import run_basic_inference
 
 logger = logging.getLogger("skyrim_amd")
 
-SAVE_WORKERS = 6          # per-step netCDF files written at once by ``rollout`` (SKYRIM_SAVE_WORKERS; measured in ncio.py / tools/predict_cost.py)
+STEPS_AHEAD = 3           # steps ``rollout`` lets the host queue in front of the GPU
+SAVE_WORKERS = 8          # per-step netCDF files written at once by ``rollout`` (SKYRIM_SAVE_WORKERS; one file is one pwrite stream of ~6 GB/s, files side by side scale: docs/experiments.md A6.5)
 
 
 def adjust_lead_time(lead_time: int, step_size: int = 6):
@@ -91,10 +92,22 @@ class GlobalModel:
 
     def predict_one_step(self, start_time: datetime.datetime, initial_condition=None) -> DataArray:
         # if initial_condition is None, it is fetched from the self.ic_source
-        return self._predict_one_step(start_time, initial_condition, None)
+        return self._step_delivering(start_time, initial_condition, None)
 
-    def _predict_one_step(self, start_time, initial_condition, deliver) -> DataArray:
-        return run_basic_inference(model=self.model, n=1, data_source=self.data_source, time=start_time, x=initial_condition, deliver=deliver)
+    def _mark_step(self):
+        """An event behind everything queued so far on the model's GPU (None for a model that is not on one)."""
+        import torch
+        dev = getattr(self.model, "device", None)
+        if dev is None or torch.device(dev).type != "cuda":
+            return None
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(torch.device(dev)))
+        return ev
+
+    def _step_delivering(self, start_time, initial_condition, deliver, defer_check=False) -> DataArray:
+        # (not ``_predict_one_step``: the GraphCast wrapper has a method of that name, as the reference's does)
+        return run_basic_inference(model=self.model, n=1, data_source=self.data_source, time=start_time, x=initial_condition, deliver=deliver,
+                                   defer_check=defer_check)
 
     def forecast(self, start_time: datetime.datetime, n_steps: int = 3, channels: List[str] = []):
         da = run_basic_inference(model=self.model, n=n_steps, data_source=self.data_source, time=start_time, x=None)
@@ -131,12 +144,23 @@ class GlobalModel:
         # are produced in HBM and copied to the host as they will lie in the file (skyrim_amd/deliver.py): the save threads only pwrite.
         # Intermediate steps bring ONLY that image over PCIe -- the next step reads the state from HBM, nobody reads their ``values``
         # (which would be filled from the image on demand); the last step, returned to the caller, brings both.
-        image = netcdf_local and cfg.get("mapping_func") is None and not cfg.get("filter_vars") \
-            and type(self).predict_one_step is GlobalModel.predict_one_step
+        own_step = type(self).predict_one_step is GlobalModel.predict_one_step       # (an overriding subclass is called as the reference would)
+        image = netcdf_local and cfg.get("mapping_func") is None and not cfg.get("filter_vars") and own_step
+        # The loop never waits for the GPU: a step's non-finite check is read with its copy to the host -- by the save thread, whose
+        # exception stops the rollout below, or at the end of the rollout -- instead of between two steps, where the host would sit
+        # out every step before queueing the next (17.4 -> 14.6 ms per step at 721x1440, the engine's own pace).
+        ahead = []
         try:
             for n in range(n_steps):
-                if image:
-                    pred = self._predict_one_step(start_time, pred, "be" if n < n_steps - 1 else "both")
+                if own_step:
+                    last = n == n_steps - 1
+                    deliver = ("both" if last else "be") if image else (None if last or save else "skip")
+                    pred = self._step_delivering(start_time, pred, deliver, defer_check=True)
+                    ahead.append(self._mark_step())
+                    if len(ahead) > STEPS_AHEAD:                   # the host queues at most STEPS_AHEAD steps in front of the GPU (each holds its output buffer)
+                        mark = ahead.pop(0)
+                        if mark is not None:
+                            mark.synchronize()
                 else:
                     pred = self.predict_one_step(start_time, initial_condition=pred)
                 pred_time = start_time + self.time_step
@@ -150,6 +174,8 @@ class GlobalModel:
                 start_time, source = pred_time, "file"
                 logger.info(f"Rollout step {n + 1}/{n_steps} completed")
             output_paths = [f.result() for f in pending]         # re-raises a writer's exception here, in step order
+            if own_step and n_steps > 0 and isinstance(pred, DataArray):
+                pred.values                                      # the last state's copy and check: a rollout returns numbers that passed it
         finally:
             if pool is not None:
                 pool.shutdown(wait=True)

@@ -57,15 +57,15 @@ def bswap32(src, dst, stream) -> None:
         raise RuntimeError(f"skio_bswap32 failed ({rc})")
 
 
-class BigEndianImage:
-    """The payload of a delivered DataArray as the file wants it: ``array`` is a ``>f4`` view (same shape as the DataArray) of a pinned
-    host block whose device-to-host copy may still be in flight; ``wait()`` returns once it has landed.  ``of`` remembers which native
-    array the image mirrors: the writer uses the image only while the DataArray still carries that very array."""
+class ImagePart:
+    """Consecutive time entries of a prediction in file byte order: a C-contiguous ``>f4`` array in (pinned) host memory, the wait for its
+    device-to-host copy, and whatever owns the memory."""
+    __slots__ = ("array", "_wait", "keep")
 
-    def __init__(self, array: np.ndarray, of: np.ndarray, wait=None, keep=None):
-        if array.dtype != np.dtype(">f4") or array.shape != of.shape:
-            raise ValueError(f"big-endian image {array.dtype} {array.shape} for a {of.dtype} {of.shape} array")
-        self.array, self._of, self._wait, self._keep = array, of, wait, keep
+    def __init__(self, array: np.ndarray, wait=None, keep=None):
+        if array.dtype != np.dtype(">f4") or not array.flags.c_contiguous:
+            raise ValueError(f"an image part is a C-contiguous big-endian float32 array, not {array.dtype} (contiguous: {array.flags.c_contiguous})")
+        self.array, self._wait, self.keep = array, wait, keep
 
     def wait(self) -> None:
         w = self._wait
@@ -73,13 +73,54 @@ class BigEndianImage:
             w()
             self._wait = None
 
+    def tail(self, rows: int) -> "ImagePart":
+        return ImagePart(self.array[self.array.shape[0] - rows:], self._wait, self.keep)
+
+
+class BigEndianImage:
+    """The payload of a delivered DataArray as the file wants it: ``>f4`` parts that follow each other along the first (time) axis, in
+    pinned host memory whose device-to-host copies may still be in flight; ``wait()`` returns once they have landed.  ``of`` remembers
+    which native array the image mirrors: the writer uses the image only while the DataArray still carries that very array.
+    ``head``: parts in front of ``array`` -- in a rollout the state a step starts from IS the previous step's prediction, whose image is
+    already on the host: the new image borrows those bytes (``tail``) instead of bringing them over again."""
+
+    def __init__(self, array: np.ndarray, of: np.ndarray, wait=None, keep=None, head=()):
+        self.parts = list(head) + [ImagePart(array, wait, keep)]
+        rows = sum(p.array.shape[0] for p in self.parts)
+        if any(p.array.shape[1:] != of.shape[1:] for p in self.parts) or rows != of.shape[0]:
+            raise ValueError(f"big-endian image of {[p.array.shape for p in self.parts]} for a {of.dtype} {of.shape} array")
+        self._of = of
+
+    @property
+    def array(self) -> np.ndarray:
+        """The whole image as one array (a copy when it has several parts: tests and diagnostics, not the writer)."""
+        return self.parts[0].array if len(self.parts) == 1 else np.concatenate([p.array for p in self.parts])
+
+    def wait(self) -> None:
+        for p in self.parts:
+            p.wait()
+
+    def segments(self) -> list:
+        """The bytes of the payload in file order (after ``wait``)."""
+        self.wait()
+        return [memoryview(p.array.reshape(-1).view(np.uint8)) for p in self.parts]
+
     def mirrors(self, values: np.ndarray) -> bool:
         return values is self._of
+
+    def tail(self, rows: int = 1) -> "ImagePart | None":
+        """The last ``rows`` time entries as a part another image can start with (None when they straddle two parts)."""
+        last = self.parts[-1]
+        return last.tail(rows) if last.array.shape[0] >= rows else None
 
     def fill_native(self, out: np.ndarray) -> None:
         """``out`` (native float32, same shape) = the image's numbers: the host-side swap the default path never needs."""
         self.wait()
-        np.copyto(out, self.array)
+        r = 0
+        for p in self.parts:
+            n = p.array.shape[0]
+            np.copyto(out[r:r + n], p.array)
+            r += n
 
 
 def enabled() -> bool:

@@ -148,7 +148,7 @@ def _unlink(p):
 def _image_of(da):
     """The big-endian host image a delivered prediction carries (deliver.BigEndianImage), if it still mirrors the array ``da`` holds."""
     image, raw = da.__dict__.get("_image"), da.__dict__.get("_values")
-    if image is None or raw is None or not image.mirrors(raw) or not image.array.flags.c_contiguous:
+    if image is None or raw is None or not image.mirrors(raw):
         return None
     return image
 
@@ -158,13 +158,13 @@ def _image_payload_write(path, offset: int, image):
     inode whatever the thread count, so there is nothing to split; the throughput of a rollout comes from its files being written side
     by side (core/models/base.py SAVE_WORKERS)."""
     import os
-    image.wait()
-    mv, off = memoryview(image.array.reshape(-1).view(np.uint8)), offset
+    off = offset
     fd = os.open(str(path), os.O_RDWR)
     try:
-        while len(mv):
-            w = os.pwrite(fd, mv[:64 << 20], off)
-            mv, off = mv[w:], off + w
+        for mv in image.segments():                       # (one per part of the image: the state the step started from, the states it produced)
+            while len(mv):
+                w = os.pwrite(fd, mv[:64 << 20], off)
+                mv, off = mv[w:], off + w
     finally:
         os.close(fd)
 

@@ -36,6 +36,12 @@ class FiniteGuard:
         self.check()
         self.pending = (torch.isfinite(state).all(), step)
 
+    def take(self):
+        """The pending (flag tensor, step) -- or None -- handed to a caller that reads it later, together with the state's copy to the host
+        (core/models/utils.py: a rollout never waits for a step it does not look at); nothing is left for ``check``."""
+        pending, self.pending = self.pending, None
+        return pending
+
     def check(self):
         if self.pending is not None:
             flag, step = self.pending

@@ -257,17 +257,11 @@ def test_bswap32_kernel_against_numpy():
         D.bswap32(x.double(), x.double(), torch.cuda.current_stream())
 
 
-def test_saving_rollout_delivers_the_bytes_of_its_files(tmp_path, monkeypatch):
-    """``rollout(save=True)`` (reference base.py:134-143 -> common.py:144): the per-step netCDF files written from the big-endian image
-    produced in HBM are byte-identical to the files of the host-swapping path (SKYRIM_SAVE_BE=0); intermediate steps bring only the
-    image to the host, the state stays resident, and a reader of their ``values`` still gets the numbers."""
+def _rollouts_with_and_without_the_image(m, tmp_path, monkeypatch, n_steps=3):
+    """``m.rollout(save=True)`` twice from one initial condition -- host swap (SKYRIM_SAVE_BE=0), then the big-endian image -- with the toy
+    payloads forced through the large-payload writers; returns {mode: (final values, paths)} after checking which writer ran."""
     from skyrim_amd import ncio
-    from skyrim_amd.core.models.pangu import PanguModel
-    from skyrim_amd.core.models.utils import run_basic_inference
-    from skyrim_amd.pangu.spec import PanguGeometry, init_synthetic
-    g = PanguGeometry(49, 192)
-    m = PanguModel(ic_source="synthetic", geom=g, params=init_synthetic(g, 0))
-    monkeypatch.setattr(ncio, "FAST_PAYLOAD_BYTES", 0)               # toy payloads (5 MB) through the large-payload writers
+    monkeypatch.setattr(ncio, "FAST_PAYLOAD_BYTES", 0)
     calls = {"image": 0, "host": 0}
     image_w, host_w = ncio._image_payload_write, ncio._parallel_payload_write
     monkeypatch.setattr(ncio, "_image_payload_write", lambda *a, **k: (calls.__setitem__("image", calls["image"] + 1), image_w(*a, **k))[1])
@@ -277,21 +271,97 @@ def test_saving_rollout_delivers_the_bytes_of_its_files(tmp_path, monkeypatch):
     for mode in ("0", "1"):
         monkeypatch.setenv("SKYRIM_SAVE_BE", mode)
         before = dict(calls)
-        pred, paths = m.rollout(T0, n_steps=3, save=True, save_config={"output_dir": str(tmp_path / mode), "forecast_id": "x"}, initial_condition=ic)
+        pred, paths = m.rollout(T0, n_steps=n_steps, save=True, save_config={"output_dir": str(tmp_path / mode), "forecast_id": "x"}, initial_condition=ic)
         out[mode] = (np.array(pred.values), [Path(p) for p in paths])
-        assert (calls["image"] - before["image"], calls["host"] - before["host"]) == ((3, 0) if mode == "1" else (0, 3))
-        assert (pred.__dict__["_image"] is not None) == (mode == "1")
+        assert (calls["image"] - before["image"], calls["host"] - before["host"]) == ((n_steps, 0) if mode == "1" else (0, n_steps))
+        image = pred.__dict__["_image"]
+        assert (image is not None) == (mode == "1")
+        if image is not None:                        # steps after the first borrow the state they start from out of the previous image
+            assert len(image.parts) == 2 and [p.array.shape[0] for p in image.parts] == [1, 1]
+            assert np.array_equal(np.asarray(image.array, dtype=np.float32), pred.values)
+    monkeypatch.delenv("SKYRIM_SAVE_BE")
     assert np.array_equal(out["0"][0], out["1"][0])
     for a, b in zip(out["0"][1], out["1"][1]):
         assert a.name == b.name and a.read_bytes() == b.read_bytes()
+    return ic
+
+
+def test_saving_rollout_delivers_the_bytes_of_its_files(tmp_path, monkeypatch):
+    """``rollout(save=True)`` (reference base.py:134-143 -> common.py:144): the per-step netCDF files written from the big-endian image
+    produced in HBM are byte-identical to the files of the host-swapping path (SKYRIM_SAVE_BE=0); intermediate steps bring only the
+    image of the NEW state to the host (the state they start from is the previous image's), the state stays resident, and a reader of
+    their ``values`` still gets the numbers."""
+    from skyrim_amd.core.models.pangu import PanguModel
+    from skyrim_amd.core.models.utils import run_basic_inference
+    from skyrim_amd.pangu.spec import PanguGeometry, init_synthetic
+    g = PanguGeometry(49, 192)
+    m = PanguModel(ic_source="synthetic", geom=g, params=init_synthetic(g, 0))
+    ic = _rollouts_with_and_without_the_image(m, tmp_path, monkeypatch)
     # an intermediate step as the rollout asks for it: nothing but the image crosses to the host, the numbers appear on first read
     both = run_basic_inference(m.model, 1, m.data_source, T0, ic, deliver="both")
     only = run_basic_inference(m.model, 1, m.data_source, T0, ic, deliver="be")
+    assert len(only.__dict__["_image"].parts) == 1                                     # (``ic`` was not resident: the whole pair came over)
     uploads = m.model.io_counters["state_uploads"]
     assert only.__dict__["_ready"] is not None and only.__dict__["_image"] is not None
-    nxt = run_basic_inference(m.model, 1, m.data_source, T0, only)                     # fed back without a read: resident, no upload
+    nxt = run_basic_inference(m.model, 1, m.data_source, T0, only, deliver="be")      # fed back without a read: resident, no upload
     assert m.model.io_counters["state_uploads"] == uploads and only.__dict__["_ready"] is not None
+    parts = nxt.__dict__["_image"].parts
+    assert len(parts) == 2 and parts[0].array.base is not None and np.shares_memory(parts[0].array, only.__dict__["_image"].parts[-1].array)
     assert np.array_equal(only.values, both.values) and only.__dict__["_ready"] is None
     assert np.array_equal(np.asarray(both.__dict__["_image"].array, dtype=np.float32), both.values)
     ref = run_basic_inference(m.model, 1, m.data_source, T0, both)
-    assert np.array_equal(nxt.values, ref.values)
+    assert np.array_equal(nxt.values, ref.values) and np.array_equal(nxt.values[0], only.values[1])
+
+
+def test_saving_rollout_image_on_the_sfno_wrapper_and_graphcast_keeps_its_own_loop(tmp_path, monkeypatch):
+    """The same byte-for-byte comparison through FourcastnetV2Model.  GraphcastModel drives its stepper itself, as the reference's wrapper
+    does (graphcast.py:93-142: own ``_predict_one_step`` / ``rollout``, synchronous saves): no image there, and the public
+    ``predict_one_step`` of the base class still reaches its TimeLoop."""
+    from skyrim_amd.core.models.fourcastnet_v2 import FourcastnetV2Model
+    from skyrim_amd.core.models.graphcast import GraphcastModel
+    from skyrim_amd.graphcast.spec import GraphcastConfig
+    from skyrim_amd.sfno.spec import SfnoConfig
+    sfno = FourcastnetV2Model(ic_source="synthetic", cfg=SfnoConfig(n_lat=49, n_lon=192, embed_dim=32, num_layers=3, scale_factor=2))
+    _rollouts_with_and_without_the_image(sfno, tmp_path / "sfno", monkeypatch)
+    gc = GraphcastModel(ic_source="synthetic", cfg=GraphcastConfig(n_lat=33, n_lon=64, splits=2, latent=32, steps=2))
+    one = gc.predict_one_step(T0)
+    assert one.values.shape[0] == 2 and one.__dict__.get("_image") is None and np.isfinite(one.values).all()
+    pred, paths = gc.rollout(T0, n_steps=2, save=True, save_config={"output_dir": str(tmp_path / "gc")})
+    assert len(paths) == 2 and all(Path(p).exists() for p in paths) and pred.__dict__.get("_image") is None
+
+
+def test_rollout_reads_a_steps_finite_check_with_its_copy_not_between_steps(tmp_path):
+    """``rollout`` never waits for the GPU between two steps: the non-finite flag of a step travels to the host behind the state and is read
+    by whoever reads the numbers.  A step that overflows still stops the rollout with the TimeLoop's FloatingPointError -- from the save
+    thread (no file, no partial file for that step) or at the end of a rollout that saves nothing; ``predict_one_step`` raises at once."""
+    from skyrim_amd.core.models.pangu import PanguModel
+    from skyrim_amd.pangu.spec import PanguGeometry, init_synthetic
+    g = PanguGeometry(49, 192)
+    m = PanguModel(ic_source="synthetic", geom=g, params=init_synthetic(g, 0))
+    ic = m.predict_one_step(T0)
+    good, calls = m.model.engine.step, []
+
+    def step(x, *a, **k):
+        calls.append(1)
+        y = good(x, *a, **k)
+        if len(calls) == 2:
+            y[3, 5, 7] = float("inf")
+        return y
+    m.model.engine.step = step
+    try:
+        with pytest.raises(FloatingPointError, match="after step 1"):
+            m.rollout(T0, n_steps=4, save=True, save_config={"output_dir": str(tmp_path), "forecast_id": "x"}, initial_condition=ic)
+        files = sorted(p.name for p in (tmp_path / "x").iterdir())
+        assert len(files) == 1 and files[0].endswith("20240513_18:00__20240514_00:00.nc"), files       # the first step's file, nothing of the second
+        calls.clear()
+        calls.append(1)                                                                                 # the FIRST step of this rollout overflows
+        with pytest.raises(FloatingPointError, match="after step 1"):
+            m.rollout(T0, n_steps=3, save=False, initial_condition=ic)
+        calls.clear()
+        calls.append(1)
+        with pytest.raises(FloatingPointError, match="after step 1"):
+            m.predict_one_step(T0, initial_condition=ic)
+    finally:
+        m.model.engine.step = good
+    pred, _ = m.rollout(T0, n_steps=2, save=False, initial_condition=ic)                                # and the model still works
+    assert np.isfinite(pred.values).all()

@@ -42,7 +42,7 @@ def main():
         setattr(obj, name, inner)
     wrap(ncio, "write_dataarray_netcdf3", "file")
     wrap(ncio, "_parallel_payload_write", "payload")
-    wrap(base.GlobalModel, "_predict_one_step", "step")
+    wrap(base.GlobalModel, "_step_delivering", "step")
     values = labeled.DataArray.values.fget
 
     def timed_values(self):
@@ -69,8 +69,9 @@ def main():
                 ev.append(("pin_alloc", threading.current_thread().name, t, time.perf_counter()))
     torch.empty = timed_empty
     if os.environ.get("PRIME_PINNED"):
-        blocks = [real_empty((2, 69, 721, 1440), dtype=torch.float32, pin_memory=True) for _ in range(int(os.environ["PRIME_PINNED"]))]
-        del blocks
+        for entries in (1, 2):             # an intermediate step's image holds one state (the other is borrowed), the last step's arrays two
+            blocks = [real_empty((entries, 69, 721, 1440), dtype=torch.float32, pin_memory=True) for _ in range(int(os.environ["PRIME_PINNED"]))]
+            del blocks
     t0 = datetime.datetime(2024, 1, 1)
     d = tempfile.mkdtemp(prefix="skyrim_tl_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
     try:
