@@ -129,7 +129,9 @@ def _drain(model, loop, n: int, time, deliver=None, head=None, defer_check=False
         if k == n:
             break
     verdict = None
-    if defer_check and stacked is not None and (be is not None or stacked.is_pinned()) and hasattr(model, "take_pending_check"):
+    if defer_check and stacked is not None and deliver == "skip" and hasattr(model, "take_pending_check"):
+        model.take_pending_check()      # this state reaches nobody: the check of the rollout's last step answers for it (non-finite values never leave the network again)
+    elif defer_check and stacked is not None and (be is not None or stacked.is_pinned()) and hasattr(model, "take_pending_check"):
         pend = model.take_pending_check()
         if pend is not None:    # the flag goes to the host behind the states, on the same stream: read after the same event
             flag, step, hint = pend
